@@ -1,0 +1,172 @@
+/*
+ * qed_splat.h -- C ABI of libqed_splat.so, the MI355X (gfx950) native replacement for the
+ * render hot path behind qed_splatter/model.py get_outputs() / get_loss_dict().
+ *
+ * The reference has NO native boundary of its own: its hot path is the single Python call
+ *     render, alpha, info = gsplat.rendering.rasterization(...)
+ * at /root/reference/qed_splatter/model.py:267-288 (gsplat is a third-party CUDA package, not
+ * vendored).  The entry points below are what a native FFI for that call decomposes into
+ * (SURVEY.md section 8b); each cites the piece of the reference call path it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless it is named h_*; all float data is fp32
+ *   - the caller (PyTorch) owns every buffer: the library never allocates or frees device
+ *     memory, never synchronises the stream and keeps no global mutable state besides a
+ *     thread-local error string -> re-entrant per stream, safe to capture into a hipGraph
+ *   - `stream` is a hipStream_t passed as void*
+ *   - return value: 0 = ok, <0 = error (see QED_E_*); qed_last_error() describes it
+ *   - C = cameras, N = Gaussians, M = tile/Gaussian intersections, T = tile_w * tile_h
+ *   - quaternions are wxyz; pixel centres are at (x + 0.5, y + 0.5); tile size is 16
+ */
+#ifndef QED_SPLAT_H
+#define QED_SPLAT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QED_OK 0
+#define QED_E_INVALID_ARG (-1)
+#define QED_E_WORKSPACE (-2)
+#define QED_E_LAUNCH (-3)
+#define QED_E_UNSUPPORTED (-4)
+
+#define QED_TILE 16             /* BLOCK_WIDTH = 16, model.py:243 */
+#define QED_SPLAT_FLOATS 12     /* packed per-(camera,Gaussian) record, see qed_project_fwd */
+#define QED_VSPLAT_FLOATS 16    /* packed per-(camera,Gaussian) gradient row, see qed_composite_bwd */
+
+/* flags of qed_project_fwd / qed_project_bwd */
+#define QED_F_ANTIALIASED 1u    /* rasterize_mode == "antialiased": opacity *= compensation */
+#define QED_F_LOG_SCALES 2u     /* `scales` holds log-scales: fuse torch.exp        (model.py:270) */
+#define QED_F_LOGIT_OPAC 4u     /* `opacities` holds logits:  fuse torch.sigmoid    (model.py:271) */
+#define QED_F_DEPTH_CHANNEL 8u  /* render_mode "RGB+D": depth is colour channel 3   (model.py:256-259) */
+#define QED_F_SIGMOID_COLORS 16u /* sh_degree None path: fuse torch.sigmoid(colors) (model.py:264) */
+
+int qed_version(void);
+const char* qed_last_error(void);
+/* size in bytes of the error/overflow status word block a caller passes as `status` (int32[4]):
+ * [0] != 0 -> intersection buffer capacity exceeded (value = required M),
+ * [1] != 0 -> radix-sort look-back watchdog fired. */
+#define QED_STATUS_WORDS 4
+
+/* ---- K1+K2: projection + SH colour, fused ------------------------------------------------
+ * Replaces, inside rasterization() (model.py:267-288): world->camera, 3D covariance from
+ * quat+scale, EWA 2D covariance + eps2d blur, conic, radius, near/far/frustum culling
+ * (near_plane=0.01, far_plane=1e10: model.py:279-280), SH evaluation to degree sh_degree
+ * (model.py:261-262, 282) with +0.5 and clamp, and the per-Gaussian tile count.
+ *
+ * means[N,3] quats[N,4] scales[N,3] opacities[N] viewmats[C,4,4] Ks[C,3,3] (row major).
+ * sh0 / shN: degree-0 coefficient [.,3] and higher coefficients [.,K-1,3] with row strides
+ * (in floats) sh0_stride / shN_stride -- `colors[N,K,3]` is (colors, 3K, colors+3, 3K);
+ * features_dc / features_rest (model.py:241) can be passed without the torch.cat.
+ * sh_degree < 0: sh0 holds ready colours [N,3] (model.py:263-265).
+ *
+ * outputs: radii[C,N] i32, means2d[C,N,2], depths[C,N], conics[C,N,3], opac_out[C,N],
+ *   colors_out[C,N,3], tiles_per_gauss[C,N] i32 and the packed record splats[C*N][12] =
+ *   {x, y, conic_a, conic_b | conic_c, opacity, r, g | b, depth, 0, 0} read by the
+ *   compositing kernels; block_sums[ceil(C*N/256)] i32 = tile counts summed per 256
+ *   consecutive (camera,Gaussian) slots (input of qed_isect_scan).
+ * Culled Gaussians get radius 0 and zeros everywhere. */
+int qed_project_fwd(int32_t N, int32_t C, const float* means, const float* quats, const float* scales,
+                    const float* opacities, const float* sh0, int32_t sh0_stride, const float* shN,
+                    int32_t shN_stride, int32_t sh_degree, const float* viewmats, const float* Ks,
+                    int32_t width, int32_t height, int32_t tile_w, int32_t tile_h, float eps2d,
+                    float near_plane, float far_plane, float radius_clip, uint32_t flags,
+                    int32_t* radii, float* means2d, float* depths, float* conics, float* opac_out,
+                    float* colors_out, float* splats, int32_t* tiles_per_gauss, int32_t* block_sums,
+                    void* stream);
+
+/* Backward of qed_project_fwd (autograd backward of the projection + SH part of model.py:267-288).
+ * vsplat[C*N][16] = packed gradient row written by qed_composite_bwd:
+ *   {v_x, v_y, |v_x|, |v_y|, v_conic_a, v_conic_b, v_conic_c, v_opacity, v_r, v_g, v_b, v_depth, 0,0,0,0}
+ * Outputs (overwritten, summed over cameras): v_means[N,3] v_quats[N,4] v_scales[N,3]
+ * v_opacities[N] v_sh0 (stride v_sh0_stride) v_shN (stride v_shN_stride); with
+ * QED_F_LOG_SCALES / QED_F_LOGIT_OPAC / QED_F_SIGMOID_COLORS the exp / sigmoid Jacobians are
+ * applied so the gradients are w.r.t. the raw parameters.  v_viewmats[C,4,4] (nullable) is
+ * accumulated with atomics and must be zeroed by the caller (camera optimiser, model.py:212). */
+int qed_project_bwd(int32_t N, int32_t C, const float* means, const float* quats, const float* scales,
+                    const float* opacities, const float* sh0, int32_t sh0_stride, const float* shN,
+                    int32_t shN_stride, int32_t sh_degree, const float* viewmats, const float* Ks,
+                    int32_t width, int32_t height, float eps2d, uint32_t flags, const int32_t* radii,
+                    const float* vsplat, float* v_means, float* v_quats, float* v_scales,
+                    float* v_opacities, float* v_sh0, int32_t v_sh0_stride, float* v_shN,
+                    int32_t v_shN_stride, float* v_viewmats, void* stream);
+
+/* ---- K3: tile intersection ------------------------------------------------------------------
+ * qed_isect_scan: exclusive scan of block_sums -> block_offsets[n_blocks] and the total
+ * M -> n_isect[0] (device int32).  If M > capacity, status[0] = M (emit/sort then do nothing).
+ * qed_isect_emit: for every (camera,Gaussian) with radius > 0 writes one (key,value) per touched
+ * tile: key = (cam << tile_bits | tile_id) << 32 | float_bits(depth), value = cam*N + n, in
+ * Gaussian-index then row-major tile order (gsplat isect_tiles, behind model.py:267-288). */
+int qed_isect_scan(const int32_t* block_sums, int32_t n_blocks, int32_t* block_offsets,
+                   int32_t* n_isect, int64_t capacity, int32_t* status, void* stream);
+int qed_isect_emit(int32_t N, int32_t C, const float* means2d, const int32_t* radii, const float* depths,
+                   const int32_t* tiles_per_gauss, const int32_t* block_offsets, int32_t tile_w,
+                   int32_t tile_h, int32_t tile_bits, const int32_t* n_isect, int64_t capacity,
+                   uint64_t* keys, int32_t* vals, void* stream);
+
+/* ---- K4: device radix sort of (u64 key, i32 value) pairs, LSD, 8-bit digits, stable ------------
+ * Sorts the first *n_dev (device int32, <= capacity) pairs on key bits [0, end_bit).  Ping-pongs
+ * between (keys,vals) and (keys_alt,vals_alt); returns 0 if the sorted result is in (keys,vals),
+ * 1 if it is in (keys_alt,vals_alt), <0 on error.  `workspace` needs
+ * qed_sort_workspace_bytes(capacity) bytes. */
+int64_t qed_sort_workspace_bytes(int64_t capacity);
+int qed_sort_pairs(uint64_t* keys, int32_t* vals, uint64_t* keys_alt, int32_t* vals_alt,
+                   const int32_t* n_dev, int64_t capacity, int32_t end_bit, void* workspace,
+                   int64_t workspace_bytes, int32_t* status, void* stream);
+
+/* ---- K5: tile offsets --------------------------------------------------------------------------
+ * offsets[C*T + 1]: offsets[t] = first sorted index whose (cam,tile) >= t; offsets[C*T] = M. */
+int qed_tile_offsets(const uint64_t* sorted_keys, const int32_t* n_dev, int64_t capacity, int32_t C,
+                     int32_t n_tiles, int32_t tile_bits, int32_t* offsets, void* stream);
+
+/* ---- K6: alpha compositing forward -------------------------------------------------------------
+ * One workgroup per 16x16 tile; front-to-back over the tile's run of the sorted list:
+ * sigma = .5(a dx^2 + c dy^2) + b dx dy, alpha = min(.999, o e^-sigma), skip if sigma < 0 or
+ * alpha < 1/255, stop (Gaussian not applied) when T(1-alpha) <= 1e-4.
+ * channels = 3 (RGB) or 4 (RGB+D).  backgrounds[C,channels] may be NULL (model.py:267-288 passes
+ * none).  Outputs render[C,H,W,channels], alpha[C,H,W], last_ids[C,H,W] i32. */
+int qed_composite_fwd(int32_t C, int32_t N, const float* splats, const int32_t* flatten_ids,
+                      const int32_t* offsets, int32_t width, int32_t height, int32_t tile_w,
+                      int32_t tile_h, int32_t channels, const float* backgrounds, float* render,
+                      float* alpha, int32_t* last_ids, void* stream);
+
+/* ---- K7: alpha compositing backward ------------------------------------------------------------
+ * Back-to-front replay from last_ids; per-pixel gradients are reduced across each 64-wide wave
+ * (permlane swaps + DPP), accumulated per tile in LDS, and added once per (tile,Gaussian) to the
+ * 64-byte row vsplat[C*N][16] (layout at qed_project_bwd; includes absgrad, model.py:284).
+ * vsplat must be zeroed by the caller. */
+int qed_composite_bwd(int32_t C, int32_t N, const float* splats, const int32_t* flatten_ids,
+                      const int32_t* offsets, int32_t width, int32_t height, int32_t tile_w,
+                      int32_t tile_h, int32_t channels, const float* backgrounds,
+                      const float* render_alpha, const int32_t* last_ids, const float* v_render,
+                      const float* v_alpha, float* vsplat, void* stream);
+
+/* ---- K8: fused image-space loss + gradient ------------------------------------------------------
+ * Collapses model.py:295-297 (background composite + clamp), :304-306 (depth fix-up), :87-116
+ * (masked depth-L1, depth_lambda) and the L1 part of the parent's RGB loss into one pass.
+ * Pass 1 (qed_loss_reduce) produces sums[0..3] = {sum |rgb-gt|, sum |d-dgt| over valid, n_valid,
+ * max depth}; pass 2 (qed_loss_grad) writes v_render[H,W,channels] and v_alpha[H,W] for
+ *   loss = rgb_weight * mean|rgb - gt| + depth_lambda * sum|d - dgt| / n_valid
+ * and the scalar losses -> losses[0..1].  mask[H,W] may be NULL (model.py:93-97). */
+int qed_loss_reduce(int32_t n_pix, int32_t channels, const float* render, const float* alpha,
+                    const float* background, const float* gt_rgb, const float* gt_depth,
+                    const float* mask, float* sums, void* stream);
+int qed_loss_grad(int32_t n_pix, int32_t channels, const float* render, const float* alpha,
+                  const float* background, const float* gt_rgb, const float* gt_depth,
+                  const float* mask, const float* sums, float rgb_weight, float depth_lambda,
+                  float* v_render, float* v_alpha, float* losses, void* stream);
+
+/* ---- fused multi-tensor Adam over one flat parameter buffer (config.py:44-68) --
+ * n_groups contiguous segments; segment g covers elements [h_group_begin[g], h_group_begin[g+1])
+ * and uses learning rate h_lr[g].  bias corrections use `step` (1-based). */
+int qed_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                  int32_t n_groups, const int64_t* h_group_begin, const float* h_lr, float beta1,
+                  float beta2, float eps, int32_t step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QED_SPLAT_H */

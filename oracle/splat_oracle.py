@@ -1,0 +1,488 @@
+"""TEST INFRASTRUCTURE ONLY -- not part of the shipped product path.
+
+CPU (PyTorch-eager) restatement of the render hot path that sits behind
+``qed_splatter/model.py`` ``get_outputs()`` / ``get_loss_dict()``.
+
+What it follows
+---------------
+* Reference-owned arithmetic, restated from the reference text:
+    - ``get_viewmat``                       /root/reference/qed_splatter/model.py:22-38
+    - activations / SH packing             model.py:241, 261-265, 269-271
+    - the ``rasterization(...)`` kwargs     model.py:267-288
+    - background composite + clamp          model.py:295-297
+    - depth fix-up                          model.py:304-306
+    - masked depth-L1 loss                  model.py:87-116
+* The operator behind ``model.py:267-288`` is third-party **gsplat**
+  (``gsplat.rendering.rasterization``).  It is NOT vendored in /root/reference and
+  NOT pinned there (pyproject.toml:6 pins only ``nerfstudio >= 1.1.0``; the
+  ``use_bilateral_grid`` use at model.py:300 implies nerfstudio >= 1.1.4, which pins
+  gsplat 1.4.0).  Its published algorithm (3DGS / EWA splatting as implemented by
+  gsplat 1.x) is restated below from SURVEY.md Appendix A.
+
+PARITY UNPINNED for the rasterizer: the reference holds no tests, fixtures or golden
+vectors for this path and gsplat cannot run here, so K1-K7 parity is "vs. this
+restatement".  The reference-owned pieces (get_viewmat, depth-L1) ARE pinned by
+fixtures generated from the reference itself (tests/golden/make_reference_kats.py).
+
+Everything is dtype-generic (float32 / float64); gradients come from autograd, which
+makes this an independent check of the hand-derived HIP backward kernels.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+# ----------------------------------------------------------------------------------
+# constants of the gsplat 1.x operator
+# ----------------------------------------------------------------------------------
+EPS2D = 0.3                 # screen-space blur added to the 2D covariance diagonal
+ALPHA_MAX = 0.999           # alpha clamp
+ALPHA_MIN = 1.0 / 255.0     # alpha cut
+T_MIN = 1e-4                # transmittance cut (early termination)
+RADIUS_SIGMA = 3.0          # radius = ceil(3 * sqrt(lambda_max))
+JAC_LIM_MARGIN = 0.3        # Jacobian x/z clamp: +30 % of the half FOV
+
+SH_C0 = 0.28209479177387814
+SH_C1 = 0.4886025119029199
+SH_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005,
+         -1.0925484305920792, 0.5462742152960396)
+SH_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658,
+         0.3731763325901154, -0.4570457994644658, 1.445305721320277,
+         -0.5900435899266435)
+
+
+# ----------------------------------------------------------------------------------
+# a1: get_viewmat                                              (model.py:22-38)
+# ----------------------------------------------------------------------------------
+def get_viewmat(optimized_camera_to_world: Tensor) -> Tensor:
+    """OpenGL c2w [C,3,4] -> OpenCV-style w2c [C,4,4] (model.py:22-38)."""
+    R = optimized_camera_to_world[:, :3, :3]
+    T = optimized_camera_to_world[:, :3, 3:4]
+    flip = torch.tensor([[[1.0, -1.0, -1.0]]], dtype=R.dtype, device=R.device)
+    R = R * flip                                   # flip y and z columns (model.py:29-30)
+    R_inv = R.transpose(1, 2)
+    T_inv = -torch.bmm(R_inv, T)
+    viewmat = torch.zeros(R.shape[0], 4, 4, dtype=R.dtype, device=R.device)
+    viewmat[:, 3, 3] = 1.0
+    viewmat[:, :3, :3] = R_inv
+    viewmat[:, :3, 3:4] = T_inv
+    return viewmat
+
+
+# ----------------------------------------------------------------------------------
+# K1: projection  (gsplat fully_fused_projection)
+# ----------------------------------------------------------------------------------
+def quat_to_rotmat(quats: Tensor) -> Tensor:
+    """wxyz quaternion -> rotation matrix; normalises first (as gsplat does)."""
+    q = quats / quats.norm(dim=-1, keepdim=True)
+    w, x, y, z = q.unbind(-1)
+    R = torch.stack(
+        [
+            1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+            2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+            2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y),
+        ],
+        dim=-1,
+    )
+    return R.reshape(quats.shape[:-1] + (3, 3))
+
+
+def project_gaussians(
+    means: Tensor, quats: Tensor, scales: Tensor, viewmats: Tensor, Ks: Tensor,
+    width: int, height: int, eps2d: float = EPS2D, near_plane: float = 0.01,
+    far_plane: float = 1e10, radius_clip: float = 0.0, calc_compensations: bool = False,
+    radii_override: Optional[Tensor] = None,
+) -> Tuple[Tensor, Tensor, Tensor, Tensor, Optional[Tensor]]:
+    """-> radii [C,N] int32, means2d [C,N,2], depths [C,N], conics [C,N,3], compensations|None.
+
+    Culled Gaussians get radius 0 and zeros in every other output.
+    """
+    C = viewmats.shape[0]
+    dt = means.dtype
+    R = viewmats[:, :3, :3]
+    t = viewmats[:, :3, 3]
+    mean_c = torch.einsum("cij,nj->cni", R, means) + t[:, None, :]          # [C,N,3]
+    z = mean_c[..., 2]
+    valid = (z >= near_plane) & (z <= far_plane)
+
+    Rq = quat_to_rotmat(quats)                                              # [N,3,3]
+    Mq = Rq * scales[:, None, :]
+    covar = Mq @ Mq.transpose(-1, -2)                                       # [N,3,3]
+    covar_c = torch.einsum("cij,njk,clk->cnil", R, covar, R)                # [C,N,3,3]
+
+    fx = Ks[:, 0, 0][:, None]
+    fy = Ks[:, 1, 1][:, None]
+    cx = Ks[:, 0, 2][:, None]
+    cy = Ks[:, 1, 2][:, None]
+    x = mean_c[..., 0]
+    y = mean_c[..., 1]
+    zs = torch.where(valid, z, torch.ones_like(z))
+    rz = 1.0 / zs
+    rz2 = rz * rz
+    tan_fovx = 0.5 * width / fx
+    tan_fovy = 0.5 * height / fy
+    lim_x_pos = (width - cx) / fx + JAC_LIM_MARGIN * tan_fovx
+    lim_x_neg = cx / fx + JAC_LIM_MARGIN * tan_fovx
+    lim_y_pos = (height - cy) / fy + JAC_LIM_MARGIN * tan_fovy
+    lim_y_neg = cy / fy + JAC_LIM_MARGIN * tan_fovy
+    tx = zs * torch.minimum(lim_x_pos, torch.maximum(-lim_x_neg, x * rz))
+    ty = zs * torch.minimum(lim_y_pos, torch.maximum(-lim_y_neg, y * rz))
+    zero = torch.zeros_like(rz)
+    J = torch.stack(
+        [fx * rz, zero, -fx * tx * rz2, zero, fy * rz, -fy * ty * rz2], dim=-1
+    ).reshape(C, -1, 2, 3)
+    cov2d = J @ covar_c @ J.transpose(-1, -2)                               # [C,N,2,2]
+    mean2d = torch.stack([fx * x * rz + cx, fy * y * rz + cy], dim=-1)
+
+    a0 = cov2d[..., 0, 0]
+    b0 = cov2d[..., 0, 1]
+    c0 = cov2d[..., 1, 1]
+    det_orig = a0 * c0 - b0 * b0
+    a = a0 + eps2d
+    c = c0 + eps2d
+    det = a * c - b0 * b0
+    valid = valid & (det > 0)
+    det_s = torch.where(valid, det, torch.ones_like(det))
+    compensation = torch.sqrt(torch.clamp(det_orig / det_s, min=0.0))
+    conics = torch.stack([c / det_s, -b0 / det_s, a / det_s], dim=-1)
+
+    bh = 0.5 * (a + c)
+    v1 = bh + torch.sqrt(torch.clamp(bh * bh - det, min=0.01))
+    radius = torch.ceil(RADIUS_SIGMA * torch.sqrt(v1.detach()))
+    if radii_override is not None:
+        # tests pass the radii of the implementation under test: ceil() of a value within fp32
+        # rounding of an integer is a coin toss, and the radius is non-differentiable anyway
+        radius = radii_override.to(radius.dtype)
+        valid = valid & (radius > 0)
+    valid = valid & (radius > radius_clip)
+    mx = mean2d[..., 0].detach()
+    my = mean2d[..., 1].detach()
+    inside = ~((mx + radius <= 0) | (mx - radius >= width) | (my + radius <= 0) | (my - radius >= height))
+    valid = valid & inside
+
+    radii = torch.where(valid, radius, torch.zeros_like(radius)).to(torch.int32)
+    vm = valid.to(dt)
+    means2d = torch.where(valid[..., None], mean2d, torch.zeros_like(mean2d))
+    depths = torch.where(valid, z, torch.zeros_like(z))
+    conics = torch.where(valid[..., None], conics, torch.zeros_like(conics))
+    comp = torch.where(valid, compensation, torch.zeros_like(compensation)) if calc_compensations else None
+    del vm
+    return radii, means2d, depths, conics, comp
+
+
+# ----------------------------------------------------------------------------------
+# K2: spherical harmonics  
+# ----------------------------------------------------------------------------------
+def eval_sh(degree: int, dirs: Tensor, coeffs: Tensor) -> Tensor:
+    """dirs [...,3] (un-normalised), coeffs [...,K,3] -> colours [...,3] (no +0.5, no clamp)."""
+    d = dirs / dirs.norm(dim=-1, keepdim=True)
+    x, y, z = d.unbind(-1)
+    x, y, z = x[..., None], y[..., None], z[..., None]
+    res = SH_C0 * coeffs[..., 0, :]
+    if degree > 0:
+        res = res - SH_C1 * y * coeffs[..., 1, :] + SH_C1 * z * coeffs[..., 2, :] - SH_C1 * x * coeffs[..., 3, :]
+    if degree > 1:
+        xx, yy, zz = x * x, y * y, z * z
+        xy, yz, xz = x * y, y * z, x * z
+        res = (res + SH_C2[0] * xy * coeffs[..., 4, :] + SH_C2[1] * yz * coeffs[..., 5, :]
+               + SH_C2[2] * (2.0 * zz - xx - yy) * coeffs[..., 6, :]
+               + SH_C2[3] * xz * coeffs[..., 7, :] + SH_C2[4] * (xx - yy) * coeffs[..., 8, :])
+    if degree > 2:
+        res = (res + SH_C3[0] * y * (3.0 * xx - yy) * coeffs[..., 9, :]
+               + SH_C3[1] * xy * z * coeffs[..., 10, :]
+               + SH_C3[2] * y * (4.0 * zz - xx - yy) * coeffs[..., 11, :]
+               + SH_C3[3] * z * (2.0 * zz - 3.0 * xx - 3.0 * yy) * coeffs[..., 12, :]
+               + SH_C3[4] * x * (4.0 * zz - xx - yy) * coeffs[..., 13, :]
+               + SH_C3[5] * z * (xx - yy) * coeffs[..., 14, :]
+               + SH_C3[6] * x * (xx - 3.0 * yy) * coeffs[..., 15, :])
+    if degree > 3:
+        raise NotImplementedError("SH degree > 3 is not used by the reference (config sh_degree=3)")
+    return res
+
+
+def sh_colors(sh_degree: int, means: Tensor, viewmats: Tensor, coeffs: Tensor, radii: Tensor) -> Tensor:
+    """View-dependent colours [C,N,3] = max(0, SH + 0.5); zero where radii == 0."""
+    campos = torch.linalg.inv(viewmats)[:, :3, 3]                # [C,3]
+    dirs = means[None, :, :] - campos[:, None, :]                # [C,N,3]
+    vis = radii > 0
+    safe_dirs = torch.where(vis[..., None], dirs, torch.ones_like(dirs))
+    col = eval_sh(sh_degree, safe_dirs, coeffs[None])
+    col = torch.clamp_min(col + 0.5, 0.0)
+    return torch.where(vis[..., None], col, torch.zeros_like(col))
+
+
+# ----------------------------------------------------------------------------------
+# K3-K5: tile intersection, sort, offsets   -- integer exact
+# ----------------------------------------------------------------------------------
+def tile_bits(n_tiles: int) -> int:
+    return int(math.floor(math.log2(n_tiles))) + 1 if n_tiles > 0 else 1
+
+
+def tile_rects(means2d: Tensor, radii: Tensor, tile_size: int, tile_w: int, tile_h: int):
+    """Inclusive-min / exclusive-max tile rectangle per (camera, Gaussian), in float32."""
+    m = means2d.detach().to(torch.float32)
+    r = radii.to(torch.float32)
+    ts = torch.tensor(float(tile_size), dtype=torch.float32)
+    tr = r / ts
+    txc = m[..., 0] / ts
+    tyc = m[..., 1] / ts
+    xmin = torch.clamp(torch.floor(txc - tr), 0, tile_w).to(torch.int64)
+    ymin = torch.clamp(torch.floor(tyc - tr), 0, tile_h).to(torch.int64)
+    xmax = torch.clamp(torch.ceil(txc + tr), 0, tile_w).to(torch.int64)
+    ymax = torch.clamp(torch.ceil(tyc + tr), 0, tile_h).to(torch.int64)
+    vis = radii > 0
+    z = torch.zeros_like(xmin)
+    return (torch.where(vis, xmin, z), torch.where(vis, ymin, z),
+            torch.where(vis, xmax, z), torch.where(vis, ymax, z))
+
+
+def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, tile_w: int, tile_h: int):
+    """-> tiles_per_gauss [C,N] int32, isect_ids [M] int64 (sorted), flatten_ids [M] int32 (sorted).
+
+    key = (cam << tile_bits | tile_id) << 32 | float32_bits(depth); value = cam * N + n.
+    Stable sort, so equal keys keep emission order (Gaussian index, then tile row-major).
+    """
+    C, N = radii.shape
+    xmin, ymin, xmax, ymax = tile_rects(means2d, radii, tile_size, tile_w, tile_h)
+    w = xmax - xmin
+    cnt = (w * (ymax - ymin)).reshape(-1)                      # [C*N]
+    cum = torch.cumsum(cnt, 0)
+    M = int(cum[-1]) if cnt.numel() else 0
+    flat = torch.repeat_interleave(torch.arange(C * N), cnt)   # [M]
+    local = torch.arange(M) - (cum - cnt)[flat]
+    wf = w.reshape(-1)[flat].clamp(min=1)
+    ty = ymin.reshape(-1)[flat] + local // wf
+    tx = xmin.reshape(-1)[flat] + local % wf
+    cam = flat // N
+    tb = tile_bits(tile_w * tile_h)
+    depth_bits = depths.detach().to(torch.float32).reshape(-1).view(torch.int32).to(torch.int64)[flat]
+    keys = (((cam << tb) | (ty * tile_w + tx)) << 32) | depth_bits
+    keys_sorted, order = torch.sort(keys, stable=True)
+    return cnt.reshape(C, N).to(torch.int32), keys_sorted, flat[order].to(torch.int32)
+
+
+def isect_offset_encode(isect_ids: Tensor, C: int, tile_w: int, tile_h: int) -> Tensor:
+    """offsets[c,ty,tx] = first sorted index whose (cam,tile) >= that tile; trailing tiles = M."""
+    n_tiles = tile_w * tile_h
+    tb = tile_bits(n_tiles)
+    ct = isect_ids >> 32
+    lin = (ct >> tb) * n_tiles + (ct & ((1 << tb) - 1))
+    offs = torch.searchsorted(lin.contiguous(), torch.arange(C * n_tiles, dtype=torch.int64))
+    return offs.to(torch.int32).reshape(C, tile_h, tile_w)
+
+
+# ----------------------------------------------------------------------------------
+# K6: alpha compositing   -- vectorised per tile, autograd = K7
+# ----------------------------------------------------------------------------------
+def composite_tiles(
+    means2d: Tensor, conics: Tensor, colors: Tensor, opacities: Tensor,
+    width: int, height: int, tile_size: int, isect_offsets: Tensor, flatten_ids: Tensor,
+    return_margin: bool = False,
+):
+    """means2d [C,N,2], conics [C,N,3], colors [C,N,D], opacities [C,N]
+    -> render [C,H,W,D], alpha [C,H,W,1], last_ids [C,H,W] int32 (absolute sorted index).
+
+    Per pixel, front to back over the tile's run: sigma = .5(a dx^2 + c dy^2) + b dx dy,
+    alpha = min(.999, o e^-sigma); skip if sigma < 0 or alpha < 1/255; stop (Gaussian not
+    applied) when T(1-alpha) <= 1e-4.
+
+    With ``return_margin`` also returns, per pixel, the smallest relative distance of any
+    evaluated decision (alpha cut, T cut) to its threshold -- tests use it to discount
+    pixels whose decision is within fp32 rounding of a threshold.
+    """
+    C, N = opacities.shape
+    D = colors.shape[-1]
+    dt = means2d.dtype
+    tile_h, tile_w = isect_offsets.shape[1:]
+    M = flatten_ids.numel()
+    offs = torch.cat([isect_offsets.reshape(-1).to(torch.int64), torch.tensor([M], dtype=torch.int64)])
+    m2 = means2d.reshape(C * N, 2)
+    cn = conics.reshape(C * N, 3)
+    cl = colors.reshape(C * N, D)
+    op = opacities.reshape(C * N)
+    fid = flatten_ids.to(torch.int64)
+
+    render = torch.zeros(C, height, width, D, dtype=dt)
+    alpha_img = torch.zeros(C, height, width, 1, dtype=dt)
+    last_ids = torch.zeros(C, height, width, dtype=torch.int32)
+    margin = torch.full((C, height, width), float("inf"), dtype=torch.float64) if return_margin else None
+    render_parts = []
+
+    ys, xs = torch.meshgrid(torch.arange(tile_size), torch.arange(tile_size), indexing="ij")
+    for c in range(C):
+        for ty in range(tile_h):
+            for tx in range(tile_w):
+                t = (c * tile_h + ty) * tile_w + tx
+                s, e = int(offs[t]), int(offs[t + 1])
+                if e <= s:
+                    continue
+                py = (ty * tile_size + ys).reshape(-1)
+                px = (tx * tile_size + xs).reshape(-1)
+                ins = (py < height) & (px < width)
+                py, px = py[ins], px[ins]
+                g = fid[s:e]
+                xy = m2[g]                                           # [K,2]
+                dx = xy[None, :, 0] - (px.to(dt)[:, None] + 0.5)     # [P,K]
+                dy = xy[None, :, 1] - (py.to(dt)[:, None] + 0.5)
+                con = cn[g]
+                sigma = 0.5 * (con[None, :, 0] * dx * dx + con[None, :, 2] * dy * dy) + con[None, :, 1] * dx * dy
+                ov = op[g][None, :] * torch.exp(-sigma)
+                a = torch.clamp(ov, max=ALPHA_MAX)
+                ok = (sigma >= 0) & (a >= ALPHA_MIN)
+                a = torch.where(ok, a, torch.zeros_like(a))
+                T_after = torch.cumprod(1.0 - a, dim=1)
+                T_before = torch.cat([torch.ones_like(T_after[:, :1]), T_after[:, :-1]], dim=1)
+                contrib = ok & (T_after > T_MIN)
+                wgt = torch.where(contrib, a * T_before, torch.zeros_like(a))
+                out = wgt @ cl[g]                                    # [P,D]
+                T_fin = torch.prod(torch.where(contrib, 1.0 - a, torch.ones_like(a)), dim=1)
+                kk = torch.arange(e - s)[None, :].expand_as(contrib)
+                last = torch.where(contrib, kk + s, torch.zeros_like(kk)).amax(dim=1)
+                render_parts.append((c, py, px, out, 1.0 - T_fin))
+                last_ids[c, py, px] = last.to(torch.int32)
+                if return_margin:
+                    with torch.no_grad():
+                        alive = T_before > T_MIN                      # pixel not yet terminated
+                        # was the pixel terminated by an earlier Gaussian?  then decisions don't matter
+                        term = (ok & (T_after <= T_MIN)).to(torch.int64).cumsum(1)
+                        reached = (term - (ok & (T_after <= T_MIN)).to(torch.int64)) == 0
+                        m_alpha = torch.abs(torch.clamp(ov, max=ALPHA_MAX) / ALPHA_MIN - 1.0).to(torch.float64)
+                        m_T = torch.abs(T_after / T_MIN - 1.0).to(torch.float64)
+                        m_T = torch.where(ok, m_T, torch.full_like(m_T, float("inf")))
+                        mm = torch.minimum(m_alpha, m_T)
+                        mm = torch.where(reached & alive, mm, torch.full_like(mm, float("inf")))
+                        margin[c, py, px] = mm.amin(dim=1)
+    # scatter the per-tile results with index_put (keeps autograd simple)
+    if render_parts:
+        ci = torch.cat([torch.full_like(p[1], p[0]) for p in render_parts])
+        pyc = torch.cat([p[1] for p in render_parts])
+        pxc = torch.cat([p[2] for p in render_parts])
+        render = render.index_put((ci, pyc, pxc), torch.cat([p[3] for p in render_parts]))
+        alpha_img = alpha_img.index_put((ci, pyc, pxc), torch.cat([p[4] for p in render_parts])[:, None])
+    if return_margin:
+        return render, alpha_img, last_ids, margin
+    return render, alpha_img, last_ids
+
+
+# ----------------------------------------------------------------------------------
+# a5: the rasterization(...) operator  (model.py:267-288)
+# ----------------------------------------------------------------------------------
+def rasterization(
+    means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, colors: Tensor,
+    viewmats: Tensor, Ks: Tensor, width: int, height: int, tile_size: int = 16,
+    packed: bool = False, near_plane: float = 0.01, far_plane: float = 1e10,
+    render_mode: str = "RGB", sh_degree: Optional[int] = None, sparse_grad: bool = False,
+    absgrad: bool = False, rasterize_mode: str = "classic", radius_clip: float = 0.0,
+    eps2d: float = EPS2D, return_margin: bool = False, radii_override: Optional[Tensor] = None,
+) -> Tuple[Tensor, Tensor, Dict]:
+    """Same keyword surface as the call at model.py:267-288 -> (render, alpha, info)."""
+    assert not packed and not sparse_grad, "the reference passes packed=False, sparse_grad=False"
+    assert render_mode in ("RGB", "RGB+D", "D", "RGB+ED", "ED"), render_mode
+    assert rasterize_mode in ("classic", "antialiased"), rasterize_mode
+    C = viewmats.shape[0]
+    N = means.shape[0]
+    radii, means2d, depths, conics, comp = project_gaussians(
+        means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
+        radius_clip, calc_compensations=(rasterize_mode == "antialiased"), radii_override=radii_override)
+    opac = opacities[None, :].expand(C, N)
+    if comp is not None:
+        opac = opac * comp
+    tile_w = math.ceil(width / tile_size)
+    tile_h = math.ceil(height / tile_size)
+    tiles_per_gauss, isect_ids, flatten_ids = isect_tiles(means2d, radii, depths, tile_size, tile_w, tile_h)
+    isect_offsets = isect_offset_encode(isect_ids, C, tile_w, tile_h)
+
+    if sh_degree is None:
+        cols = colors[None].expand(C, N, colors.shape[-1]) if colors.dim() == 2 else colors
+    else:
+        cols = sh_colors(sh_degree, means, viewmats, colors[:, : (sh_degree + 1) ** 2, :], radii)
+    if render_mode in ("RGB+D", "RGB+ED"):
+        cols = torch.cat([cols, depths[..., None]], dim=-1)
+    elif render_mode in ("D", "ED"):
+        cols = depths[..., None]
+
+    if means2d.requires_grad:
+        means2d.retain_grad()
+    out = composite_tiles(means2d, conics, cols, opac, width, height, tile_size, isect_offsets,
+                          flatten_ids, return_margin=return_margin)
+    render, alpha, last_ids = out[:3]
+    if render_mode in ("RGB+ED", "ED"):
+        render = torch.cat([render[..., :-1], render[..., -1:] / alpha.clamp(min=1e-10)], dim=-1)
+    info = {
+        "means2d": means2d, "radii": radii, "depths": depths, "conics": conics, "opacities": opac,
+        "tile_width": tile_w, "tile_height": tile_h, "tiles_per_gauss": tiles_per_gauss,
+        "isect_ids": isect_ids, "flatten_ids": flatten_ids, "isect_offsets": isect_offsets,
+        "width": width, "height": height, "tile_size": tile_size, "n_cameras": C,
+        "last_ids": last_ids, "colors": cols,
+    }
+    if return_margin:
+        info["margin"] = out[3]
+    return render, alpha, info
+
+
+# ----------------------------------------------------------------------------------
+# a2/a7/a9: what get_outputs does around the operator  (model.py:241-321)
+# ----------------------------------------------------------------------------------
+def splatfacto_outputs(
+    means: Tensor, scales_log: Tensor, quats_raw: Tensor, opacities_logit: Tensor,
+    features_dc: Tensor, features_rest: Tensor, camera_to_worlds: Tensor, Ks: Tensor,
+    width: int, height: int, background: Tensor, sh_degree_to_use: Optional[int] = 3,
+    render_mode: str = "RGB+D", rasterize_mode: str = "classic", **kw,
+) -> Dict[str, Tensor]:
+    """Restates model.py:241-321 for one call: activations, operator, composite, depth fix-up."""
+    colors = torch.cat((features_dc[:, None, :], features_rest), dim=1)            # model.py:241
+    viewmat = get_viewmat(camera_to_worlds)                                        # model.py:246
+    if sh_degree_to_use is None:                                                   # model.py:263-265
+        colors = torch.sigmoid(colors).squeeze(1)
+    render, alpha, info = rasterization(
+        means=means,
+        quats=quats_raw / quats_raw.norm(dim=-1, keepdim=True),                   # model.py:269
+        scales=torch.exp(scales_log),                                             # model.py:270
+        opacities=torch.sigmoid(opacities_logit).squeeze(-1),                     # model.py:271
+        colors=colors, viewmats=viewmat, Ks=Ks, width=width, height=height, tile_size=16,
+        packed=False, near_plane=0.01, far_plane=1e10, render_mode=render_mode,
+        sh_degree=sh_degree_to_use, sparse_grad=False, absgrad=True,
+        rasterize_mode=rasterize_mode, **kw)
+    rgb = render[..., :3] + (1 - alpha) * background                               # model.py:296
+    rgb = torch.clamp(rgb, 0.0, 1.0)                                               # model.py:297
+    if render_mode == "RGB+D":
+        depth_im = render[..., 3:4]
+        depth_im = torch.where(alpha > 0, depth_im, depth_im.detach().max()).squeeze(0)   # model.py:306
+    else:
+        depth_im = None
+    return {"rgb": rgb.squeeze(0), "depth": depth_im, "accumulation": alpha.squeeze(0),
+            "background": background, "info": info, "render": render}
+
+
+# ----------------------------------------------------------------------------------
+# a11: depth-L1 term of get_loss_dict  (model.py:87-116)
+# ----------------------------------------------------------------------------------
+def depth_l1_loss(depth_out: Tensor, depth_gt: Tensor, mask: Optional[Tensor] = None,
+                  depth_lambda: float = 0.2) -> Tensor:
+    if mask is not None:
+        assert mask.shape[:2] == depth_out.shape[:2]
+        depth_out = depth_out * mask
+        depth_gt = depth_gt * mask
+    valid = torch.isfinite(depth_out) & torch.isfinite(depth_gt) & (depth_gt > 0.0)
+    vo = depth_out[valid]
+    vg = depth_gt[valid]
+    if vo.numel() > 0:
+        loss = torch.abs(vo - vg).mean()
+    else:
+        loss = torch.tensor(0.0, dtype=depth_out.dtype)
+    return depth_lambda * loss
+
+
+def rgb_l1_loss(rgb: Tensor, gt: Tensor) -> Tensor:
+    """L1 part of the parent's main loss (SplatfactoModel.get_loss_dict, upstream).  The
+    (1 - SSIM) part is SURVEY section 8(f) rank 1 ("next"), not yet on the built path."""
+    return torch.abs(gt - rgb).mean()
+
+
+# ----------------------------------------------------------------------------------
+# synthetic scene generator of SURVEY section 8(d): shared with the product's bench / tests
+# ----------------------------------------------------------------------------------
+from qed_splatter_amd.scene import synthetic_scene  # noqa: E402,F401  (pure-torch data generator, no kernels)

@@ -1,0 +1,139 @@
+"""ctypes binding of libqed_splat.so (the C ABI declared in include/qed_splat.h).
+
+This is the binding a maintainer of the reference would add instead of ``from gsplat.rendering
+import rasterization`` (model.py:6-9).  There is deliberately NO fallback: if the library is
+missing or a call fails, an exception is raised -- the product path never routes through the CPU
+oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import types
+from pathlib import Path
+
+_LIB = None
+LIB_PATH = Path(__file__).resolve().parent / "lib" / "libqed_splat.so"
+
+# name -> (restype, argtypes); must list EVERY symbol include/qed_splat.h declares
+_P = C.c_void_p
+_I = C.c_int32
+_L = C.c_int64
+_F = C.c_float
+_U = C.c_uint32
+SIGNATURES = {
+    "qed_version": (C.c_int, []),
+    "qed_last_error": (C.c_char_p, []),
+    "qed_project_fwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _F, _F, _F,
+                                  _F, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "qed_project_bwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _I, _F, _U, _P, _P, _P,
+                                  _P, _P, _P, _P, _I, _P, _I, _P, _P]),
+    "qed_isect_scan": (C.c_int, [_P, _I, _P, _P, _L, _P, _P]),
+    "qed_isect_emit": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _L, _P, _P, _P]),
+    "qed_sort_workspace_bytes": (_L, [_L]),
+    "qed_sort_pairs": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P, _L, _P, _P]),
+    "qed_tile_offsets": (C.c_int, [_P, _P, _L, _I, _I, _I, _P, _P]),
+    "qed_composite_fwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "qed_composite_bwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "qed_loss_reduce": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "qed_loss_grad": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P]),
+    "qed_adam_step": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _F, _F, _F, _I, _P]),
+}
+
+# flags (include/qed_splat.h)
+F_ANTIALIASED = 1
+F_LOG_SCALES = 2
+F_LOGIT_OPAC = 4
+F_DEPTH_CHANNEL = 8
+F_SIGMOID_COLORS = 16
+SPLAT_FLOATS = 12
+VSPLAT_FLOATS = 16
+STATUS_WORDS = 4
+TILE = 16
+
+
+class QedSplatError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    # torch first: it ships its own libamdhip64; loading ours after it makes the dynamic loader
+    # resolve both to the ONE runtime torch's streams and allocations belong to
+    import torch  # noqa: F401
+    path = Path(os.environ.get("QED_SPLAT_LIB", LIB_PATH))
+    if not path.exists():
+        raise QedSplatError(
+            f"{path} not found: build it with `python -m qed_splatter_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback on the product path.")
+    cdll = C.CDLL(str(path))
+    ns = {"_cdll": cdll}
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(cdll, name)         # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+        ns[name] = _wrap(name, fn) if res is C.c_int and args else fn
+    _LIB = types.SimpleNamespace(**ns)
+    return _LIB
+
+
+def _wrap(name, fn):
+    def call(*a):
+        if TIMER.active:
+            tok = TIMER.begin(name)
+            rc = fn(*a)
+            TIMER.end(tok)
+            return rc
+        return fn(*a)
+    call.__name__ = name
+    return call
+
+
+class KernelTimer:
+    """Optional per-entry-point HIP-event timing on the stream the kernels are launched on
+    (bench.py's roofline leg).  Inactive (zero overhead beyond one attribute test) by default."""
+
+    def __init__(self):
+        self.active = False
+        self.events = {}
+
+    def begin(self, name: str):
+        import torch
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return (name, ev)
+
+    def end(self, tok) -> None:
+        import torch
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.events.setdefault(tok[0], []).append((tok[1], ev))
+
+    def summary(self):
+        """name -> (calls, mean ms); call after torch.cuda.synchronize()."""
+        out = {}
+        for name, pairs in self.events.items():
+            ms = [a.elapsed_time(b) for a, b in pairs]
+            out[name] = (len(ms), sum(ms) / max(len(ms), 1))
+        return out
+
+    def reset(self):
+        self.events = {}
+
+
+TIMER = KernelTimer()
+
+
+def check(rc: int, what: str) -> int:
+    if rc < 0:
+        msg = load().qed_last_error().decode("utf-8", "replace")
+        raise QedSplatError(f"{what} failed (rc={rc}): {msg}")
+    return rc
+
+
+def ptr(t) -> int:
+    """Device pointer of a tensor (0 for None)."""
+    return 0 if t is None else t.data_ptr()

@@ -1,0 +1,278 @@
+// K8: fused image-space loss + gradient, and the fused flat Adam step.
+//
+// K8 collapses what the reference does in eager torch after rasterization():
+//   rgb   = clamp(render[..., :3] + (1 - alpha) * background, 0, 1)        model.py:296-297
+//   depth = where(alpha > 0, render[..., 3:4], render[..., 3:4].max())      model.py:304-306
+//   depth_loss = depth_lambda * mean |depth - gt| over finite & gt > 0     model.py:87-116
+//   L1 part of the parent's RGB loss (SplatfactoModel.get_loss_dict, upstream of model.py:83-85)
+// into two streaming passes (a global max / count must be known before gradients can be written).
+// Pure HBM streaming: 20 B/pixel render+alpha, 16-20 B/pixel ground truth in, 20 B/pixel out.
+#include <stdarg.h>
+
+#include "qed_common.h"
+
+namespace qed {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// order-preserving float <-> int map so that atomicMax works for any sign
+__device__ __forceinline__ int float_to_ordered(float f) {
+    const int i = __float_as_int(f);
+    return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__device__ __forceinline__ float ordered_to_float(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+struct PixelEval {
+    float pre[3];      // rgb before the clamp
+    float rgb[3];
+    float a;
+    float d_render;    // render depth channel (0 if RGB only)
+};
+
+template <int CH>
+__device__ __forceinline__ PixelEval eval_pixel(const float* __restrict__ render, const float* __restrict__ alpha,
+                                                const float* __restrict__ bg, size_t i) {
+    PixelEval p;
+    float c[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (CH == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(render + 4 * i);
+        c[0] = t.x; c[1] = t.y; c[2] = t.z; c[3] = t.w;
+    } else {
+        c[0] = render[3 * i]; c[1] = render[3 * i + 1]; c[2] = render[3 * i + 2];
+    }
+    p.a = alpha[i];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        p.pre[k] = c[k] + (1.f - p.a) * bg[k];
+        p.rgb[k] = fminf(fmaxf(p.pre[k], 0.f), 1.f);
+    }
+    p.d_render = c[3];
+    return p;
+}
+
+// sums: [0] sum |rgb - gt|   [1] sum |depth - gt| over valid (filled by the grad pass)
+//       [2] n_valid           [3] max depth as ordered int (bit pattern)
+template <int CH>
+__global__ void __launch_bounds__(256)
+loss_reduce_kernel(int n_pix, const float* __restrict__ render, const float* __restrict__ alpha,
+                   const float* __restrict__ bg, const float* __restrict__ gt_rgb, const float* __restrict__ gt_depth,
+                   const float* __restrict__ mask, float* __restrict__ sums) {
+    float l1 = 0.f, nv = 0.f;
+    float dmax = -3.0e38f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n_pix; i += (size_t)gridDim.x * 256) {
+        const PixelEval p = eval_pixel<CH>(render, alpha, bg, i);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) l1 += fabsf(p.rgb[k] - gt_rgb[3 * i + k]);
+        if constexpr (CH == 4) {
+            dmax = fmaxf(dmax, p.d_render);
+            const float m = mask ? mask[i] : 1.f;
+            const float dg = gt_depth[i] * m;
+            // the predicted depth is finite whenever the render is; NaN renders fail isfinite below
+            const float dp = p.d_render * m;
+            if (isfinite(dp) && isfinite(dg) && dg > 0.f) nv += 1.f;
+        }
+    }
+    l1 = wave_sum(l1);
+    nv = wave_sum(nv);
+    dmax = wave_max(dmax);
+    __shared__ float s[3][4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { s[0][wid] = l1; s[1][wid] = nv; s[2][wid] = dmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[0], s[0][0] + s[0][1] + s[0][2] + s[0][3]);
+        if constexpr (CH == 4) {
+            atomicAdd(&sums[2], s[1][0] + s[1][1] + s[1][2] + s[1][3]);
+            const float m = fmaxf(fmaxf(s[2][0], s[2][1]), fmaxf(s[2][2], s[2][3]));
+            atomicMax(reinterpret_cast<int*>(&sums[3]), float_to_ordered(m));
+        }
+    }
+}
+
+template <int CH>
+__global__ void __launch_bounds__(256)
+loss_grad_kernel(int n_pix, const float* __restrict__ render, const float* __restrict__ alpha,
+                 const float* __restrict__ bg, const float* __restrict__ gt_rgb, const float* __restrict__ gt_depth,
+                 const float* __restrict__ mask, float* __restrict__ sums, float rgb_weight, float depth_lambda,
+                 float* __restrict__ v_render, float* __restrict__ v_alpha) {
+    const float w_rgb = rgb_weight / (3.f * (float)n_pix);
+    const float nvalid = sums[2];
+    const float w_d = nvalid > 0.f ? depth_lambda / nvalid : 0.f;
+    const float dmax = CH == 4 ? ordered_to_float(*reinterpret_cast<const int*>(&sums[3])) : 0.f;
+    float dsum = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n_pix; i += (size_t)gridDim.x * 256) {
+        const PixelEval p = eval_pixel<CH>(render, alpha, bg, i);
+        float vr[4] = {0.f, 0.f, 0.f, 0.f};
+        float va = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float diff = p.rgb[k] - gt_rgb[3 * i + k];
+            const float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+            const bool pass = p.pre[k] >= 0.f && p.pre[k] <= 1.f;     // torch.clamp backward (inclusive)
+            const float g = pass ? w_rgb * sg : 0.f;
+            vr[k] = g;
+            va -= g * bg[k];
+        }
+        if constexpr (CH == 4) {
+            const float m = mask ? mask[i] : 1.f;
+            const float dg = gt_depth[i] * m;
+            const float dsel = p.a > 0.f ? p.d_render : dmax;          // model.py:306
+            const float dp = dsel * m;
+            if (isfinite(dp) && isfinite(dg) && dg > 0.f) {
+                const float diff = dp - dg;
+                dsum += fabsf(diff);
+                const float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+                if (p.a > 0.f) vr[3] = w_d * sg * m;
+            }
+            *reinterpret_cast<float4*>(v_render + 4 * i) = make_float4(vr[0], vr[1], vr[2], vr[3]);
+        } else {
+            v_render[3 * i] = vr[0]; v_render[3 * i + 1] = vr[1]; v_render[3 * i + 2] = vr[2];
+        }
+        v_alpha[i] = va;
+    }
+    if constexpr (CH == 4) {
+        dsum = wave_sum(dsum);
+        __shared__ float s[4];
+        if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = dsum;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(&sums[1], s[0] + s[1] + s[2] + s[3]);
+    }
+}
+
+__global__ void loss_finalize_kernel(int n_pix, const float* __restrict__ sums, float rgb_weight, float depth_lambda,
+                                     float* __restrict__ losses) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        losses[0] = rgb_weight * sums[0] / (3.f * (float)n_pix);
+        losses[1] = sums[2] > 0.f ? depth_lambda * sums[1] / sums[2] : 0.f;    // empty -> 0.0 (model.py:111-114)
+    }
+}
+
+// ---- fused flat Adam ---------------------------------------------------------------------------------
+struct AdamGroups {
+    long long begin[9];
+    float lr[8];
+    int n;
+};
+
+__global__ void __launch_bounds__(256)
+adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+            AdamGroups grp, float beta1, float beta2, float eps, float inv_bc1, float inv_bc2_sqrt) {
+    const long long total = grp.begin[grp.n];
+    const long long nvec = total >> 2;
+    auto lr_of = [&](long long i) {
+        float lr = grp.lr[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k)
+            if (k < grp.n && i >= grp.begin[k]) lr = grp.lr[k];
+        return lr;
+    };
+    auto upd = [&](float pp, float gg, float& mm, float& vv, float lr) {
+        mm = beta1 * mm + (1.f - beta1) * gg;
+        vv = beta2 * vv + (1.f - beta2) * gg * gg;
+        const float denom = sqrtf(vv) * inv_bc2_sqrt + eps;
+        return pp - lr * inv_bc1 * mm / denom;
+    };
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        const long long e = i << 2;
+        pp.x = upd(pp.x, gg.x, mm.x, vv.x, lr_of(e));
+        pp.y = upd(pp.y, gg.y, mm.y, vv.y, lr_of(e + 1));
+        pp.z = upd(pp.z, gg.z, mm.z, vv.z, lr_of(e + 2));
+        pp.w = upd(pp.w, gg.w, mm.w, vv.w, lr_of(e + 3));
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    // tail (total not a multiple of 4)
+    if (blockIdx.x == 0 && threadIdx.x < (total & 3)) {
+        const long long e = (nvec << 2) + threadIdx.x;
+        float mm = m[e], vv = v[e];
+        p[e] = upd(p[e], g[e], mm, vv, lr_of(e));
+        m[e] = mm; v[e] = vv;
+    }
+}
+
+}  // namespace qed
+
+using namespace qed;
+
+extern "C" int qed_version(void) { return 1; }
+extern "C" const char* qed_last_error(void) { return g_err; }
+
+static unsigned stream_grid(long long n_items) {
+    long long g = (n_items + 255) / 256;
+    if (g > 2048) g = 2048;      // 256 CUs x 8 workgroups, grid-stride the rest
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+extern "C" int qed_loss_reduce(int32_t n_pix, int32_t channels, const float* render, const float* alpha,
+                               const float* background, const float* gt_rgb, const float* gt_depth,
+                               const float* mask, float* sums, void* stream) {
+    QED_REQUIRE(n_pix > 0 && (channels == 3 || channels == 4), "bad arguments");
+    QED_REQUIRE(render && alpha && background && gt_rgb && sums, "null buffers");
+    QED_REQUIRE(channels == 3 || gt_depth, "gt_depth required with a depth channel");
+    hipStream_t st = (hipStream_t)stream;
+    // sums = {0, 0, 0, ordered(-FLT_MAX)}: -FLT_MAX = 0xFF7FFFFF, ordered form = bits ^ 0x7FFFFFFF
+    hipError_t e = hipMemsetAsync(sums, 0, 3 * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(sums + 3), (int)0x80800000, 1, st);
+    if (e != hipSuccess) { set_error("qed_loss_reduce: memset failed: %s", hipGetErrorString(e)); return QED_E_LAUNCH; }
+    if (channels == 4)
+        hipLaunchKernelGGL(loss_reduce_kernel<4>, dim3(stream_grid(n_pix)), dim3(256), 0, st, n_pix, render, alpha,
+                           background, gt_rgb, gt_depth, mask, sums);
+    else
+        hipLaunchKernelGGL(loss_reduce_kernel<3>, dim3(stream_grid(n_pix)), dim3(256), 0, st, n_pix, render, alpha,
+                           background, gt_rgb, gt_depth, mask, sums);
+    return check_launch("qed_loss_reduce");
+}
+
+extern "C" int qed_loss_grad(int32_t n_pix, int32_t channels, const float* render, const float* alpha,
+                             const float* background, const float* gt_rgb, const float* gt_depth, const float* mask,
+                             const float* sums, float rgb_weight, float depth_lambda, float* v_render,
+                             float* v_alpha, float* losses, void* stream) {
+    QED_REQUIRE(n_pix > 0 && (channels == 3 || channels == 4), "bad arguments");
+    QED_REQUIRE(render && alpha && background && gt_rgb && sums && v_render && v_alpha && losses, "null buffers");
+    QED_REQUIRE(channels == 3 || gt_depth, "gt_depth required with a depth channel");
+    hipStream_t st = (hipStream_t)stream;
+    float* sums_rw = const_cast<float*>(sums);     // slot [1] is accumulated by this pass
+    if (channels == 4)
+        hipLaunchKernelGGL(loss_grad_kernel<4>, dim3(stream_grid(n_pix)), dim3(256), 0, st, n_pix, render, alpha,
+                           background, gt_rgb, gt_depth, mask, sums_rw, rgb_weight, depth_lambda, v_render, v_alpha);
+    else
+        hipLaunchKernelGGL(loss_grad_kernel<3>, dim3(stream_grid(n_pix)), dim3(256), 0, st, n_pix, render, alpha,
+                           background, gt_rgb, gt_depth, mask, sums_rw, rgb_weight, depth_lambda, v_render, v_alpha);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, n_pix, sums, rgb_weight, depth_lambda, losses);
+    return check_launch("qed_loss_grad");
+}
+
+extern "C" int qed_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t n_groups,
+                             const int64_t* h_group_begin, const float* h_lr, float beta1, float beta2, float eps,
+                             int32_t step, void* stream) {
+    QED_REQUIRE(n_groups >= 1 && n_groups <= 8, "1..8 parameter groups");
+    QED_REQUIRE(params && grads && exp_avg && exp_avg_sq && h_group_begin && h_lr && step >= 1, "bad arguments");
+    QED_REQUIRE((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
+                "buffers must be 16-byte aligned");
+    AdamGroups grp;
+    for (int i = 0; i <= n_groups; ++i) grp.begin[i] = h_group_begin[i];
+    for (int i = n_groups + 1; i < 9; ++i) grp.begin[i] = h_group_begin[n_groups];
+    for (int i = 0; i < 8; ++i) grp.lr[i] = i < n_groups ? h_lr[i] : 0.f;
+    grp.n = n_groups;
+    QED_REQUIRE(grp.begin[0] == 0, "group 0 must start at element 0");
+    const long long total = grp.begin[n_groups];
+    if (total == 0) return QED_OK;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(total / 4 + 1)), dim3(256), 0, (hipStream_t)stream, params, grads,
+                       exp_avg, exp_avg_sq, grp, beta1, beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+    return check_launch("qed_adam_step");
+}

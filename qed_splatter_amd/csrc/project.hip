@@ -1,0 +1,642 @@
+// K1 + K2 fused: projection + spherical-harmonics colour, forward and backward.
+//
+// Replaces the projection / SH part of gsplat.rendering.rasterization as called at
+// /root/reference/qed_splatter/model.py:267-288 (math: SURVEY.md Appendix A.1-A.3, A.8) and,
+// with the QED_F_* activation flags, the eager torch ops around it (model.py:241, 264, 269-271).
+//
+// HBM-bound: one thread per Gaussian streams 44 B of geometry + 192 B of SH coefficients and
+// writes the 48-byte packed record the compositing kernels gather from, plus the separate
+// info[...] arrays the reference reads (model.py:289-292).
+#include "qed_common.h"
+
+namespace qed {
+
+struct Cam {
+    float R[9];
+    float t[3];
+    float fx, fy, cx, cy;
+    float campos[3];
+};
+
+__device__ __forceinline__ Cam load_cam(const float* __restrict__ viewmats, const float* __restrict__ Ks, int c) {
+    Cam cam;
+    const float* V = viewmats + 16 * c;
+    const float* K = Ks + 9 * c;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) cam.R[3 * i + j] = V[4 * i + j];
+        cam.t[i] = V[4 * i + 3];
+    }
+    cam.fx = K[0]; cam.fy = K[4]; cam.cx = K[2]; cam.cy = K[5];
+    // camera position = -R^T t  (translation of the inverse view matrix)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        cam.campos[j] = -(cam.R[0 + j] * cam.t[0] + cam.R[3 + j] * cam.t[1] + cam.R[6 + j] * cam.t[2]);
+    return cam;
+}
+
+// normalised wxyz quaternion -> rotation matrix (row major)
+__device__ __forceinline__ void quat_to_rotmat(float w, float x, float y, float z, float* R) {
+    R[0] = 1.f - 2.f * (y * y + z * z); R[1] = 2.f * (x * y - w * z);       R[2] = 2.f * (x * z + w * y);
+    R[3] = 2.f * (x * y + w * z);       R[4] = 1.f - 2.f * (x * x + z * z); R[5] = 2.f * (y * z - w * x);
+    R[6] = 2.f * (x * z - w * y);       R[7] = 2.f * (y * z + w * x);       R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+// C = A(3x3) * B(3x3), row major
+__device__ __forceinline__ void mat3_mul(const float* A, const float* B, float* C) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+
+// Everything the projection of one Gaussian into one camera produces.
+struct Proj {
+    bool valid;
+    float mx, my, z;        // mean2d, depth
+    float A, B, Cc, det;    // blurred 2D covariance and its determinant
+    float ca, cb, cc;       // conic
+    float comp;             // anti-aliasing compensation
+    float radius;
+    float x, y, rz;         // camera-space mean
+    float tx, ty;           // clamped x, y used by the Jacobian
+    bool clamp_x, clamp_y;
+    float Tm[6];            // T = J * W (2x3), cov2d = T T^T + eps I
+    float W[9];             // W = R_cam * R_q * diag(s)
+    float M[9];             // M = R_q * diag(s)
+    float Rq[9];
+};
+
+__device__ __forceinline__ void project_one(const Cam& cam, const float* mean, const float* qn, const float* s,
+                                            int width, int height, float eps2d, float near_plane, float far_plane,
+                                            float radius_clip, Proj& p) {
+    p.valid = false;
+    p.x = cam.R[0] * mean[0] + cam.R[1] * mean[1] + cam.R[2] * mean[2] + cam.t[0];
+    p.y = cam.R[3] * mean[0] + cam.R[4] * mean[1] + cam.R[5] * mean[2] + cam.t[1];
+    p.z = cam.R[6] * mean[0] + cam.R[7] * mean[1] + cam.R[8] * mean[2] + cam.t[2];
+    if (p.z < near_plane || p.z > far_plane) return;
+
+    quat_to_rotmat(qn[0], qn[1], qn[2], qn[3], p.Rq);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) p.M[3 * i + j] = p.Rq[3 * i + j] * s[j];
+    mat3_mul(cam.R, p.M, p.W);
+
+    const float rz = 1.f / p.z;
+    const float rz2 = rz * rz;
+    p.rz = rz;
+    const float tan_fovx = 0.5f * width / cam.fx;
+    const float tan_fovy = 0.5f * height / cam.fy;
+    const float lim_x_pos = (width - cam.cx) / cam.fx + kJacMargin * tan_fovx;
+    const float lim_x_neg = cam.cx / cam.fx + kJacMargin * tan_fovx;
+    const float lim_y_pos = (height - cam.cy) / cam.fy + kJacMargin * tan_fovy;
+    const float lim_y_neg = cam.cy / cam.fy + kJacMargin * tan_fovy;
+    const float xr = p.x * rz, yr = p.y * rz;
+    p.clamp_x = !(xr <= lim_x_pos && xr >= -lim_x_neg);
+    p.clamp_y = !(yr <= lim_y_pos && yr >= -lim_y_neg);
+    p.tx = p.z * fminf(lim_x_pos, fmaxf(-lim_x_neg, xr));
+    p.ty = p.z * fminf(lim_y_pos, fmaxf(-lim_y_neg, yr));
+    const float j00 = cam.fx * rz, j02 = -cam.fx * p.tx * rz2;
+    const float j11 = cam.fy * rz, j12 = -cam.fy * p.ty * rz2;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        p.Tm[j] = j00 * p.W[j] + j02 * p.W[6 + j];
+        p.Tm[3 + j] = j11 * p.W[3 + j] + j12 * p.W[6 + j];
+    }
+    const float a0 = p.Tm[0] * p.Tm[0] + p.Tm[1] * p.Tm[1] + p.Tm[2] * p.Tm[2];
+    const float b0 = p.Tm[0] * p.Tm[3] + p.Tm[1] * p.Tm[4] + p.Tm[2] * p.Tm[5];
+    const float c0 = p.Tm[3] * p.Tm[3] + p.Tm[4] * p.Tm[4] + p.Tm[5] * p.Tm[5];
+    p.mx = cam.fx * p.x * rz + cam.cx;
+    p.my = cam.fy * p.y * rz + cam.cy;
+
+    const float det_orig = a0 * c0 - b0 * b0;
+    p.A = a0 + eps2d;
+    p.B = b0;
+    p.Cc = c0 + eps2d;
+    p.det = p.A * p.Cc - p.B * p.B;
+    if (p.det <= 0.f) return;
+    p.comp = sqrtf(fmaxf(0.f, det_orig / p.det));
+    const float rdet = 1.f / p.det;
+    p.ca = p.Cc * rdet;
+    p.cb = -p.B * rdet;
+    p.cc = p.A * rdet;
+
+    const float bh = 0.5f * (p.A + p.Cc);
+    const float v1 = bh + sqrtf(fmaxf(0.01f, bh * bh - p.det));
+    p.radius = ceilf(3.f * sqrtf(v1));
+    if (p.radius <= radius_clip) return;
+    if (p.mx + p.radius <= 0.f || p.mx - p.radius >= (float)width || p.my + p.radius <= 0.f ||
+        p.my - p.radius >= (float)height)
+        return;
+    p.valid = true;
+}
+
+// ---- spherical harmonics (standard real SH basis, 3DGS constants) ------------------------------
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+__device__ __constant__ float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                          -1.0925484305920792f, 0.5462742152960396f};
+__device__ __constant__ float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                          0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                          -0.5900435899266435f};
+
+// basis values b[0..K) for unit direction (x,y,z)
+template <int DEG>
+__device__ __forceinline__ void sh_basis(float x, float y, float z, float* b) {
+    b[0] = SH_C0;
+    if constexpr (DEG > 0) {
+        b[1] = -SH_C1 * y; b[2] = SH_C1 * z; b[3] = -SH_C1 * x;
+    }
+    if constexpr (DEG > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        b[4] = 1.0925484305920792f * xy;
+        b[5] = -1.0925484305920792f * yz;
+        b[6] = 0.31539156525252005f * (2.f * zz - xx - yy);
+        b[7] = -1.0925484305920792f * xz;
+        b[8] = 0.5462742152960396f * (xx - yy);
+        if constexpr (DEG > 2) {
+            b[9] = -0.5900435899266435f * y * (3.f * xx - yy);
+            b[10] = 2.890611442640554f * xy * z;
+            b[11] = -0.4570457994644658f * y * (4.f * zz - xx - yy);
+            b[12] = 0.3731763325901154f * z * (2.f * zz - 3.f * xx - 3.f * yy);
+            b[13] = -0.4570457994644658f * x * (4.f * zz - xx - yy);
+            b[14] = 1.445305721320277f * z * (xx - yy);
+            b[15] = -0.5900435899266435f * x * (xx - 3.f * yy);
+        }
+    }
+}
+
+// d(basis)/dx, /dy, /dz
+template <int DEG>
+__device__ __forceinline__ void sh_basis_grad(float x, float y, float z, float* bx, float* by, float* bz) {
+    bx[0] = by[0] = bz[0] = 0.f;
+    if constexpr (DEG > 0) {
+        bx[1] = 0.f;     by[1] = -SH_C1; bz[1] = 0.f;
+        bx[2] = 0.f;     by[2] = 0.f;    bz[2] = SH_C1;
+        bx[3] = -SH_C1;  by[3] = 0.f;    bz[3] = 0.f;
+    }
+    if constexpr (DEG > 1) {
+        const float c0 = 1.0925484305920792f, c2 = 0.31539156525252005f, c4 = 0.5462742152960396f;
+        bx[4] = c0 * y;         by[4] = c0 * x;         bz[4] = 0.f;
+        bx[5] = 0.f;            by[5] = -c0 * z;        bz[5] = -c0 * y;
+        bx[6] = -2.f * c2 * x;  by[6] = -2.f * c2 * y;  bz[6] = 4.f * c2 * z;
+        bx[7] = -c0 * z;        by[7] = 0.f;            bz[7] = -c0 * x;
+        bx[8] = 2.f * c4 * x;   by[8] = -2.f * c4 * y;  bz[8] = 0.f;
+        if constexpr (DEG > 2) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            const float k0 = -0.5900435899266435f, k1 = 2.890611442640554f, k2 = -0.4570457994644658f,
+                        k3 = 0.3731763325901154f, k5 = 1.445305721320277f;
+            bx[9] = k0 * 6.f * xy;                  by[9] = k0 * 3.f * (xx - yy);            bz[9] = 0.f;
+            bx[10] = k1 * yz;                       by[10] = k1 * xz;                        bz[10] = k1 * xy;
+            bx[11] = k2 * (-2.f * xy);              by[11] = k2 * (4.f * zz - xx - 3.f * yy); bz[11] = k2 * 8.f * yz;
+            bx[12] = k3 * (-6.f * xz);              by[12] = k3 * (-6.f * yz);               bz[12] = k3 * 3.f * (2.f * zz - xx - yy);
+            bx[13] = k2 * (4.f * zz - 3.f * xx - yy); by[13] = k2 * (-2.f * xy);             bz[13] = k2 * 8.f * xz;
+            bx[14] = k5 * 2.f * xz;                 by[14] = k5 * (-2.f * yz);               bz[14] = k5 * (xx - yy);
+            bx[15] = k0 * 3.f * (xx - yy);          by[15] = k0 * (-6.f * xy);               bz[15] = 0.f;
+        }
+    }
+}
+
+// gather one Gaussian's SH coefficients (K x 3) into registers
+template <int K>
+__device__ __forceinline__ void load_sh(const float* __restrict__ sh0, const float* __restrict__ shN, float* c) {
+    c[0] = sh0[0]; c[1] = sh0[1]; c[2] = sh0[2];
+    if constexpr (K > 1) {
+#pragma unroll
+        for (int i = 0; i < 3 * (K - 1); ++i) c[3 + i] = shN[i];
+    }
+}
+
+template <int DEG>
+__device__ __forceinline__ void sh_color(const float* __restrict__ sh0, const float* __restrict__ shN,
+                                         const float* dir, float* rgb) {
+    constexpr int K = (DEG + 1) * (DEG + 1);
+    const float inorm = rsqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+    float b[K];
+    sh_basis<DEG>(dir[0] * inorm, dir[1] * inorm, dir[2] * inorm, b);
+    float c[3 * K];
+    load_sh<K>(sh0, shN, c);
+    float r = 0.f, g = 0.f, bl = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        r += b[k] * c[3 * k]; g += b[k] * c[3 * k + 1]; bl += b[k] * c[3 * k + 2];
+    }
+    rgb[0] = fmaxf(r + 0.5f, 0.f); rgb[1] = fmaxf(g + 0.5f, 0.f); rgb[2] = fmaxf(bl + 0.5f, 0.f);
+}
+
+__device__ __forceinline__ void sh_color_dyn(int deg, const float* sh0, const float* shN, const float* dir, float* rgb) {
+    switch (deg) {
+        case 0: sh_color<0>(sh0, shN, dir, rgb); break;
+        case 1: sh_color<1>(sh0, shN, dir, rgb); break;
+        case 2: sh_color<2>(sh0, shN, dir, rgb); break;
+        default: sh_color<3>(sh0, shN, dir, rgb); break;
+    }
+}
+
+// ================================================================================================
+// forward
+// ================================================================================================
+__global__ void __launch_bounds__(256)
+project_fwd_kernel(int N, int C, const float* __restrict__ means, const float* __restrict__ quats,
+                   const float* __restrict__ scales, const float* __restrict__ opacities,
+                   const float* __restrict__ sh0, int sh0_stride, const float* __restrict__ shN, int shN_stride,
+                   int sh_degree, const float* __restrict__ viewmats, const float* __restrict__ Ks, int width,
+                   int height, int tile_w, int tile_h, float eps2d, float near_plane, float far_plane,
+                   float radius_clip, unsigned flags, int* __restrict__ radii, float* __restrict__ means2d,
+                   float* __restrict__ depths, float* __restrict__ conics, float* __restrict__ opac_out,
+                   float* __restrict__ colors_out, float4* __restrict__ splats, int* __restrict__ tiles_per_gauss,
+                   int* __restrict__ block_sums) {
+    // slot = c * N + n ; 256 consecutive slots per block (block_sums granularity)
+    const long long slot = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)C * N;
+    int ntiles = 0;
+    if (slot < total) {
+        const int c = (int)(slot / N);
+        const int n = (int)(slot - (long long)c * N);
+        const Cam cam = load_cam(viewmats, Ks, c);
+        float mean[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
+        float q[4] = {quats[4 * n], quats[4 * n + 1], quats[4 * n + 2], quats[4 * n + 3]};
+        const float qin = rsqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        q[0] *= qin; q[1] *= qin; q[2] *= qin; q[3] *= qin;
+        float s[3] = {scales[3 * n], scales[3 * n + 1], scales[3 * n + 2]};
+        if (flags & QED_F_LOG_SCALES) { s[0] = __expf(s[0]); s[1] = __expf(s[1]); s[2] = __expf(s[2]); }
+        Proj p;
+        project_one(cam, mean, q, s, width, height, eps2d, near_plane, far_plane, radius_clip, p);
+
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+        int rad = 0;
+        float mx = 0.f, my = 0.f, z = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, op = 0.f;
+        float rgb[3] = {0.f, 0.f, 0.f};
+        if (p.valid) {
+            rad = (int)p.radius;
+            mx = p.mx; my = p.my; z = p.z; ca = p.ca; cb = p.cb; cc = p.cc;
+            op = opacities[n];
+            if (flags & QED_F_LOGIT_OPAC) op = sigmoidf_dev(op);
+            if (flags & QED_F_ANTIALIASED) op *= p.comp;
+            if (sh_degree >= 0) {
+                const float dir[3] = {mean[0] - cam.campos[0], mean[1] - cam.campos[1], mean[2] - cam.campos[2]};
+                sh_color_dyn(sh_degree, sh0 + (size_t)n * sh0_stride, shN + (size_t)n * shN_stride, dir, rgb);
+            } else {
+                const float* cptr = sh0 + (size_t)n * sh0_stride;
+                rgb[0] = cptr[0]; rgb[1] = cptr[1]; rgb[2] = cptr[2];
+                if (flags & QED_F_SIGMOID_COLORS) {
+                    rgb[0] = sigmoidf_dev(rgb[0]); rgb[1] = sigmoidf_dev(rgb[1]); rgb[2] = sigmoidf_dev(rgb[2]);
+                }
+            }
+            int x0, y0, x1, y1;
+            tile_rect(mx, my, p.radius, tile_w, tile_h, x0, y0, x1, y1);
+            ntiles = (x1 - x0) * (y1 - y0);
+            r0 = make_float4(mx, my, ca, cb);
+            r1 = make_float4(cc, op, rgb[0], rgb[1]);
+            r2 = make_float4(rgb[2], (flags & QED_F_DEPTH_CHANNEL) ? z : 0.f, 0.f, 0.f);
+        }
+        radii[slot] = rad;
+        means2d[2 * slot] = mx; means2d[2 * slot + 1] = my;
+        depths[slot] = z;
+        conics[3 * slot] = ca; conics[3 * slot + 1] = cb; conics[3 * slot + 2] = cc;
+        opac_out[slot] = op;
+        colors_out[3 * slot] = rgb[0]; colors_out[3 * slot + 1] = rgb[1]; colors_out[3 * slot + 2] = rgb[2];
+        splats[3 * slot] = r0; splats[3 * slot + 1] = r1; splats[3 * slot + 2] = r2;
+        tiles_per_gauss[slot] = ntiles;
+    }
+    // block sum of tile counts (input of the intersection scan)
+    __shared__ int wsum[4];
+    int v = ntiles;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// ================================================================================================
+// backward
+// ================================================================================================
+template <int DEG>
+__device__ __forceinline__ void sh_bwd(const float* __restrict__ sh0, const float* __restrict__ shN,
+                                       const float* dir, const float* v_rgb_in, float* v_coef /*3K, +=*/,
+                                       float* v_dir /*3, +=*/) {
+    constexpr int K = (DEG + 1) * (DEG + 1);
+    const float n2 = dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2];
+    const float inorm = rsqrtf(n2);
+    const float x = dir[0] * inorm, y = dir[1] * inorm, z = dir[2] * inorm;
+    float b[K];
+    sh_basis<DEG>(x, y, z, b);
+    float c[3 * K];
+    load_sh<K>(sh0, shN, c);
+    float col[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        col[0] += b[k] * c[3 * k]; col[1] += b[k] * c[3 * k + 1]; col[2] += b[k] * c[3 * k + 2];
+    }
+    // clamp_min(colour + 0.5, 0): gradient passes where colour + 0.5 >= 0
+    float v[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) v[ch] = (col[ch] + 0.5f >= 0.f) ? v_rgb_in[ch] : 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        v_coef[3 * k] += b[k] * v[0]; v_coef[3 * k + 1] += b[k] * v[1]; v_coef[3 * k + 2] += b[k] * v[2];
+    }
+    if constexpr (DEG > 0) {
+        float bx[K], by[K], bz[K];
+        sh_basis_grad<DEG>(x, y, z, bx, by, bz);
+        float vx = 0.f, vy = 0.f, vz = 0.f;
+#pragma unroll
+        for (int k = 1; k < K; ++k) {
+            const float w = c[3 * k] * v[0] + c[3 * k + 1] * v[1] + c[3 * k + 2] * v[2];
+            vx += bx[k] * w; vy += by[k] * w; vz += bz[k] * w;
+        }
+        // through d = dir / |dir|
+        const float dot = vx * x + vy * y + vz * z;
+        v_dir[0] += (vx - dot * x) * inorm;
+        v_dir[1] += (vy - dot * y) * inorm;
+        v_dir[2] += (vz - dot * z) * inorm;
+    }
+}
+
+template <int DEG>
+__global__ void __launch_bounds__(256)
+project_bwd_kernel(int N, int C, const float* __restrict__ means, const float* __restrict__ quats,
+                   const float* __restrict__ scales, const float* __restrict__ opacities,
+                   const float* __restrict__ sh0, int sh0_stride, const float* __restrict__ shN, int shN_stride,
+                   const float* __restrict__ viewmats, const float* __restrict__ Ks, int width, int height,
+                   float eps2d, unsigned flags, const int* __restrict__ radii, const float4* __restrict__ vsplat,
+                   float* __restrict__ v_means, float* __restrict__ v_quats, float* __restrict__ v_scales,
+                   float* __restrict__ v_opacities, float* __restrict__ v_sh0, int v_sh0_stride,
+                   float* __restrict__ v_shN, int v_shN_stride, float* __restrict__ v_viewmats) {
+    // DEG = -1: colours pass through (sh_degree None)
+    constexpr int K = DEG < 0 ? 1 : (DEG + 1) * (DEG + 1);
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const bool active = n < N;
+
+    float vm[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f}, vo = 0.f;
+    float vcoef[3 * K];
+#pragma unroll
+    for (int i = 0; i < 3 * K; ++i) vcoef[i] = 0.f;
+
+    float mean[3] = {0.f, 0.f, 0.f}, qraw[4] = {1.f, 0.f, 0.f, 0.f}, q[4], sraw[3] = {0.f, 0.f, 0.f}, s[3];
+    float qin = 1.f, oraw = 0.f, oact = 0.f;
+    if (active) {
+        mean[0] = means[3 * n]; mean[1] = means[3 * n + 1]; mean[2] = means[3 * n + 2];
+        qraw[0] = quats[4 * n]; qraw[1] = quats[4 * n + 1]; qraw[2] = quats[4 * n + 2]; qraw[3] = quats[4 * n + 3];
+        sraw[0] = scales[3 * n]; sraw[1] = scales[3 * n + 1]; sraw[2] = scales[3 * n + 2];
+        oraw = opacities[n];
+    }
+    qin = rsqrtf(qraw[0] * qraw[0] + qraw[1] * qraw[1] + qraw[2] * qraw[2] + qraw[3] * qraw[3]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = qraw[i] * qin;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) s[i] = (flags & QED_F_LOG_SCALES) ? __expf(sraw[i]) : sraw[i];
+    oact = (flags & QED_F_LOGIT_OPAC) ? sigmoidf_dev(oraw) : oraw;
+
+    for (int c = 0; c < C; ++c) {
+        const Cam cam = load_cam(viewmats, Ks, c);
+        const size_t slot = (size_t)c * N + n;
+        const bool vis = active && radii[slot] > 0;
+        float vR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, vt[3] = {0.f, 0.f, 0.f};
+        if (vis) {
+            Proj p;
+            // radius_clip / near / far already decided in the forward pass (radii > 0)
+            project_one(cam, mean, q, s, width, height, eps2d, -3.0e38f, 3.0e38f, -1.f, p);
+            const float4 g0 = vsplat[4 * slot], g1 = vsplat[4 * slot + 1], g2 = vsplat[4 * slot + 2];
+            const float v_mx = g0.x, v_my = g0.y;
+            float v_ca = g1.x, v_cb = g1.y, v_cc = g1.z;
+            const float v_op = g1.w;
+            const float v_rgb[3] = {g2.x, g2.y, g2.z};
+            const float v_depth = (flags & QED_F_DEPTH_CHANNEL) ? g2.w : 0.f;
+
+            // ---- opacity (+ compensation) ----
+            float v_comp = 0.f;
+            if (flags & QED_F_ANTIALIASED) {
+                vo += v_op * p.comp;
+                v_comp = v_op * oact;
+            } else {
+                vo += v_op;
+            }
+            // ---- conic -> blurred covariance:  H = -X G X,  X = conic, G = [[v_ca, v_cb/2],[v_cb/2, v_cc]] ----
+            const float g01 = 0.5f * v_cb;
+            const float xg00 = p.ca * v_ca + p.cb * g01, xg01 = p.ca * g01 + p.cb * v_cc;
+            const float xg10 = p.cb * v_ca + p.cc * g01, xg11 = p.cb * g01 + p.cc * v_cc;
+            float h00 = -(xg00 * p.ca + xg01 * p.cb);
+            float h01 = -(xg00 * p.cb + xg01 * p.cc);
+            float h11 = -(xg10 * p.cb + xg11 * p.cc);
+            if (flags & QED_F_ANTIALIASED) {
+                // compensation = sqrt(max(0, det_orig / det_blur))  (gsplat add_blur_vjp)
+                const float det_conic = p.ca * p.cc - p.cb * p.cb;
+                const float v_sqr = v_comp * 0.5f / (p.comp + 1e-6f);
+                const float om = 1.f - p.comp * p.comp;
+                h00 += v_sqr * (om * p.ca - eps2d * det_conic);
+                h01 += v_sqr * (om * p.cb);
+                h11 += v_sqr * (om * p.cc - eps2d * det_conic);
+            }
+            // ---- cov2d = T T^T + eps I  ->  v_T = 2 H T ----
+            float vT[6];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                vT[j] = 2.f * (h00 * p.Tm[j] + h01 * p.Tm[3 + j]);
+                vT[3 + j] = 2.f * (h01 * p.Tm[j] + h11 * p.Tm[3 + j]);
+            }
+            // ---- T = J W ----
+            const float rz = p.rz, rz2 = rz * rz, rz3 = rz2 * rz;
+            const float j00 = cam.fx * rz, j02 = -cam.fx * p.tx * rz2;
+            const float j11 = cam.fy * rz, j12 = -cam.fy * p.ty * rz2;
+            // v_J = v_T W^T (only the 4 non-constant entries)
+            const float vJ00 = vT[0] * p.W[0] + vT[1] * p.W[1] + vT[2] * p.W[2];
+            const float vJ02 = vT[0] * p.W[6] + vT[1] * p.W[7] + vT[2] * p.W[8];
+            const float vJ11 = vT[3] * p.W[3] + vT[4] * p.W[4] + vT[5] * p.W[5];
+            const float vJ12 = vT[3] * p.W[6] + vT[4] * p.W[7] + vT[5] * p.W[8];
+            // v_W = J^T v_T
+            float vW[9];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                vW[j] = j00 * vT[j];
+                vW[3 + j] = j11 * vT[3 + j];
+                vW[6 + j] = j02 * vT[j] + j12 * vT[3 + j];
+            }
+            // ---- camera-space mean ----
+            float vx = v_mx * cam.fx * rz;
+            float vy = v_my * cam.fy * rz;
+            float vz = -v_mx * cam.fx * p.x * rz2 - v_my * cam.fy * p.y * rz2 - vJ00 * cam.fx * rz2 -
+                       vJ11 * cam.fy * rz2 + v_depth;
+            if (!p.clamp_x) {
+                vx += -cam.fx * rz2 * vJ02;
+                vz += 2.f * cam.fx * p.tx * rz3 * vJ02;
+            } else {
+                vz += cam.fx * p.tx * rz3 * vJ02;
+            }
+            if (!p.clamp_y) {
+                vy += -cam.fy * rz2 * vJ12;
+                vz += 2.f * cam.fy * p.ty * rz3 * vJ12;
+            } else {
+                vz += cam.fy * p.ty * rz3 * vJ12;
+            }
+            // world mean: mean_c = R mean + t
+            float vmw[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) vmw[j] = cam.R[j] * vx + cam.R[3 + j] * vy + cam.R[6 + j] * vz;
+            // ---- W = R_cam M  ->  v_M = R_cam^T v_W ----
+            float vM[9];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    vM[3 * i + j] = cam.R[i] * vW[j] + cam.R[3 + i] * vW[3 + j] + cam.R[6 + i] * vW[6 + j];
+            // ---- SH colour ----
+            float vdir[3] = {0.f, 0.f, 0.f};
+            if constexpr (DEG >= 0) {
+                const float dir[3] = {mean[0] - cam.campos[0], mean[1] - cam.campos[1], mean[2] - cam.campos[2]};
+                sh_bwd<(DEG < 0 ? 0 : DEG)>(sh0 + (size_t)n * sh0_stride, shN + (size_t)n * shN_stride, dir, v_rgb,
+                                            vcoef, vdir);
+            } else {
+                if (flags & QED_F_SIGMOID_COLORS) {
+                    const float* cptr = sh0 + (size_t)n * sh0_stride;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const float sg = sigmoidf_dev(cptr[ch]);
+                        vcoef[ch] += v_rgb[ch] * sg * (1.f - sg);
+                    }
+                } else {
+                    vcoef[0] += v_rgb[0]; vcoef[1] += v_rgb[1]; vcoef[2] += v_rgb[2];
+                }
+            }
+            vm[0] += vmw[0] + vdir[0]; vm[1] += vmw[1] + vdir[1]; vm[2] += vmw[2] + vdir[2];
+            // ---- M = Rq diag(s) ----
+            float vRq[9];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    vRq[3 * i + j] = vM[3 * i + j] * s[j];
+                    vs[j] += vM[3 * i + j] * p.Rq[3 * i + j];
+                }
+            // ---- Rq(q) with q normalised ----
+            const float w = q[0], x = q[1], y = q[2], z = q[3];
+            float vqn[4];
+            vqn[0] = 2.f * (x * (vRq[7] - vRq[5]) + y * (vRq[2] - vRq[6]) + z * (vRq[3] - vRq[1]));
+            vqn[1] = 2.f * (-2.f * x * (vRq[4] + vRq[8]) + y * (vRq[1] + vRq[3]) + z * (vRq[2] + vRq[6]) +
+                            w * (vRq[7] - vRq[5]));
+            vqn[2] = 2.f * (x * (vRq[1] + vRq[3]) - 2.f * y * (vRq[0] + vRq[8]) + z * (vRq[5] + vRq[7]) +
+                            w * (vRq[2] - vRq[6]));
+            vqn[3] = 2.f * (x * (vRq[2] + vRq[6]) + y * (vRq[5] + vRq[7]) - 2.f * z * (vRq[0] + vRq[4]) +
+                            w * (vRq[3] - vRq[1]));
+            vq[0] += vqn[0]; vq[1] += vqn[1]; vq[2] += vqn[2]; vq[3] += vqn[3];
+
+            if (v_viewmats != nullptr) {
+                // v_R = v_meanc mean^T + v_W M^T ; v_t = v_meanc ; campos = -R^T t feeds the SH direction
+                const float vmc[3] = {vx, vy, vz};
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        vR[3 * i + j] = vmc[i] * mean[j] + vW[3 * i] * p.M[3 * j] + vW[3 * i + 1] * p.M[3 * j + 1] +
+                                        vW[3 * i + 2] * p.M[3 * j + 2];
+                    }
+                    vt[i] = vmc[i];
+                }
+                // dir = mean - campos, campos_j = -sum_i R_ij t_i  ->  v_campos = -v_dir
+                // v_R_ij += -v_campos_j * t_i = v_dir_j * t_i ;  v_t_i += sum_j v_dir_j R_ij
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        vR[3 * i + j] += vdir[j] * cam.t[i];
+                        vt[i] += vdir[j] * cam.R[3 * i + j];
+                    }
+                }
+            }
+        }
+        if (v_viewmats != nullptr) {
+            // block reduction -> 12 atomics per block per camera
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                float v = i < 9 ? vR[i] : vt[i - 9];
+                v = wave_sum(v);
+                if ((threadIdx.x & 63) == 0 && v != 0.f) {
+                    const int row = i < 9 ? i / 3 : i - 9, col = i < 9 ? i % 3 : 3;
+                    atomicAdd(&v_viewmats[16 * c + 4 * row + col], v);
+                }
+            }
+        }
+    }
+    if (!active) return;
+    // normalisation q = qraw / |qraw|:  v_qraw = (v_q - (v_q . q) q) / |qraw|
+    const float dq = vq[0] * q[0] + vq[1] * q[1] + vq[2] * q[2] + vq[3] * q[3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v_quats[4 * n + i] = (vq[i] - dq * q[i]) * qin;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        v_means[3 * n + i] = vm[i];
+        v_scales[3 * n + i] = (flags & QED_F_LOG_SCALES) ? vs[i] * s[i] : vs[i];
+    }
+    v_opacities[n] = (flags & QED_F_LOGIT_OPAC) ? vo * oact * (1.f - oact) : vo;
+    float* o0 = v_sh0 + (size_t)n * v_sh0_stride;
+    o0[0] = vcoef[0]; o0[1] = vcoef[1]; o0[2] = vcoef[2];
+    if constexpr (K > 1) {
+        float* oN = v_shN + (size_t)n * v_shN_stride;
+#pragma unroll
+        for (int i = 0; i < 3 * (K - 1); ++i) oN[i] = vcoef[3 + i];
+    }
+}
+
+}  // namespace qed
+
+using namespace qed;
+
+extern "C" int qed_project_fwd(int32_t N, int32_t C, const float* means, const float* quats, const float* scales,
+                               const float* opacities, const float* sh0, int32_t sh0_stride, const float* shN,
+                               int32_t shN_stride, int32_t sh_degree, const float* viewmats, const float* Ks,
+                               int32_t width, int32_t height, int32_t tile_w, int32_t tile_h, float eps2d,
+                               float near_plane, float far_plane, float radius_clip, uint32_t flags, int32_t* radii,
+                               float* means2d, float* depths, float* conics, float* opac_out, float* colors_out,
+                               float* splats, int32_t* tiles_per_gauss, int32_t* block_sums, void* stream) {
+    QED_REQUIRE(N >= 0 && C >= 1, "N >= 0 and C >= 1 required");
+    QED_REQUIRE(sh_degree <= 3, "SH degree > 3 unsupported (reference config uses sh_degree = 3)");
+    QED_REQUIRE(width > 0 && height > 0 && tile_w > 0 && tile_h > 0, "bad image / tile extents");
+    QED_REQUIRE((long long)tile_w * tile_h < (1ll << 30), "too many tiles");
+    if (N == 0) return QED_OK;
+    QED_REQUIRE(means && quats && scales && opacities && sh0 && viewmats && Ks, "null input");
+    QED_REQUIRE(sh_degree <= 0 || shN, "shN required for sh_degree > 0");
+    QED_REQUIRE(radii && means2d && depths && conics && opac_out && colors_out && splats && tiles_per_gauss &&
+                    block_sums, "null output");
+    const long long total = (long long)C * N;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(project_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, N, C, means, quats, scales,
+                       opacities, sh0, sh0_stride, shN, shN_stride, sh_degree, viewmats, Ks, width, height, tile_w,
+                       tile_h, eps2d, near_plane, far_plane, radius_clip, flags, radii, means2d, depths, conics,
+                       opac_out, colors_out, (float4*)splats, tiles_per_gauss, block_sums);
+    return check_launch("qed_project_fwd");
+}
+
+extern "C" int qed_project_bwd(int32_t N, int32_t C, const float* means, const float* quats, const float* scales,
+                               const float* opacities, const float* sh0, int32_t sh0_stride, const float* shN,
+                               int32_t shN_stride, int32_t sh_degree, const float* viewmats, const float* Ks,
+                               int32_t width, int32_t height, float eps2d, uint32_t flags, const int32_t* radii,
+                               const float* vsplat, float* v_means, float* v_quats, float* v_scales,
+                               float* v_opacities, float* v_sh0, int32_t v_sh0_stride, float* v_shN,
+                               int32_t v_shN_stride, float* v_viewmats, void* stream) {
+    QED_REQUIRE(N >= 0 && C >= 1, "N >= 0 and C >= 1 required");
+    QED_REQUIRE(sh_degree <= 3, "SH degree > 3 unsupported");
+    if (N == 0) return QED_OK;
+    QED_REQUIRE(means && quats && scales && opacities && sh0 && viewmats && Ks && radii && vsplat, "null input");
+    QED_REQUIRE(v_means && v_quats && v_scales && v_opacities && v_sh0, "null output");
+    QED_REQUIRE(sh_degree <= 0 || (shN && v_shN), "shN / v_shN required for sh_degree > 0");
+    const unsigned grid = (unsigned)((N + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+#define QED_LAUNCH_BWD(D)                                                                                          \
+    hipLaunchKernelGGL(project_bwd_kernel<D>, dim3(grid), dim3(256), 0, st, N, C, means, quats, scales, opacities, \
+                       sh0, sh0_stride, shN, shN_stride, viewmats, Ks, width, height, eps2d, flags, radii,         \
+                       (const float4*)vsplat, v_means, v_quats, v_scales, v_opacities, v_sh0, v_sh0_stride, v_shN, \
+                       v_shN_stride, v_viewmats)
+    switch (sh_degree) {
+        case 0: QED_LAUNCH_BWD(0); break;
+        case 1: QED_LAUNCH_BWD(1); break;
+        case 2: QED_LAUNCH_BWD(2); break;
+        case 3: QED_LAUNCH_BWD(3); break;
+        default: QED_LAUNCH_BWD(-1); break;
+    }
+#undef QED_LAUNCH_BWD
+    return check_launch("qed_project_bwd");
+}

@@ -1,0 +1,82 @@
+// Shared helpers for the gfx950 kernels of libqed_splat.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/qed_splat.h"
+
+namespace qed {
+
+void set_error(const char* fmt, ...);
+
+// constants of the operator behind model.py:267-288
+constexpr float kAlphaMax = 0.999f;
+constexpr float kAlphaMin = 1.0f / 255.0f;
+constexpr float kTMin = 1e-4f;
+constexpr float kJacMargin = 0.3f;
+
+constexpr int kWave = 64;  // gfx950 wavefront
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return QED_E_LAUNCH;
+    }
+    return QED_OK;
+}
+
+#define QED_REQUIRE(cond, msg)                                 \
+    do {                                                       \
+        if (!(cond)) {                                         \
+            qed::set_error("%s: %s", __func__, msg);           \
+            return QED_E_INVALID_ARG;                          \
+        }                                                      \
+    } while (0)
+
+__device__ __forceinline__ float sigmoidf_dev(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// tile rectangle [x0,x1) x [y0,y1) of a projected Gaussian (gsplat isect_tiles)
+__device__ __forceinline__ void tile_rect(float mx, float my, float radius, int tile_w, int tile_h, int& x0,
+                                          int& y0, int& x1, int& y1) {
+    const float ts = (float)QED_TILE;
+    const float tr = radius / ts, tx = mx / ts, ty = my / ts;
+    x0 = min(max(0, (int)floorf(tx - tr)), tile_w);
+    y0 = min(max(0, (int)floorf(ty - tr)), tile_h);
+    x1 = min(max(0, (int)ceilf(tx + tr)), tile_w);
+    y1 = min(max(0, (int)ceilf(ty + tr)), tile_h);
+}
+
+// ---- wave64 cross-lane helpers (DPP; no LDS traffic) --------------------------------------
+// sum over the 16 lanes of each DPP row; result valid in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+    // quad_perm / row_ror rotate within a row of 16 lanes
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));  // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+    return v;
+}
+
+// full wave64 sum, result valid in every lane
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+}  // namespace qed

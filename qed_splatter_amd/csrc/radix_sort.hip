@@ -1,0 +1,268 @@
+// K4: device LSD radix sort of (key, i32 value) pairs for gfx950 -- stable, 8-bit digits.
+//
+// Replaces the cub::DeviceRadixSort::SortPairs call inside gsplat's isect_tiles (behind
+// model.py:267-288).  Written for 64-wide waves: the in-block stable rank
+// uses 64-bit ballots ("match" on the digit), one LDS counter row per wave, and the scatter goes
+// through an LDS-staged reorder so that every digit run is written with consecutive lanes on
+// consecutive addresses.  HBM-bound: per pass each pair is read twice (histogram + scatter) and
+// written once.
+//
+// The element count is read from device memory (n_dev) so the whole pipeline can be enqueued
+// without a host round trip (and captured into a hipGraph); grids are sized by `capacity`.
+#include "qed_common.h"
+
+namespace qed {
+
+constexpr int kSortThreads = 256;
+constexpr int kSortWaves = kSortThreads / 64;
+constexpr int kRadixBits = 8;
+constexpr int kRadix = 1 << kRadixBits;
+
+template <typename KeyT, int KPT>
+struct SortCfg {
+    static constexpr int kItems = kSortThreads * KPT;
+};
+
+template <typename KeyT>
+__device__ __forceinline__ unsigned digit_of(KeyT k, int shift, unsigned mask) {
+    return (unsigned)(k >> shift) & mask;
+}
+
+// ---- (1) per-block digit histogram ----------------------------------------------------------------
+template <typename KeyT, int KPT>
+__global__ void __launch_bounds__(kSortThreads)
+sort_hist_kernel(const KeyT* __restrict__ keys, const int* __restrict__ n_dev, int shift, unsigned mask,
+                 int nblocks_max, int* __restrict__ hist) {
+    constexpr int kItems = SortCfg<KeyT, KPT>::kItems;
+    const int n = n_dev[0];
+    const long long base = (long long)blockIdx.x * kItems;
+    if (base >= n) return;
+    __shared__ int s_hist[kSortWaves][kRadix];
+    const int tid = threadIdx.x, wid = tid >> 6;
+#pragma unroll
+    for (int w = 0; w < kSortWaves; ++w) s_hist[w][tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        const long long i = base + k * kSortThreads + tid;
+        if (i < n) atomicAdd(&s_hist[wid][digit_of<KeyT>(keys[i], shift, mask)], 1);
+    }
+    __syncthreads();
+    int tot = 0;
+#pragma unroll
+    for (int w = 0; w < kSortWaves; ++w) tot += s_hist[w][tid];
+    hist[(long long)tid * nblocks_max + blockIdx.x] = tot;
+}
+
+// ---- (2) scan: one workgroup per digit row -> row-exclusive prefix in place + digit totals ------------
+template <int ITEMS>
+__global__ void __launch_bounds__(kSortThreads)
+sort_scan_kernel(const int* __restrict__ n_dev, int nblocks_max, int* __restrict__ hist, int* __restrict__ digit_tot) {
+    const int n = n_dev[0];
+    const int nb = (int)(((long long)n + ITEMS - 1) / ITEMS);
+    int* row = hist + (long long)blockIdx.x * nblocks_max;
+    __shared__ int s_wave[kSortWaves];
+    __shared__ int s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nb; b0 += kSortThreads) {
+        const int i = b0 + tid;
+        const int v = i < nb ? row[i] : 0;
+        int x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) s_wave[wid] = x;
+        __syncthreads();
+        int wb = 0;
+        for (int w = 0; w < wid; ++w) wb += s_wave[w];
+        const int carry = s_carry;
+        if (i < nb) row[i] = carry + wb + x - v;
+        __syncthreads();
+        if (tid == kSortThreads - 1) s_carry = carry + wb + x;
+        __syncthreads();
+    }
+    if (tid == 0) digit_tot[blockIdx.x] = s_carry;
+}
+
+// ---- (3) stable rank + scatter --------------------------------------------------------------------------
+template <typename KeyT, int KPT>
+__global__ void __launch_bounds__(kSortThreads)
+sort_scatter_kernel(const KeyT* __restrict__ keys_in, const int* __restrict__ vals_in, KeyT* __restrict__ keys_out,
+                    int* __restrict__ vals_out, const int* __restrict__ n_dev, int shift, unsigned mask,
+                    int nblocks_max, const int* __restrict__ hist, const int* __restrict__ digit_tot) {
+    constexpr int kItems = SortCfg<KeyT, KPT>::kItems;
+    const int n = n_dev[0];
+    const long long base = (long long)blockIdx.x * kItems;
+    if (base >= n) return;
+    const int block_n = (int)min((long long)kItems, (long long)n - base);
+
+    __shared__ KeyT s_keys[kItems];
+    __shared__ int s_vals[kItems];
+    __shared__ int s_cnt[kSortWaves][kRadix];   // per-wave digit counters -> per-wave digit bases
+    __shared__ int s_lbase[kRadix];             // block-local exclusive digit base
+    __shared__ int s_gofs[kRadix];              // global offset - local base
+    __shared__ int s_wsum[kSortWaves];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+#pragma unroll
+    for (int w = 0; w < kSortWaves; ++w) s_cnt[w][tid] = 0;
+
+    // wave-striped load: wave w owns [w*64*KPT, (w+1)*64*KPT), item k of lane l = k*64 + l
+    KeyT key[KPT];
+    int val[KPT];
+    int rank[KPT];
+    const int wbase = wid * 64 * KPT;
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        const int li = wbase + k * 64 + lane;
+        if (li < block_n) {
+            key[k] = keys_in[base + li];
+            val[k] = vals_in[base + li];
+        } else {
+            key[k] = (KeyT)0;
+            val[k] = 0;
+        }
+    }
+    __syncthreads();
+
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        const int li = wbase + k * 64 + lane;
+        const bool valid = li < block_n;
+        const unsigned d = digit_of<KeyT>(key[k], shift, mask);
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < kRadixBits; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        int r = 0;
+        if (valid) {
+            r = s_cnt[wid][d] + __popcll(peers & lt_mask);
+            // highest peer lane publishes the new count (after every peer has read the old one:
+            // LDS operations of one wave complete in program order)
+            if ((peers >> lane) == 1ull) s_cnt[wid][d] = r + 1;
+        }
+        rank[k] = r;
+    }
+    __syncthreads();
+
+    // thread tid owns digit tid: wave bases, block count, block-local scan, global offset
+    {
+        int c[kSortWaves];
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < kSortWaves; ++w) { c[w] = s_cnt[w][tid]; }
+#pragma unroll
+        for (int w = 0; w < kSortWaves; ++w) { s_cnt[w][tid] = tot; tot += c[w]; }
+        // exclusive scan of `tot` over the 256 digits, and of digit_tot (global)
+        int x = tot;
+        int g = digit_tot[tid];
+        int gx = g;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(x, o, 64);
+            const int gy = __shfl_up(gx, o, 64);
+            if (lane >= o) { x += y; gx += gy; }
+        }
+        __shared__ int s_gw[kSortWaves];
+        if (lane == 63) { s_wsum[wid] = x; s_gw[wid] = gx; }
+        __syncthreads();
+        int wb = 0, gwb = 0;
+        for (int w = 0; w < wid; ++w) { wb += s_wsum[w]; gwb += s_gw[w]; }
+        const int lbase = wb + x - tot;
+        const int gbase = gwb + gx - g + hist[(long long)tid * nblocks_max + blockIdx.x];
+        s_lbase[tid] = lbase;
+        s_gofs[tid] = gbase - lbase;
+    }
+    __syncthreads();
+
+    // reorder through LDS
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        const int li = wbase + k * 64 + lane;
+        if (li < block_n) {
+            const unsigned d = digit_of<KeyT>(key[k], shift, mask);
+            const int pos = s_lbase[d] + s_cnt[wid][d] + rank[k];
+            s_keys[pos] = key[k];
+            s_vals[pos] = val[k];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        const int pos = k * kSortThreads + tid;
+        if (pos < block_n) {
+            const KeyT kk = s_keys[pos];
+            const unsigned d = digit_of<KeyT>(kk, shift, mask);
+            const long long dst = (long long)s_gofs[d] + pos;
+            keys_out[dst] = kk;
+            vals_out[dst] = s_vals[pos];
+        }
+    }
+}
+
+template <typename KeyT, int KPT>
+static int sort_pairs_impl(KeyT* keys, int* vals, KeyT* keys_alt, int* vals_alt, const int* n_dev, long long capacity,
+                           int end_bit, void* workspace, long long workspace_bytes, hipStream_t st) {
+    constexpr int kItems = SortCfg<KeyT, KPT>::kItems;
+    const int nblocks_max = (int)((capacity + kItems - 1) / kItems);
+    if (nblocks_max == 0) return 0;
+    const long long need = ((long long)kRadix * nblocks_max + kRadix) * (long long)sizeof(int);
+    if (workspace_bytes < need) {
+        set_error("qed_sort_pairs: workspace too small (%lld < %lld)", workspace_bytes, need);
+        return QED_E_WORKSPACE;
+    }
+    int* hist = (int*)workspace;
+    int* digit_tot = hist + (long long)kRadix * nblocks_max;
+    const int passes = (end_bit + kRadixBits - 1) / kRadixBits;
+    KeyT* kin = keys; int* vin = vals; KeyT* kout = keys_alt; int* vout = vals_alt;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = p * kRadixBits;
+        const int bits = min(kRadixBits, end_bit - shift);
+        const unsigned mask = (1u << bits) - 1u;
+        hipLaunchKernelGGL((sort_hist_kernel<KeyT, KPT>), dim3(nblocks_max), dim3(kSortThreads), 0, st, kin, n_dev,
+                           shift, mask, nblocks_max, hist);
+        hipLaunchKernelGGL((sort_scan_kernel<kItems>), dim3(kRadix), dim3(kSortThreads), 0, st, n_dev, nblocks_max,
+                           hist, digit_tot);
+        hipLaunchKernelGGL((sort_scatter_kernel<KeyT, KPT>), dim3(nblocks_max), dim3(kSortThreads), 0, st, kin, vin,
+                           kout, vout, n_dev, shift, mask, nblocks_max, hist, digit_tot);
+        KeyT* tk = kin; kin = kout; kout = tk;
+        int* tv = vin; vin = vout; vout = tv;
+    }
+    const int rc = check_launch("qed_sort_pairs");
+    if (rc != QED_OK) return rc;
+    return passes & 1;
+}
+
+constexpr int kKpt64 = 8;   // 2048 pairs per workgroup: >= 1400 workgroups at M = 3e6
+
+}  // namespace qed
+
+using namespace qed;
+
+extern "C" int64_t qed_sort_workspace_bytes(int64_t capacity) {
+    if (capacity < 0) return QED_E_INVALID_ARG;
+    const long long items = SortCfg<unsigned long long, kKpt64>::kItems;
+    const long long nb = (capacity + items - 1) / items;
+    return ((long long)kRadix * nb + kRadix) * (long long)sizeof(int) + 256;
+}
+
+extern "C" int qed_sort_pairs(uint64_t* keys, int32_t* vals, uint64_t* keys_alt, int32_t* vals_alt,
+                              const int32_t* n_dev, int64_t capacity, int32_t end_bit, void* workspace,
+                              int64_t workspace_bytes, int32_t* status, void* stream) {
+    QED_REQUIRE(capacity >= 0 && capacity < (1ll << 31), "capacity out of range");
+    QED_REQUIRE(end_bit >= 1 && end_bit <= 64, "end_bit must be in [1, 64]");
+    (void)status;
+    if (capacity == 0) return 0;
+    QED_REQUIRE(keys && vals && keys_alt && vals_alt && n_dev && workspace, "null buffers");
+    return sort_pairs_impl<unsigned long long, kKpt64>((unsigned long long*)keys, vals, (unsigned long long*)keys_alt,
+                                                      vals_alt, n_dev, capacity, end_bit, workspace, workspace_bytes,
+                                                      (hipStream_t)stream);
+}

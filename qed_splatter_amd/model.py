@@ -1,0 +1,459 @@
+"""Host-side mirror of the reference's model-level interface for the render hot path.
+
+Mirrors /root/reference/qed_splatter/model.py:
+  * ``get_viewmat``                    model.py:22-38
+  * ``QEDSplatterModelConfig``         model.py:41-47 (fields depth_lambda, output_depth_during_training)
+  * ``QEDSplatterModel.get_outputs``   model.py:199-321
+  * ``QEDSplatterModel.get_loss_dict`` model.py:73-118 (depth-L1 term; parent's L1 RGB term)
+
+The reference class inherits Nerfstudio's ``SplatfactoModel`` (not installed here);
+this mirror is a plain ``nn.Module`` holding the same six parameter groups under the same names
+(``means, scales, quats, features_dc, features_rest, opacities``; model.py:227-239) so checkpoints
+interchange, and it accepts any camera object with the few attributes model.py:199-250 touches
+(``Cameras`` of Nerfstudio or ``PinholeCameras`` below).  INTEGRATION.md shows the two-line change
+that makes the real ``QEDSplatterModel`` call this package instead of gsplat.
+
+Two ways to run a training step:
+  * API-compatible: ``get_outputs`` -> ``get_loss_dict`` -> ``backward`` (eager torch post-ops with
+    autograd exactly as model.py:295-306 / 87-116; the rasterization itself is the HIP operator);
+  * fused: ``fused_step`` = rasterization + K8 fused loss/gradient kernel + backward, with the
+    exp / sigmoid / cat of model.py:241,269-271 folded into the projection kernel.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Union
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib as L
+from .rasterization import rasterization, _stream
+
+
+def get_viewmat(optimized_camera_to_world: Tensor) -> Tensor:
+    """c2w [C,3,4] (OpenGL) -> gsplat world2camera [C,4,4]  (model.py:22-38)."""
+    R = optimized_camera_to_world[:, :3, :3]
+    T = optimized_camera_to_world[:, :3, 3:4]
+    flip = torch.tensor([[[1.0, -1.0, -1.0]]], device=R.device, dtype=R.dtype)
+    R = R * flip
+    R_inv = R.transpose(1, 2)
+    T_inv = -torch.bmm(R_inv, T)
+    viewmat = torch.zeros(R.shape[0], 4, 4, device=R.device, dtype=R.dtype)
+    viewmat[:, 3, 3] = 1.0
+    viewmat[:, :3, :3] = R_inv
+    viewmat[:, :3, 3:4] = T_inv
+    return viewmat
+
+
+@dataclass
+class QEDSplatterModelConfig:
+    """Fields the hot path reads.  The first two are the reference's own (model.py:44,46); the rest
+    are the inherited SplatfactoModelConfig fields that model.py:199-321 touches."""
+    depth_lambda: float = 0.2
+    output_depth_during_training: bool = True
+    sh_degree: int = 3
+    sh_degree_interval: int = 1000
+    rasterize_mode: str = "classic"
+    use_bilateral_grid: bool = False
+    background_color: str = "black"          # "random" | "black" | "white"
+    ssim_lambda: float = 0.2                 # parent's main loss: (1-l) L1 + l (1-SSIM); SSIM is 8f "next"
+    num_downscales: int = 0
+    resolution_schedule: int = 3000
+
+
+class PinholeCameras:
+    """The subset of nerfstudio ``Cameras`` that model.py:199-250 touches."""
+
+    def __init__(self, camera_to_worlds: Tensor, fx: float, fy: float, cx: float, cy: float, width: int, height: int,
+                 metadata: Optional[dict] = None):
+        self.camera_to_worlds = camera_to_worlds                       # [C,3,4]
+        C = camera_to_worlds.shape[0]
+        dev = camera_to_worlds.device
+        self.fx = torch.full((C, 1), float(fx), device=dev)
+        self.fy = torch.full((C, 1), float(fy), device=dev)
+        self.cx = torch.full((C, 1), float(cx), device=dev)
+        self.cy = torch.full((C, 1), float(cy), device=dev)
+        self.width = torch.full((C, 1), int(width), dtype=torch.int64)
+        self.height = torch.full((C, 1), int(height), dtype=torch.int64)
+        self.metadata = metadata
+
+    @property
+    def shape(self):
+        return self.camera_to_worlds.shape[:1]
+
+    def get_intrinsics_matrices(self) -> Tensor:
+        K = torch.zeros(self.shape[0], 3, 3, device=self.fx.device)
+        K[:, 0, 0] = self.fx[:, 0]
+        K[:, 1, 1] = self.fy[:, 0]
+        K[:, 0, 2] = self.cx[:, 0]
+        K[:, 1, 2] = self.cy[:, 0]
+        K[:, 2, 2] = 1.0
+        return K
+
+    def rescale_output_resolution(self, s: float) -> None:
+        self.fx = self.fx * s
+        self.fy = self.fy * s
+        self.cx = self.cx * s
+        self.cy = self.cy * s
+        self.width = (self.width * s).to(torch.int64)
+        self.height = (self.height * s).to(torch.int64)
+
+
+GROUP_ORDER = ("means", "scales", "quats", "opacities", "features_dc", "features_rest")
+
+
+def _is_camera(obj) -> bool:
+    return all(hasattr(obj, a) for a in ("camera_to_worlds", "get_intrinsics_matrices", "width", "height"))
+
+
+class _FusedImageLoss(torch.autograd.Function):
+    """K8: composite + clamp + depth fix-up + L1 RGB + masked depth-L1, value and gradient in two
+    streaming passes (model.py:295-297, 304-306, 87-116)."""
+
+    @staticmethod
+    def forward(ctx, render, alpha, background, gt_rgb, gt_depth, mask, rgb_weight, depth_lambda):
+        lib = L.load()
+        C, H, W, CH = render.shape
+        assert C == 1, "one camera per training step (model.py:211)"
+        dev = render.device
+        n_pix = H * W
+        sums = torch.empty(4, dtype=torch.float32, device=dev)
+        losses = torch.empty(2, dtype=torch.float32, device=dev)
+        v_render = torch.empty_like(render)
+        v_alpha = torch.empty_like(alpha)
+        st = _stream()
+        args = (n_pix, CH, L.ptr(render), L.ptr(alpha), L.ptr(background), L.ptr(gt_rgb), L.ptr(gt_depth), L.ptr(mask))
+        L.check(lib.qed_loss_reduce(*args, L.ptr(sums), st), "qed_loss_reduce")
+        L.check(lib.qed_loss_grad(*args, L.ptr(sums), rgb_weight, depth_lambda, L.ptr(v_render), L.ptr(v_alpha),
+                                  L.ptr(losses), st), "qed_loss_grad")
+        ctx.save_for_backward(v_render, v_alpha)
+        return losses
+
+    @staticmethod
+    def backward(ctx, v_losses):
+        v_render, v_alpha = ctx.saved_tensors
+        # both loss terms enter the total with weight 1 (loss = sum of loss_dict values); a caller
+        # that scales them differently goes through the API-compatible path instead
+        return v_render, v_alpha, None, None, None, None, None, None
+
+
+class QEDSplatterModel(nn.Module):
+    """Mirror of QEDSplatterModel (model.py:50-321) for the render hot path."""
+
+    def __init__(self, config: Optional[QEDSplatterModelConfig] = None, *, means: Tensor, scales: Tensor,
+                 quats: Tensor, opacities: Tensor, features_dc: Tensor, features_rest: Tensor):
+        super().__init__()
+        self.config = config or QEDSplatterModelConfig()
+        N = means.shape[0]
+        # One flat buffer holds all six groups (59 N floats for SH degree 3); the six Parameters are
+        # leaf views into it.  _ProjectSH.backward lays the six gradients out in the same order in
+        # one allocation, so the data-parallel all-reduce and the fused Adam step each
+        # touch a single contiguous range and nothing is ever concatenated.
+        srcs = dict(means=means, scales=scales, quats=quats, opacities=opacities.reshape(N, 1),
+                    features_dc=features_dc.reshape(N, 3), features_rest=features_rest)
+        self.group_names = list(GROUP_ORDER)
+        total = sum(srcs[n].numel() for n in self.group_names)
+        flat = torch.empty(total, dtype=torch.float32, device=means.device)
+        self.group_begin: List[int] = [0]
+        params = {}
+        off = 0
+        for name in self.group_names:
+            src = srcs[name]
+            n = src.numel()
+            flat[off:off + n] = src.reshape(-1).to(torch.float32)
+            params[name] = nn.Parameter(flat[off:off + n].view(src.shape))
+            off += n
+            self.group_begin.append(off)
+        self._flat = flat
+        self.gauss_params = nn.ParameterDict(params)          # same container name as SplatfactoModel
+        self.step = 0
+        self.crop_box = None
+        self.camera_optimizer = None
+
+    # ---- parameter groups (same names as the reference reads at model.py:227-239) ----
+    means = property(lambda self: self.gauss_params["means"])
+    scales = property(lambda self: self.gauss_params["scales"])
+    quats = property(lambda self: self.gauss_params["quats"])
+    opacities = property(lambda self: self.gauss_params["opacities"])
+    features_dc = property(lambda self: self.gauss_params["features_dc"])
+    features_rest = property(lambda self: self.gauss_params["features_rest"])
+
+    @property
+    def device(self):
+        return self._flat.device
+
+    @property
+    def flat_params(self) -> Tensor:
+        """All six groups as one contiguous [59 N] tensor (aliases the Parameters)."""
+        return self._flat
+
+    def flat_grad(self) -> Optional[Tensor]:
+        """The six ``.grad`` tensors as one contiguous tensor.  Zero-copy when they alias one
+        allocation in group order (what _ProjectSH.backward produces); otherwise concatenated."""
+        grads = [self.gauss_params[n].grad for n in self.group_names]
+        if any(g is None for g in grads):
+            return None
+        g0 = grads[0]
+        base, ok = g0.storage_offset(), True
+        for g, beg in zip(grads, self.group_begin):
+            ok = ok and g.is_contiguous() and g.untyped_storage().data_ptr() == g0.untyped_storage().data_ptr() \
+                and g.storage_offset() == base + beg
+        total = self.group_begin[-1]
+        if ok and g0.untyped_storage().nbytes() >= 4 * (base + total):
+            return torch.empty(0, dtype=torch.float32, device=g0.device).set_(g0.untyped_storage(), base, (total,))
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        off = 0
+        for n, g in zip(self.group_names, grads):           # re-alias so later steps stay zero-copy
+            self.gauss_params[n].grad = flat[off:off + g.numel()].view(g.shape)
+            off += g.numel()
+        return flat
+
+    @property
+    def num_points(self) -> int:
+        return self.gauss_params["means"].shape[0]
+
+    def get_param_groups(self) -> Dict[str, List[Tensor]]:
+        return {n: [self.gauss_params[n]] for n in self.group_names}
+
+    # ---- inherited helpers model.py calls, minimal restatements ----
+    def _get_downscale_factor(self) -> int:
+        if self.training:
+            return 2 ** max(self.config.num_downscales - self.step // self.config.resolution_schedule, 0)
+        return 1
+
+    def _get_background_color(self) -> Tensor:
+        dev = self.device
+        if self.config.background_color == "random":
+            return torch.rand(3, device=dev) if self.training else torch.zeros(3, device=dev)
+        if self.config.background_color == "white":
+            return torch.ones(3, device=dev)
+        return torch.zeros(3, device=dev)
+
+    def get_gt_img(self, image: Tensor) -> Tensor:
+        if image.dtype == torch.uint8:
+            image = image.float() / 255.0
+        return image.to(self.device)
+
+    def get_empty_outputs(self, width: int, height: int, background: Tensor) -> Dict[str, Tensor]:
+        rgb = background.repeat(height, width, 1)
+        depth = background.new_ones(*rgb.shape[:2], 1) * 10
+        accumulation = background.new_zeros(*rgb.shape[:2], 1)
+        return {"rgb": rgb, "depth": depth, "accumulation": accumulation, "background": background}
+
+    # ---- a2-a10: get_outputs (model.py:199-321) ----
+    def get_outputs(self, camera) -> Dict[str, Union[Tensor, List]]:
+        if not _is_camera(camera):
+            print("Called get_outputs with not a camera")                     # model.py:206-208
+            return {}
+        if self.training:
+            assert camera.shape[0] == 1, "Only one camera at a time"          # model.py:211
+            if self.camera_optimizer is not None:
+                optimized_camera_to_world = self.camera_optimizer.apply_to_camera(camera)
+            else:
+                optimized_camera_to_world = camera.camera_to_worlds
+        else:
+            optimized_camera_to_world = camera.camera_to_worlds
+
+        if self.crop_box is not None and not self.training:                   # model.py:217-224
+            crop_ids = self.crop_box.within(self.means).squeeze()
+            if crop_ids.sum() == 0:
+                return self.get_empty_outputs(int(camera.width.item()), int(camera.height.item()),
+                                              self._get_background_color())
+        else:
+            crop_ids = None
+
+        if crop_ids is not None:                                              # model.py:226-239
+            opacities_crop = self.opacities[crop_ids]
+            means_crop = self.means[crop_ids]
+            features_dc_crop = self.features_dc[crop_ids]
+            features_rest_crop = self.features_rest[crop_ids]
+            scales_crop = self.scales[crop_ids]
+            quats_crop = self.quats[crop_ids]
+        else:
+            opacities_crop, means_crop = self.opacities, self.means
+            features_dc_crop, features_rest_crop = self.features_dc, self.features_rest
+            scales_crop, quats_crop = self.scales, self.quats
+
+        BLOCK_WIDTH = 16                                                      # model.py:243
+        camera_scale_fac = self._get_downscale_factor()
+        camera.rescale_output_resolution(1 / camera_scale_fac)
+        viewmat = get_viewmat(optimized_camera_to_world)
+        K = camera.get_intrinsics_matrices().to(self.device)
+        W, H = int(camera.width.item()), int(camera.height.item())
+        self.last_size = (H, W)
+        camera.rescale_output_resolution(camera_scale_fac)
+
+        if self.config.rasterize_mode not in ["antialiased", "classic"]:      # model.py:253-254
+            raise ValueError("Unknown rasterize_mode: %s", self.config.rasterize_mode)
+        if self.config.output_depth_during_training or not self.training:    # model.py:256-259
+            render_mode = "RGB+D"
+        else:
+            render_mode = "RGB"
+
+        flags = L.F_LOG_SCALES | L.F_LOGIT_OPAC                               # exp / sigmoid fused (model.py:270-271)
+        if self.config.sh_degree > 0:                                         # model.py:261-265
+            sh_degree_to_use = min(self.step // self.config.sh_degree_interval, self.config.sh_degree)
+            colors, sh_rest = features_dc_crop, features_rest_crop            # no torch.cat (model.py:241)
+        else:
+            sh_degree_to_use = None
+            colors, sh_rest = features_dc_crop, None
+            flags |= L.F_SIGMOID_COLORS                                       # torch.sigmoid(colors) fused
+
+        render, alpha, self.info = rasterization(
+            means=means_crop,
+            quats=quats_crop,                       # normalised inside the projection kernel (model.py:269)
+            scales=scales_crop,
+            opacities=opacities_crop,
+            colors=colors,
+            viewmats=viewmat.to(torch.float32),
+            Ks=K.to(torch.float32),
+            width=W,
+            height=H,
+            tile_size=BLOCK_WIDTH,
+            packed=False,
+            near_plane=0.01,
+            far_plane=1e10,
+            render_mode=render_mode,
+            sh_degree=sh_degree_to_use,
+            sparse_grad=False,
+            absgrad=True,
+            rasterize_mode=self.config.rasterize_mode,
+            _flags=flags,
+            _sh_rest=sh_rest,
+        )
+        if self.training and self.info["means2d"].requires_grad:              # model.py:289-290
+            self.info["means2d"].retain_grad()
+        self.xys = self.info["means2d"]                                       # [1,N,2]
+        self.radii = self.info["radii"][0]                                    # [N]
+        alpha = alpha[:, ...]
+
+        background = self._get_background_color()
+        rgb = render[:, ..., :3] + (1 - alpha) * background                   # model.py:296
+        rgb = torch.clamp(rgb, 0.0, 1.0)
+
+        if self.config.use_bilateral_grid and self.training:                  # model.py:300-302 (pass-through)
+            if getattr(camera, "metadata", None) is not None and "cam_idx" in camera.metadata:
+                rgb = self._apply_bilateral_grid(rgb, camera.metadata["cam_idx"], H, W)
+
+        if render_mode == "RGB+D":                                            # model.py:304-308
+            depth_im = render[:, ..., 3:4]
+            depth_im = torch.where(alpha > 0, depth_im, depth_im.detach().max()).squeeze(0)
+        else:
+            depth_im = None
+        # model.py:310-311 `del render; torch.cuda.empty_cache()` is a per-call device sync +
+        # allocator flush with no effect on results; deliberately not reproduced.
+        self._last_render, self._last_alpha = render, alpha
+
+        if background.shape[0] == 3 and not self.training:                    # model.py:313-314
+            background = background.expand(H, W, 3)
+        return {
+            "rgb": rgb.squeeze(0),
+            "depth": depth_im,
+            "accumulation": alpha.squeeze(0),
+            "background": background,
+        }
+
+    # ---- a11: get_loss_dict (model.py:73-118) ----
+    def _parent_loss_dict(self, outputs, batch) -> Dict[str, Tensor]:
+        """L1 part of SplatfactoModel's main loss (upstream of model.py:83-85).  The (1-SSIM) term
+        is SURVEY 8(f) rank 1 and not built yet; its weight ssim_lambda is applied to L1 only."""
+        gt_img = self.get_gt_img(batch["image"])
+        Ll1 = torch.abs(gt_img - outputs["rgb"]).mean()
+        return {"main_loss": (1 - self.config.ssim_lambda) * Ll1}
+
+    def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, Tensor]:
+        loss_dict = self._parent_loss_dict(outputs, batch)                     # model.py:83-85
+        depth_out = outputs["depth"]
+        depth_batch = self.get_gt_img(batch["depth_image"])
+        pred_img = outputs["rgb"]
+        gt_img = self.get_gt_img(batch["image"])
+        if "mask" in batch:                                                    # model.py:93-97
+            mask = self.get_gt_img(batch["mask"])
+            assert mask.shape[:2] == gt_img.shape[:2] == pred_img.shape[:2]
+            depth_out = depth_out * mask
+            depth_batch = depth_batch * mask
+        valid_mask = torch.isfinite(depth_out) & torch.isfinite(depth_batch) & (depth_batch > 0.0)
+        valid_depth_out = depth_out[valid_mask]
+        valid_depth_batch = depth_batch[valid_mask]
+        if valid_depth_out.numel() > 0:                                        # model.py:111-114
+            loss = torch.abs(valid_depth_out - valid_depth_batch).mean()
+        else:
+            loss = torch.tensor(0.0, device=depth_out.device)
+        loss_dict["depth_loss"] = self.config.depth_lambda * loss             # model.py:116
+        return loss_dict
+
+    # ---- fused training step: model.py:199-321 + 73-118 in as few passes as possible ----
+    def fused_loss(self, camera, batch, background: Optional[Tensor] = None, sync: bool = True) -> Dict[str, Tensor]:
+        """Forward + K8 fused loss.  Returns {"main_loss", "depth_loss"} whose sum backpropagates
+        into the parameter ``.grad``s; numerically the same quantities as get_outputs + get_loss_dict."""
+        assert camera.shape[0] == 1, "Only one camera at a time"
+        cfg = self.config
+        viewmat = get_viewmat(camera.camera_to_worlds).to(torch.float32)
+        K = camera.get_intrinsics_matrices().to(self.device, torch.float32)
+        W, H = int(camera.width[0]), int(camera.height[0])
+        self.last_size = (H, W)
+        flags = L.F_LOG_SCALES | L.F_LOGIT_OPAC
+        if cfg.sh_degree > 0:
+            deg = min(self.step // cfg.sh_degree_interval, cfg.sh_degree)
+            colors, sh_rest = self.features_dc, self.features_rest
+        else:
+            deg, colors, sh_rest = None, self.features_dc, None
+            flags |= L.F_SIGMOID_COLORS
+        render, alpha, self.info = rasterization(
+            means=self.means, quats=self.quats, scales=self.scales, opacities=self.opacities, colors=colors,
+            viewmats=viewmat, Ks=K, width=W, height=H, tile_size=16, packed=False, near_plane=0.01, far_plane=1e10,
+            render_mode="RGB+D", sh_degree=deg, sparse_grad=False, absgrad=True,
+            rasterize_mode=cfg.rasterize_mode, _flags=flags, _sh_rest=sh_rest, _sync=sync)
+        self.xys = self.info["means2d"]
+        self.radii = self.info["radii"][0]
+        bg = background if background is not None else self._get_background_color()
+        gt_rgb = batch["image"]
+        gt_depth = batch["depth_image"]
+        mask = batch.get("mask")
+        assert gt_rgb.dtype == torch.float32 and gt_rgb.is_contiguous() and gt_depth.is_contiguous()
+        losses = _FusedImageLoss.apply(render, alpha, bg.contiguous(), gt_rgb, gt_depth,
+                                       mask.contiguous() if mask is not None else None,
+                                       1.0 - cfg.ssim_lambda, cfg.depth_lambda)
+        return {"main_loss": losses[0], "depth_loss": losses[1]}
+
+
+class FlatAdam:
+    """Fused multi-tensor Adam over the model's flat parameter buffer, one learning rate per group
+    (the six Gaussian groups of config.py:44-68, eps=1e-15).  SURVEY 8(f) rank 2."""
+
+    DEFAULT_LRS = {"means": 1.6e-4, "scales": 0.005, "quats": 0.001, "opacities": 0.05,
+                   "features_dc": 0.0025, "features_rest": 0.0025 / 20}
+
+    def __init__(self, model: QEDSplatterModel, lrs: Optional[Dict[str, float]] = None, betas=(0.9, 0.999),
+                 eps: float = 1e-15):
+        import ctypes as C
+        self.model = model
+        lrs = {**self.DEFAULT_LRS, **(lrs or {})}
+        self.lr = [float(lrs[n]) for n in model.group_names]
+        begins = list(model.group_begin)
+        self._begin = (C.c_int64 * len(begins))(*begins)
+        self._lr = (C.c_float * len(self.lr))(*self.lr)
+        self.betas, self.eps = betas, eps
+        self.exp_avg = torch.zeros_like(model.flat_params)
+        self.exp_avg_sq = torch.zeros_like(model.flat_params)
+        self.t = 0
+
+    def set_lr(self, name: str, lr: float) -> None:
+        i = self.model.group_names.index(name)
+        self.lr[i] = float(lr)
+        self._lr[i] = float(lr)
+
+    @torch.no_grad()
+    def step(self) -> None:
+        import ctypes as C
+        p = self.model.flat_params
+        g = self.model.flat_grad()
+        if g is None:
+            return
+        self.t += 1
+        lib = L.load()
+        L.check(lib.qed_adam_step(L.ptr(p), L.ptr(g), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
+                                  len(self.lr), C.cast(self._begin, C.c_void_p), C.cast(self._lr, C.c_void_p),
+                                  self.betas[0], self.betas[1], self.eps, self.t, _stream()), "qed_adam_step")

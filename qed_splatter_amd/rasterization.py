@@ -1,0 +1,414 @@
+"""Drop-in for ``gsplat.rendering.rasterization`` as the reference calls it
+(/root/reference/qed_splatter/model.py:267-288): same keyword names, same return triple
+``(render[C,H,W,3|4], alpha[C,H,W,1], info)`` and the ``info`` keys the reference and Nerfstudio's
+densification strategy read (model.py:289-292).
+
+Host code is Python + PyTorch-ROCm (device memory, streams, autograd plumbing); every arithmetic
+step runs in hand-written gfx950 HIP kernels behind the C ABI of ``include/qed_splat.h``.
+
+Autograd graph (mirrors gsplat's, so ``info["means2d"].retain_grad()`` at model.py:289-290 works):
+
+    means, quats, scales, opacities, colors, viewmats
+        |  _ProjectSH   (qed_project_fwd / qed_project_bwd: projection + SH colour, fused)
+    means2d, depths, conics, opac, rgb      <- info["means2d"] is this non-leaf tensor
+        |  _Composite   (isect scan/emit -> radix sort -> tile offsets -> qed_composite_fwd/bwd)
+    render, alpha
+
+``_Composite.backward`` returns strided views of ONE packed 64-byte-per-Gaussian gradient buffer;
+``_ProjectSH.backward`` recognises them and hands the packed buffer to the fused kernel, so no
+gradient is ever repacked on the hot path.
+"""
+from __future__ import annotations
+
+import math
+import weakref
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib as L
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32c(t: Tensor, name: str) -> Tensor:
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    if not t.is_cuda:
+        raise L.QedSplatError(f"{name} must live on the GPU: this operator has no CPU path")
+    return t.contiguous()
+
+
+def tile_bits_for(n_tiles: int) -> int:
+    return int(math.floor(math.log2(n_tiles))) + 1
+
+
+class _Workspace:
+    """Per-device state that persists across calls: the status words and the intersection capacity.
+
+    Key/value buffers are taken from PyTorch's caching allocator per call (sized by a capacity
+    that only grows) and stay alive until that call's backward has run.  The kernels read the
+    actual count M from device memory, so launches never need M on the host.  If a frame overflows
+    the capacity (status word set by qed_isect_scan) a synchronous call is redone with a larger
+    buffer; an asynchronous call reports it at the next call.
+    """
+
+    def __init__(self, device):
+        self.device = device
+        self.capacity = 0
+        self.status = torch.zeros(L.STATUS_WORDS, dtype=torch.int32, device=device)
+        self.pending = None          # (pinned host copy of [M, overflow], event) of an async call
+
+    def poll_pending(self):
+        if self.pending is None:
+            return
+        host, ev = self.pending
+        ev.synchronize()
+        self.pending = None
+        M, overflow = int(host[0]), int(host[1])
+        if overflow:
+            self.status.zero_()
+            self.capacity = int(overflow * 1.5) + 4096
+            raise L.QedSplatError(
+                f"the previous asynchronous rasterization needed {overflow} tile intersections, more than the "
+                f"buffer capacity; that frame rendered empty.  Capacity raised to {self.capacity}.")
+        self.capacity = max(self.capacity, int(M * 1.25) + 4096)
+
+
+_WORKSPACES: Dict[int, _Workspace] = {}
+
+
+def _workspace(device) -> _Workspace:
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    ws = _WORKSPACES.get(idx)
+    if ws is None:
+        ws = _WORKSPACES[idx] = _Workspace(torch.device("cuda", idx))
+    return ws
+
+
+# ==================================================================================================
+# projection + SH
+# ==================================================================================================
+class _ProjectSH(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, quats, scales, opacities, sh0, shN, viewmats, Ks, width, height, tile_w, tile_h,
+                sh_degree, flags, eps2d, near_plane, far_plane, radius_clip):
+        lib = L.load()
+        N, C = means.shape[0], viewmats.shape[0]
+        dev = means.device
+        means, quats, scales = _f32c(means, "means"), _f32c(quats, "quats"), _f32c(scales, "scales")
+        opac_shape = opacities.shape
+        opacities = _f32c(opacities, "opacities").reshape(-1)
+        sh0 = _f32c(sh0, "colors")
+        shN = _f32c(shN, "colors") if shN is not None else None
+        viewmats, Ks = _f32c(viewmats, "viewmats"), _f32c(Ks, "Ks")
+        sh0_stride = sh0.stride(0) if sh0.dim() > 1 else 3
+        # a [N,K,3] colours tensor is passed as (colors, 3K, colors + 3, 3K) -- no copy
+        if sh0.dim() == 3:
+            K = sh0.shape[1]
+            sh0_flat = sh0
+            shN_ptr = sh0.data_ptr() + 12 if K > 1 else 0
+            shN_stride = 3 * K
+            sh0_stride = 3 * K
+        else:
+            sh0_flat = sh0
+            shN_ptr = L.ptr(shN)
+            shN_stride = shN.stride(0) if shN is not None else 0
+
+        radii = torch.empty(C, N, dtype=torch.int32, device=dev)
+        means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
+        depths = torch.empty(C, N, dtype=torch.float32, device=dev)
+        conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
+        opac = torch.empty(C, N, dtype=torch.float32, device=dev)
+        rgb = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
+        splats = torch.empty(C * N, L.SPLAT_FLOATS, dtype=torch.float32, device=dev)
+        tiles_per_gauss = torch.empty(C, N, dtype=torch.int32, device=dev)
+        n_blocks = (C * N + 255) // 256
+        block_sums = torch.empty(max(n_blocks, 1), dtype=torch.int32, device=dev)
+        L.check(lib.qed_project_fwd(
+            N, C, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opacities), L.ptr(sh0_flat), sh0_stride,
+            shN_ptr, shN_stride, sh_degree, L.ptr(viewmats), L.ptr(Ks), width, height, tile_w, tile_h, eps2d,
+            near_plane, far_plane, radius_clip, flags, L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics),
+            L.ptr(opac), L.ptr(rgb), L.ptr(splats), L.ptr(tiles_per_gauss), L.ptr(block_sums), _stream()),
+            "qed_project_fwd")
+        ctx.save_for_backward(means, quats, scales, opacities, sh0, shN, viewmats, Ks, radii)
+        ctx.meta = (N, C, width, height, sh_degree, flags, eps2d, sh0_stride, shN_stride)
+        ctx.opac_shape = opac_shape
+        ctx.mark_non_differentiable(radii, splats, tiles_per_gauss, block_sums)
+        return means2d, depths, conics, opac, rgb, radii, splats, tiles_per_gauss, block_sums
+
+    @staticmethod
+    def backward(ctx, v_means2d, v_depths, v_conics, v_opac, v_rgb, *_unused):
+        lib = L.load()
+        means, quats, scales, opacities, sh0, shN, viewmats, Ks, radii = ctx.saved_tensors
+        N, C, width, height, sh_degree, flags, eps2d, sh0_stride, shN_stride = ctx.meta
+        dev = means.device
+        vsplat = _packed_vsplat(C, N, v_means2d, v_depths, v_conics, v_opac, v_rgb, dev)
+
+        # All parameter gradients live in ONE allocation, in the order
+        # (means, scales, quats, opacities, sh0, shN) = qed_splatter_amd.model.GROUP_ORDER, so a
+        # caller can all-reduce / Adam-step them as a single contiguous range.
+        k_active = (sh_degree + 1) ** 2 if sh_degree >= 0 else 1
+        n_sh0 = sh0.numel()
+        n_shN = shN.numel() if shN is not None else 0
+        flat = torch.empty(11 * N + n_sh0 + n_shN, dtype=torch.float32, device=dev)
+        v_means = flat[0:3 * N].view(N, 3)
+        v_scales = flat[3 * N:6 * N].view(N, 3)
+        v_quats = flat[6 * N:10 * N].view(N, 4)
+        v_opacities = flat[10 * N:11 * N]
+        v_sh0 = flat[11 * N:11 * N + n_sh0].view(sh0.shape)
+        v_shN = flat[11 * N + n_sh0:].view(shN.shape) if shN is not None else None
+        if sh0.dim() == 3:                      # colours [N,K,3] in one tensor
+            if k_active < sh0.shape[1]:
+                v_sh0.zero_()                   # coefficients above the active degree get zero gradient
+            v_sh0_ptr, v_sh0_stride = v_sh0.data_ptr(), sh0_stride
+            v_shN_ptr, v_shN_stride = v_sh0.data_ptr() + 12, shN_stride
+            shN_ptr = sh0.data_ptr() + 12
+        else:
+            if shN is not None and k_active - 1 < shN.shape[1]:
+                v_shN.zero_()
+            v_sh0_ptr, v_sh0_stride = v_sh0.data_ptr(), sh0_stride
+            v_shN_ptr, v_shN_stride = L.ptr(v_shN), shN_stride
+            shN_ptr = L.ptr(shN)
+        del flat                                # only the views stay referenced -> autograd can adopt them
+        v_viewmats = None
+        if ctx.needs_input_grad[6]:
+            v_viewmats = torch.zeros_like(viewmats)
+        L.check(lib.qed_project_bwd(
+            N, C, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opacities), L.ptr(sh0), sh0_stride, shN_ptr,
+            shN_stride, sh_degree, L.ptr(viewmats), L.ptr(Ks), width, height, eps2d, flags, L.ptr(radii),
+            L.ptr(vsplat), L.ptr(v_means), L.ptr(v_quats), L.ptr(v_scales), L.ptr(v_opacities), v_sh0_ptr,
+            v_sh0_stride, v_shN_ptr, v_shN_stride, L.ptr(v_viewmats), _stream()), "qed_project_bwd")
+        v_opacities = v_opacities.view(ctx.opac_shape)
+        return (v_means, v_quats, v_scales, v_opacities, v_sh0, v_shN, v_viewmats, None) + (None,) * 10
+
+
+_VSPLAT_REGISTRY: "weakref.WeakValueDictionary[int, Tensor]" = weakref.WeakValueDictionary()
+
+
+def _packed_vsplat(C, N, v_means2d, v_depths, v_conics, v_opac, v_rgb, dev) -> Tensor:
+    """Return the packed [C*N,16] gradient buffer.
+
+    Fast path: the incoming gradients are exactly the strided views _Composite.backward produced
+    of one packed buffer (same storage, expected offsets and strides) -> use that buffer as is.
+    Otherwise (user-supplied or autograd-summed gradients) pack them."""
+    R = L.VSPLAT_FLOATS
+    base = None
+    if v_means2d is not None:
+        base = _VSPLAT_REGISTRY.get(v_means2d.untyped_storage().data_ptr())
+
+    def is_view(g, col, width):
+        if g is None or g.untyped_storage().data_ptr() != base.untyped_storage().data_ptr():
+            return False
+        want = (N * R, R, 1) if width > 1 else (N * R, R)
+        shape = (C, N, width) if width > 1 else (C, N)
+        return g.storage_offset() == col and tuple(g.shape) == shape and tuple(g.stride()) == want
+
+    if base is not None and base.numel() == C * N * R and is_view(v_means2d, 0, 2) and is_view(v_conics, 4, 3) \
+            and is_view(v_opac, 7, 1) and is_view(v_rgb, 8, 3) and (v_depths is None or is_view(v_depths, 11, 1)):
+        return base
+    out = torch.zeros(C * N, R, dtype=torch.float32, device=dev)
+    if v_means2d is not None:
+        out[:, 0:2] = v_means2d.reshape(C * N, 2)
+    if v_conics is not None:
+        out[:, 4:7] = v_conics.reshape(C * N, 3)
+    if v_opac is not None:
+        out[:, 7] = v_opac.reshape(C * N)
+    if v_rgb is not None:
+        out[:, 8:11] = v_rgb.reshape(C * N, 3)
+    if v_depths is not None:
+        out[:, 11] = v_depths.reshape(C * N)
+    return out
+
+
+# ==================================================================================================
+# tile binning + sort + compositing
+# ==================================================================================================
+def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, tile_w, tile_h, sync=True):
+    """isect scan -> emit -> radix sort -> tile offsets.
+
+    Returns (isect_ids, flatten_ids, offsets, M).  With ``sync=False`` (after a first calibrating
+    call) nothing is read back: M is None and the id tensors keep their full capacity length.
+    """
+    lib = L.load()
+    dev = means2d.device
+    ws = _workspace(dev)
+    n_tiles = tile_w * tile_h
+    tb = tile_bits_for(n_tiles)
+    cam_bits = int(math.ceil(math.log2(C))) if C > 1 else 0
+    end_bit = 32 + tb + cam_bits
+    n_blocks = (C * N + 255) // 256
+    block_offsets = torch.empty(max(n_blocks, 1), dtype=torch.int32, device=dev)
+    n_isect = torch.zeros(1, dtype=torch.int32, device=dev)
+    offsets = torch.empty(C * n_tiles + 1, dtype=torch.int32, device=dev)
+    ws.poll_pending()
+    if ws.capacity == 0:
+        sync = True                                   # first call calibrates the capacity
+        ws.capacity = max(1 << 16, 8 * C * N)
+    for _attempt in range(2):
+        cap = ws.capacity
+        keys_a = torch.empty(cap, dtype=torch.int64, device=dev)
+        keys_b = torch.empty(cap, dtype=torch.int64, device=dev)
+        vals_a = torch.empty(cap, dtype=torch.int32, device=dev)
+        vals_b = torch.empty(cap, dtype=torch.int32, device=dev)
+        sort_ws = torch.empty(int(lib.qed_sort_workspace_bytes(cap)), dtype=torch.uint8, device=dev)
+        st = _stream()
+        L.check(lib.qed_isect_scan(L.ptr(block_sums), n_blocks, L.ptr(block_offsets), L.ptr(n_isect), cap,
+                                   L.ptr(ws.status), st), "qed_isect_scan")
+        L.check(lib.qed_isect_emit(N, C, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(tiles_per_gauss),
+                                   L.ptr(block_offsets), tile_w, tile_h, tb, L.ptr(n_isect), cap, L.ptr(keys_a),
+                                   L.ptr(vals_a), st), "qed_isect_emit")
+        which = L.check(lib.qed_sort_pairs(L.ptr(keys_a), L.ptr(vals_a), L.ptr(keys_b), L.ptr(vals_b),
+                                           L.ptr(n_isect), cap, end_bit, L.ptr(sort_ws), sort_ws.numel(),
+                                           L.ptr(ws.status), st), "qed_sort_pairs")
+        keys, vals = (keys_b, vals_b) if which == 1 else (keys_a, vals_a)
+        L.check(lib.qed_tile_offsets(L.ptr(keys), L.ptr(n_isect), cap, C, n_tiles, tb, L.ptr(offsets), st),
+                "qed_tile_offsets")
+        if not sync:
+            host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            host[0:1].copy_(n_isect, non_blocking=True)
+            host[1:2].copy_(ws.status[:1], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            ws.pending = (host, ev)
+            return keys, vals, offsets, None
+        # one host read: M and the overflow word
+        host = torch.stack([n_isect[0], ws.status[0]]).tolist()
+        M, overflow = int(host[0]), int(host[1])
+        if overflow == 0:
+            ws.capacity = max(ws.capacity, int(M * 1.25) + 4096)
+            return keys[:M], vals[:M], offsets, M
+        ws.status.zero_()
+        ws.capacity = int(overflow * 1.25) + 4096
+    raise L.QedSplatError("intersection buffer overflow persisted after regrowth")
+
+
+class _Composite(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means2d, conics, rgb, opac, depths, splats, flatten_ids, offsets, backgrounds, width, height,
+                tile_w, tile_h, channels, absgrad):
+        lib = L.load()
+        C, N = opac.shape
+        dev = opac.device
+        render = torch.empty(C, height, width, channels, dtype=torch.float32, device=dev)
+        alpha = torch.empty(C, height, width, 1, dtype=torch.float32, device=dev)
+        last_ids = torch.empty(C, height, width, dtype=torch.int32, device=dev)
+        bg = _f32c(backgrounds, "backgrounds") if backgrounds is not None else None
+        L.check(lib.qed_composite_fwd(C, N, L.ptr(splats), L.ptr(flatten_ids), L.ptr(offsets), width, height, tile_w,
+                                      tile_h, channels, L.ptr(bg), L.ptr(render), L.ptr(alpha), L.ptr(last_ids),
+                                      _stream()), "qed_composite_fwd")
+        ctx.save_for_backward(splats, flatten_ids, offsets, alpha, last_ids, bg)
+        ctx.meta = (C, N, width, height, tile_w, tile_h, channels, absgrad)
+        ctx.means2d_ref = means2d
+        ctx.mark_non_differentiable(last_ids)
+        return render, alpha, last_ids
+
+    @staticmethod
+    def backward(ctx, v_render, v_alpha, _v_last):
+        lib = L.load()
+        splats, flatten_ids, offsets, alpha, last_ids, bg = ctx.saved_tensors
+        C, N, width, height, tile_w, tile_h, channels, absgrad = ctx.meta
+        dev = splats.device
+        v_render = _f32c(v_render, "v_render") if v_render is not None else torch.zeros(
+            C, height, width, channels, dtype=torch.float32, device=dev)
+        v_alpha = _f32c(v_alpha, "v_alpha") if v_alpha is not None else torch.zeros(
+            C, height, width, 1, dtype=torch.float32, device=dev)
+        R = L.VSPLAT_FLOATS
+        vsplat = torch.zeros(C * N, R, dtype=torch.float32, device=dev)
+        L.check(lib.qed_composite_bwd(C, N, L.ptr(splats), L.ptr(flatten_ids), L.ptr(offsets), width, height, tile_w,
+                                      tile_h, channels, L.ptr(bg), L.ptr(alpha), L.ptr(last_ids), L.ptr(v_render),
+                                      L.ptr(v_alpha), L.ptr(vsplat), _stream()), "qed_composite_bwd")
+        v3 = vsplat.view(C, N, R)
+        v_means2d = v3[..., 0:2]
+        v_conics = v3[..., 4:7]
+        v_opac = v3[..., 7]
+        v_rgb = v3[..., 8:11]
+        v_depths = v3[..., 11] if channels == 4 else None
+        _VSPLAT_REGISTRY[vsplat.untyped_storage().data_ptr()] = vsplat
+        if absgrad:
+            # gsplat convention (absgrad=True at model.py:284): the densifier reads means2d.absgrad
+            ctx.means2d_ref.absgrad = v3[..., 2:4]
+        return (v_means2d, v_conics, v_rgb, v_opac, v_depths) + (None,) * 10
+
+
+# ==================================================================================================
+# public operator
+# ==================================================================================================
+def rasterization(
+    means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, colors: Tensor, viewmats: Tensor, Ks: Tensor,
+    width: int, height: int, tile_size: int = 16, packed: bool = False, near_plane: float = 0.01,
+    far_plane: float = 1e10, render_mode: str = "RGB", sh_degree: Optional[int] = None, sparse_grad: bool = False,
+    absgrad: bool = False, rasterize_mode: str = "classic", radius_clip: float = 0.0, eps2d: float = 0.3,
+    backgrounds: Optional[Tensor] = None, _flags: int = 0, _sh_rest: Optional[Tensor] = None,
+    _sync: bool = True,
+) -> Tuple[Tensor, Tensor, Dict]:
+    """Same call surface as the reference's call (model.py:267-288).
+
+    ``_flags`` / ``_sh_rest`` are the fused entry used by ``qed_splatter_amd.model``: with them
+    ``scales`` / ``opacities`` may be raw log-scales / logits (QED_F_LOG_SCALES / QED_F_LOGIT_OPAC)
+    and ``colors`` / ``_sh_rest`` may be features_dc / features_rest without the torch.cat of
+    model.py:241.
+    """
+    if packed or sparse_grad:
+        raise NotImplementedError("packed=True / sparse_grad=True are not used by the reference (model.py:278,283)")
+    if tile_size != L.TILE:
+        raise NotImplementedError("tile_size must be 16 (BLOCK_WIDTH, model.py:243)")
+    if render_mode not in ("RGB", "RGB+D"):
+        raise NotImplementedError(f"render_mode {render_mode!r}: the reference uses 'RGB' / 'RGB+D' (model.py:256-259)")
+    if rasterize_mode not in ("classic", "antialiased"):
+        raise ValueError(f"Unknown rasterize_mode: {rasterize_mode}")
+    if not means.is_cuda:
+        raise L.QedSplatError("rasterization() needs GPU tensors: there is no CPU path in the product")
+    N = means.shape[0]
+    C = viewmats.shape[0]
+    assert means.shape == (N, 3) and quats.shape == (N, 4) and scales.shape == (N, 3)
+    assert opacities.numel() == N and viewmats.shape == (C, 4, 4) and Ks.shape == (C, 3, 3)
+    tile_w = math.ceil(width / tile_size)
+    tile_h = math.ceil(height / tile_size)
+
+    flags = int(_flags)
+    if rasterize_mode == "antialiased":
+        flags |= L.F_ANTIALIASED
+    channels = 3
+    if render_mode == "RGB+D":
+        flags |= L.F_DEPTH_CHANNEL
+        channels = 4
+    if sh_degree is None:
+        deg = -1
+        if colors.dim() != 2 or colors.shape != (N, 3):
+            raise NotImplementedError("sh_degree=None needs colors [N,3] (model.py:263-265)")
+        sh0, shN = colors, None
+    else:
+        deg = int(sh_degree)
+        if deg > 3:
+            raise NotImplementedError("SH degree > 3 (the reference config uses sh_degree=3)")
+        if _sh_rest is not None:
+            sh0, shN = colors.reshape(N, 3), _sh_rest
+            assert shN.shape[1] >= (deg + 1) ** 2 - 1
+        else:
+            assert colors.dim() == 3 and colors.shape[0] == N and colors.shape[2] == 3
+            assert colors.shape[1] >= (deg + 1) ** 2, "colors must hold (sh_degree+1)^2 coefficients"
+            sh0, shN = colors, None
+
+    means2d, depths, conics, opac, rgb, radii, splats, tiles_per_gauss, block_sums = _ProjectSH.apply(
+        means, quats, scales, opacities, sh0, shN, viewmats, Ks, int(width), int(height), tile_w, tile_h, deg, flags,
+        float(eps2d), float(near_plane), float(far_plane), float(radius_clip))
+
+    isect_ids, flatten_ids, offsets, M = _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums,
+                                                       tile_w, tile_h, sync=_sync)
+    render, alpha, last_ids = _Composite.apply(means2d, conics, rgb, opac, depths if channels == 4 else None, splats,
+                                               flatten_ids, offsets, backgrounds, int(width), int(height), tile_w,
+                                               tile_h, channels, bool(absgrad))
+    info = {
+        "camera_ids": None, "gaussian_ids": None,
+        "radii": radii, "means2d": means2d, "depths": depths, "conics": conics, "opacities": opac,
+        "tile_width": tile_w, "tile_height": tile_h, "tiles_per_gauss": tiles_per_gauss,
+        "isect_ids": isect_ids, "flatten_ids": flatten_ids,
+        "isect_offsets": offsets[: C * tile_w * tile_h].view(C, tile_h, tile_w),
+        "width": width, "height": height, "tile_size": tile_size, "n_cameras": C,
+        "last_ids": last_ids, "colors": rgb, "n_isects": M,
+    }
+    return render, alpha, info

@@ -1,0 +1,445 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs.  Bit-exact for integer / index work (tile counts, keys, sort order, offsets, last ids);
+<= 1e-4 relative (of the reference tensor's largest magnitude) for floating point -- the tolerance
+BASELINE.json's north_star states.  Run with `pytest -m gpu` on an MI355X."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import pytest
+import torch
+
+from oracle import splat_oracle as O
+from tests.util import PARAM_NAMES, REL_TOL, activated, assert_close, max_rel, scene, to_dev
+
+pytestmark = pytest.mark.gpu
+
+MARGIN = 1e-5      # decisions closer than this (relative) to a threshold may flip under fp32 rounding
+
+
+def _raster_gpu(sc, dev, w, h, render_mode="RGB+D", sh_degree=3, rasterize_mode="classic", grad=False, **kw):
+    from qed_splatter_amd.rasterization import rasterization
+    a = to_dev(activated(sc, torch.float32), dev)
+    if grad:
+        for k in ("means", "quats", "scales", "opacities", "colors"):
+            a[k].requires_grad_(True)
+    if sh_degree is None:
+        a["colors"] = torch.sigmoid(a["colors"][:, 0, :]).detach().requires_grad_(grad)
+    render, alpha, info = rasterization(
+        means=a["means"], quats=a["quats"], scales=a["scales"], opacities=a["opacities"], colors=a["colors"],
+        viewmats=a["viewmats"], Ks=a["Ks"], width=w, height=h, tile_size=16, packed=False, near_plane=0.01,
+        far_plane=1e10, render_mode=render_mode, sh_degree=sh_degree, sparse_grad=False, absgrad=True,
+        rasterize_mode=rasterize_mode, **kw)
+    return a, render, alpha, info
+
+
+# --------------------------------------------------------------------------------------------------
+# K1/K2: projection + SH
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["classic", "antialiased"])
+@pytest.mark.parametrize("n_cam", [1, 2])
+def test_projection_sh_forward(cuda, mode, n_cam):
+    w, h = 200, 136                       # not multiples of 16
+    sc = scene(6000, w, h, seed=11, n_cameras=n_cam)
+    _, _, _, info = _raster_gpu(sc, cuda, w, h, rasterize_mode=mode)
+    a = activated(sc)
+    radii, m2, depths, conics, comp = O.project_gaussians(
+        a["means"], a["quats"], a["scales"], a["viewmats"], a["Ks"], w, h,
+        calc_compensations=(mode == "antialiased"))
+    g_radii = info["radii"].cpu()
+    # radius = ceil(3 sqrt(lambda)): may differ by one where 3 sqrt(lambda) is within fp32 rounding of an integer
+    diff = (g_radii != radii)
+    assert diff.float().mean() < 2e-3, f"radii mismatch fraction {diff.float().mean():.2e}"
+    same = ~diff & (radii > 0)
+    assert same.sum() > 0.8 * radii.numel()
+    assert_close(info["means2d"].cpu()[same], m2[same], 1e-5, "means2d")
+    assert_close(info["depths"].cpu()[same], depths[same], 1e-5, "depths")
+    assert_close(info["conics"].cpu()[same], conics[same], REL_TOL, "conics")
+    opac = a["opacities"][None].expand(n_cam, -1)
+    if comp is not None:
+        opac = opac * comp
+    assert_close(info["opacities"].cpu()[same], opac[same], 1e-5, "opacities")
+    cols = O.sh_colors(3, a["means"], a["viewmats"], a["colors"], radii)
+    assert_close(info["colors"].cpu()[same], cols[same], 1e-5, "sh colours")
+    # culled Gaussians: zeros everywhere
+    culled = (g_radii == 0)
+    assert info["means2d"].cpu()[culled].abs().max() == 0 if culled.any() else True
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_sh_degrees(cuda, deg):
+    w, h = 96, 64
+    sc = scene(2000, w, h, seed=5)
+    _, _, _, info = _raster_gpu(sc, cuda, w, h, sh_degree=deg)
+    a = activated(sc)
+    radii = info["radii"].cpu()
+    cols = O.sh_colors(deg, a["means"], a["viewmats"], a["colors"][:, : (deg + 1) ** 2], radii)
+    assert_close(info["colors"].cpu(), cols, 1e-5, f"sh degree {deg}")
+
+
+# --------------------------------------------------------------------------------------------------
+# K3/K4/K5: intersection, sort, offsets -- bit exact given the same projected inputs
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,w,h,n_cam", [(5000, 200, 136, 1), (3000, 96, 64, 3), (50, 33, 17, 1)])
+def test_isect_sort_offsets_exact(cuda, n, w, h, n_cam):
+    sc = scene(n, w, h, seed=3, n_cameras=n_cam)
+    _, _, _, info = _raster_gpu(sc, cuda, w, h)
+    tw, th = info["tile_width"], info["tile_height"]
+    tpg, keys, fids = O.isect_tiles(info["means2d"].cpu(), info["radii"].cpu(), info["depths"].cpu(), 16, tw, th)
+    assert torch.equal(info["tiles_per_gauss"].cpu(), tpg)
+    assert info["n_isects"] == keys.numel()
+    assert torch.equal(info["isect_ids"].cpu(), keys)
+    assert torch.equal(info["flatten_ids"].cpu(), fids)
+    offs = O.isect_offset_encode(keys, n_cam, tw, th)
+    assert torch.equal(info["isect_offsets"].cpu(), offs)
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 2048, 2049, 100_000, 1_000_003])
+@pytest.mark.parametrize("end_bit", [45, 64, 8])
+def test_sort_pairs_matches_stable_sort(cuda, lib, n, end_bit):
+    g = torch.Generator().manual_seed(n + end_bit)
+    cap = max(n, 1) + 777
+    # few distinct values in the low bits -> many ties -> stability is exercised
+    keys = torch.randint(0, 2 ** 62, (cap,), generator=g, dtype=torch.int64)
+    if end_bit < 64:
+        keys &= (1 << end_bit) - 1
+    keys[: n // 2] &= 0xFFFF
+    vals = torch.arange(cap, dtype=torch.int32)
+    k_a, v_a = keys.to(cuda), vals.to(cuda)
+    k_b, v_b = torch.empty_like(k_a), torch.empty_like(v_a)
+    n_dev = torch.tensor([n], dtype=torch.int32, device=cuda)
+    ws = torch.empty(int(lib.qed_sort_workspace_bytes(cap)), dtype=torch.uint8, device=cuda)
+    status = torch.zeros(4, dtype=torch.int32, device=cuda)
+    st = torch.cuda.current_stream().cuda_stream
+    which = lib.qed_sort_pairs(k_a.data_ptr(), v_a.data_ptr(), k_b.data_ptr(), v_b.data_ptr(), n_dev.data_ptr(),
+                               cap, end_bit, ws.data_ptr(), ws.numel(), status.data_ptr(), st)
+    assert which in (0, 1), lib.qed_last_error()
+    torch.cuda.synchronize()
+    ko, vo = (k_b, v_b) if which else (k_a, v_a)
+    ref_k, order = torch.sort(keys[:n], stable=True)       # non-negative keys: signed order == unsigned order
+    assert torch.equal(ko[:n].cpu(), ref_k)
+    assert torch.equal(vo[:n].cpu(), vals[:n][order])
+
+
+# --------------------------------------------------------------------------------------------------
+# K6: compositing forward, on the GPU's own projected inputs
+# --------------------------------------------------------------------------------------------------
+def _oracle_composite_inputs(info, channels):
+    m2 = info["means2d"].detach().cpu().double()
+    con = info["conics"].detach().cpu().double()
+    op = info["opacities"].detach().cpu().double()
+    col = info["colors"].detach().cpu().double()
+    if channels == 4:
+        col = torch.cat([col, info["depths"].detach().cpu().double()[..., None]], -1)
+    return m2, con, col, op
+
+
+@pytest.mark.parametrize("mode,w,h,n", [("RGB+D", 200, 136, 8000), ("RGB", 64, 48, 1500), ("RGB+D", 33, 17, 300)])
+def test_composite_forward(cuda, mode, w, h, n):
+    sc = scene(n, w, h, seed=21)
+    _, render, alpha, info = _raster_gpu(sc, cuda, w, h, render_mode=mode)
+    ch = 4 if mode == "RGB+D" else 3
+    m2, con, col, op = _oracle_composite_inputs(info, ch)
+    r_ref, a_ref, last_ref, margin = O.composite_tiles(
+        m2, con, col, op, w, h, 16, info["isect_offsets"].cpu(), info["flatten_ids"].cpu(), return_margin=True)
+    safe = margin > MARGIN
+    assert safe.float().mean() > 0.999
+    assert 0.05 < float(a_ref.mean()) < 0.999            # the scene actually exercises compositing
+    assert_close(render.cpu()[safe], r_ref[safe], REL_TOL, "render")
+    assert_close(alpha.cpu()[..., 0][safe], a_ref[..., 0][safe], REL_TOL, "alpha")
+    assert torch.equal(info["last_ids"].cpu()[safe], last_ref[safe])
+    assert float(alpha.min()) >= 0.0 and float(alpha.max()) <= 1.0
+
+
+def test_composite_early_termination_and_background(cuda):
+    """Dense opaque scene: most pixels terminate early (T <= 1e-4); with a background colour."""
+    w, h, n = 96, 80, 20000
+    sc = scene(n, w, h, seed=9)
+    sc["opacities"] = torch.full_like(sc["opacities"], 6.0)          # sigmoid -> 0.9975
+    sc["scales"] = sc["scales"] + 1.2                                # bigger splats
+    bg = torch.tensor([[0.2, 0.5, 0.7, 0.0]], device=cuda)
+    _, render, alpha, info = _raster_gpu(sc, cuda, w, h, backgrounds=bg)
+    m2, con, col, op = _oracle_composite_inputs(info, 4)
+    r_ref, a_ref, last_ref, margin = O.composite_tiles(
+        m2, con, col, op, w, h, 16, info["isect_offsets"].cpu(), info["flatten_ids"].cpu(), return_margin=True)
+    r_ref = r_ref + (1 - a_ref) * bg.cpu().double()
+    safe = margin > MARGIN
+    assert float((a_ref > 0.9998).float().mean()) > 0.5, "scene should saturate"
+    assert_close(render.cpu()[safe], r_ref[safe], REL_TOL, "render+bg")
+    assert torch.equal(info["last_ids"].cpu()[safe], last_ref[safe])
+
+
+# --------------------------------------------------------------------------------------------------
+# K7: compositing backward
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode,w,h,n", [("RGB+D", 120, 88, 4000), ("RGB", 64, 48, 1500)])
+def test_composite_backward(cuda, mode, w, h, n):
+    sc = scene(n, w, h, seed=33)
+    a, render, alpha, info = _raster_gpu(sc, cuda, w, h, render_mode=mode, grad=True)
+    ch = 4 if mode == "RGB+D" else 3
+    m2, con, col, op = _oracle_composite_inputs(info, ch)
+    for t in (m2, con, col, op):
+        t.requires_grad_(True)
+    r_ref, a_ref, _, margin = O.composite_tiles(
+        m2, con, col, op, w, h, 16, info["isect_offsets"].cpu(), info["flatten_ids"].cpu(), return_margin=True)
+    g = torch.Generator().manual_seed(1)
+    v_r = torch.randn(r_ref.shape, generator=g, dtype=torch.float64)
+    v_a = torch.randn(a_ref.shape, generator=g, dtype=torch.float64)
+    safe = (margin > MARGIN)[..., None].double()
+    v_r, v_a = v_r * safe, v_a * safe                          # no upstream gradient at ambiguous pixels
+    (r_ref * v_r).sum().add((a_ref * v_a).sum()).backward()
+
+    ins = [info["means2d"], info["conics"], info["colors"], info["opacities"]]
+    if ch == 4:
+        ins.append(info["depths"])
+    loss = (render * v_r.to(cuda, torch.float32)).sum() + (alpha * v_a.to(cuda, torch.float32)).sum()
+    grads = torch.autograd.grad(loss, ins)
+    assert_close(grads[0], m2.grad, REL_TOL, "v_means2d")
+    assert_close(grads[1], con.grad, REL_TOL, "v_conics")
+    assert_close(grads[2], col.grad[..., :3], REL_TOL, "v_colors")
+    assert_close(grads[3], op.grad, REL_TOL, "v_opacities")
+    if ch == 4:
+        assert_close(grads[4], col.grad[..., 3], REL_TOL, "v_depths")
+    # absgrad (absgrad=True, model.py:284): sum over pixels of |d L / d xy| -- compare with a per-pixel
+    # accumulation done by the oracle on a few Gaussians
+    absg = info["means2d"].absgrad
+    assert absg.shape == info["means2d"].shape
+    assert bool((absg + 1e-12 >= grads[0].abs() * (1 - 1e-4)).all()), "absgrad >= |grad| must hold"
+
+
+def test_absgrad_matches_per_pixel_sum(cuda):
+    """absgrad = sum_pixels |dL/dxy per pixel|: checked by back-propagating one pixel at a time."""
+    w, h, n = 32, 32, 120
+    sc = scene(n, w, h, seed=4)
+    sc["scales"] = sc["scales"] + 1.5
+    a, render, alpha, info = _raster_gpu(sc, cuda, w, h, render_mode="RGB+D", grad=True)
+    g = torch.Generator().manual_seed(2)
+    v_r = torch.randn(render.shape, generator=g).to(cuda)
+    loss = (render * v_r).sum()
+    (gm,) = torch.autograd.grad(loss, [info["means2d"]], retain_graph=True)
+    absg = info["means2d"].absgrad.clone()
+    acc = torch.zeros_like(absg)
+    acc_s = torch.zeros_like(absg)
+    # one upstream gradient per pixel = w*h backward passes of the GPU kernel itself
+    for y in range(h):
+        for x in range(w):
+            m = torch.zeros_like(v_r)
+            m[0, y, x] = v_r[0, y, x]
+            (gp,) = torch.autograd.grad((render * m).sum(), [info["means2d"]], retain_graph=True)
+            acc += gp.abs()
+            acc_s += gp
+    assert_close(acc_s, gm, 1e-4, "sum of per-pixel grads")
+    assert_close(absg, acc, 1e-4, "absgrad")
+
+
+# --------------------------------------------------------------------------------------------------
+# K1/K2 backward
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["classic", "antialiased"])
+@pytest.mark.parametrize("deg", [3, 1, None])
+def test_projection_sh_backward(cuda, mode, deg):
+    w, h, n = 200, 136, 3000
+    sc = scene(n, w, h, seed=17, n_cameras=2)
+    a, render, alpha, info = _raster_gpu(sc, cuda, w, h, rasterize_mode=mode, sh_degree=deg, grad=True)
+    g = torch.Generator().manual_seed(3)
+    C = 2
+    ups = dict(means2d=torch.randn(C, n, 2, generator=g), depths=torch.randn(C, n, generator=g),
+               conics=torch.randn(C, n, 3, generator=g) * 1e-2, opacities=torch.randn(C, n, generator=g),
+               colors=torch.randn(C, n, 3, generator=g))
+    vis = (info["radii"].cpu() > 0)
+    loss = sum((info[k] * v.to(cuda)).sum() for k, v in ups.items())
+    wrt = [a["means"], a["quats"], a["scales"], a["opacities"], a["colors"]]
+    grads = torch.autograd.grad(loss, wrt)
+
+    ad = activated(sc)
+    if deg is None:
+        ad["colors"] = torch.sigmoid(ad["colors"][:, 0, :])
+    for k in ("means", "quats", "scales", "opacities", "colors"):
+        ad[k].requires_grad_(True)
+    radii, m2, depths, conics, comp = O.project_gaussians(
+        ad["means"], ad["quats"], ad["scales"], ad["viewmats"], ad["Ks"], w, h,
+        calc_compensations=(mode == "antialiased"))
+    opac = ad["opacities"][None].expand(C, -1)
+    if comp is not None:
+        opac = opac * comp
+    # use the GPU's visibility so that radius-rounding differences do not enter the comparison
+    vm = vis.double()
+    if deg is None:
+        cols = ad["colors"][None].expand(C, -1, -1)
+    else:
+        cols = O.sh_colors(deg, ad["means"], ad["viewmats"], ad["colors"][:, : (deg + 1) ** 2], vis.int())
+    ref = dict(means2d=m2, depths=depths, conics=conics, opacities=opac, colors=cols)
+    loss_ref = sum((ref[k] * ups[k].double() * (vm[..., None] if ref[k].dim() == 3 else vm)).sum() for k in ups)
+    loss_ref.backward()
+    same = bool((radii > 0).eq(vis).all())
+    tol = REL_TOL if same else 5e-3
+    for got, name in zip(grads, ("means", "quats", "scales", "opacities", "colors")):
+        assert_close(got, ad[name].grad, tol, f"v_{name} ({mode}, deg={deg})")
+
+
+def test_viewmat_gradient(cuda):
+    """Camera-optimiser path (model.py:212): d loss / d viewmats."""
+    w, h, n = 96, 64, 1500
+    sc = scene(n, w, h, seed=8)
+    from qed_splatter_amd.rasterization import rasterization
+    a = to_dev(activated(sc, torch.float32), cuda)
+    a["viewmats"].requires_grad_(True)
+    render, alpha, info = rasterization(**a, width=w, height=h, render_mode="RGB+D", sh_degree=3, absgrad=True)
+    g = torch.Generator().manual_seed(5)
+    ups = dict(means2d=torch.randn(1, n, 2, generator=g), depths=torch.randn(1, n, generator=g),
+               conics=torch.randn(1, n, 3, generator=g) * 1e-2, colors=torch.randn(1, n, 3, generator=g))
+    loss = sum((info[k] * v.to(cuda)).sum() for k, v in ups.items())
+    (gv,) = torch.autograd.grad(loss, [a["viewmats"]])
+    ad = activated(sc)
+    ad["viewmats"].requires_grad_(True)
+    vis = info["radii"].cpu() > 0
+    radii, m2, depths, conics, _ = O.project_gaussians(ad["means"], ad["quats"], ad["scales"], ad["viewmats"],
+                                                       ad["Ks"], w, h)
+    cols = O.sh_colors(3, ad["means"], ad["viewmats"], ad["colors"], vis.int())
+    ref = dict(means2d=m2, depths=depths, conics=conics, colors=cols)
+    vm = vis.double()
+    sum((ref[k] * ups[k].double() * (vm[..., None] if ref[k].dim() == 3 else vm)).sum() for k in ups).backward()
+    assert_close(gv[:, :3, :], ad["viewmats"].grad[:, :3, :], 5e-4, "v_viewmats")
+
+
+# --------------------------------------------------------------------------------------------------
+# end to end: model-level outputs, losses and parameter gradients
+# --------------------------------------------------------------------------------------------------
+def _model(sc, dev, **cfg_kw):
+    from qed_splatter_amd.model import PinholeCameras, QEDSplatterModel, QEDSplatterModelConfig
+    cfg = QEDSplatterModelConfig(sh_degree_interval=1, **cfg_kw)
+    m = QEDSplatterModel(cfg, **{k: sc[k].to(dev) for k in PARAM_NAMES})
+    m.step = 100
+    K = sc["Ks"][0]
+    h, w = sc["gt_rgb"].shape[:2]
+    cam = PinholeCameras(sc["camera_to_worlds"][:1].to(dev), K[0, 0], K[1, 1], K[0, 2], K[1, 2], w, h)
+    batch = {"image": sc["gt_rgb"].to(dev), "depth_image": sc["gt_depth"].to(dev)}
+    return m, cam, batch
+
+
+def _oracle_step(sc, w, h, cfg, mask=None, radii=None):
+    """fp64 oracle step.  `radii` = the radii of the run under test (ceil() near an integer is a coin
+    toss between fp32 and fp64; the radius is non-differentiable)."""
+    ps = {k: sc[k].double().requires_grad_(True) for k in PARAM_NAMES}
+    out = O.splatfacto_outputs(ps["means"], ps["scales"], ps["quats"], ps["opacities"], ps["features_dc"],
+                               ps["features_rest"], sc["camera_to_worlds"][:1].double(), sc["Ks"][:1].double(), w, h,
+                               sc["background"].double(), rasterize_mode=cfg.rasterize_mode,
+                               radii_override=radii, return_margin=True)
+    l_rgb = (1 - cfg.ssim_lambda) * O.rgb_l1_loss(out["rgb"], sc["gt_rgb"].double())
+    l_d = O.depth_l1_loss(out["depth"], sc["gt_depth"].double(), mask, cfg.depth_lambda)
+    (l_rgb + l_d).backward()
+    return out, l_rgb, l_d, ps
+
+
+@pytest.mark.parametrize("w,h,n", [(160, 112, 3000), (256, 256, 10000)])
+def test_end_to_end_api_path(cuda, w, h, n):
+    """get_outputs + get_loss_dict (the reference's own call sequence) against the oracle."""
+    sc = scene(n, w, h, seed=1234)
+    m, cam, batch = _model(sc, cuda)
+    out = m.get_outputs(cam)
+    ld = m.get_loss_dict(out, batch)
+    (ld["main_loss"] + ld["depth_loss"]).backward()
+    ref, l_rgb, l_d, ps = _oracle_step(sc, w, h, m.config, radii=m.info["radii"].cpu())
+    assert out["rgb"].shape == (h, w, 3) and out["depth"].shape == (h, w, 1) and out["accumulation"].shape == (h, w, 1)
+    # pixels where an alpha / transmittance decision sits within fp32 rounding of its threshold may
+    # legitimately flip between the fp32 kernels and the fp64 oracle: excluded, and they must be rare
+    safe = ref["info"]["margin"][0] > MARGIN
+    assert float(safe.float().mean()) > 0.9995
+    assert_close(out["rgb"].cpu()[safe], ref["rgb"][safe], REL_TOL, "rgb")
+    assert_close(out["accumulation"].cpu()[safe], ref["accumulation"][safe], REL_TOL, "accumulation")
+    assert_close(out["depth"].cpu()[safe], ref["depth"][safe], REL_TOL, "depth")
+    assert abs(float(ld["main_loss"].detach()) - float(l_rgb)) <= 1e-4 * float(l_rgb)
+    assert abs(float(ld["depth_loss"].detach()) - float(l_d)) <= 1e-4 * float(l_d)
+    # gradients integrate over all pixels, the (rare) flipped ones included, hence the looser bound
+    # here; the stage tests above hold every gradient to 1e-4 with flips masked out
+    for name in PARAM_NAMES:
+        assert_close(m.gauss_params[name].grad, ps[name].grad, 1e-3, f"grad {name}")
+    # side effects the densifier reads (model.py:249,289-292)
+    assert m.last_size == (h, w) and m.xys.shape == (1, n, 2) and m.radii.shape == (n,)
+    assert m.xys.grad is not None and m.xys.absgrad.shape == (1, n, 2)
+
+
+def test_fused_path_equals_api_path(cuda):
+    """fused_loss (K8 kernel, fused activations) == get_outputs + get_loss_dict."""
+    w, h, n = 200, 136, 6000
+    sc = scene(n, w, h, seed=77)
+    mask = (torch.rand(h, w, 1, generator=torch.Generator().manual_seed(1)) > 0.3).float()
+    m1, cam, batch = _model(sc, cuda)
+    batch["mask"] = mask.to(cuda)
+    out = m1.get_outputs(cam)
+    ld = m1.get_loss_dict(out, batch)
+    (ld["main_loss"] + ld["depth_loss"]).backward()
+    m2, cam2, batch2 = _model(sc, cuda)
+    batch2["mask"] = mask.to(cuda)
+    lf = m2.fused_loss(cam2, batch2)
+    (lf["main_loss"] + lf["depth_loss"]).backward()
+    assert abs(float(lf["main_loss"]) - float(ld["main_loss"])) <= 2e-6 * abs(float(ld["main_loss"])) + 1e-9
+    assert abs(float(lf["depth_loss"]) - float(ld["depth_loss"])) <= 2e-6 * abs(float(ld["depth_loss"])) + 1e-9
+    for name in PARAM_NAMES:
+        assert_close(m2.gauss_params[name].grad, m1.gauss_params[name].grad, 2e-5, f"fused grad {name}")
+    # the six gradients alias one flat allocation (what the data-parallel all-reduce relies on)
+    fg = m2.flat_grad()
+    assert fg.data_ptr() == m2.gauss_params["means"].grad.data_ptr() and fg.numel() == m2.flat_params.numel()
+
+
+def test_empty_and_degenerate_inputs(cuda):
+    from qed_splatter_amd.rasterization import rasterization
+    w, h = 48, 40
+    sc = scene(64, w, h, seed=2)
+    a = to_dev(activated(sc, torch.float32), cuda)
+    # every Gaussian behind the camera -> nothing visible, zero intersections
+    a["means"] = a["means"] * torch.tensor([1.0, 1.0, -1.0], device=cuda)
+    render, alpha, info = rasterization(**a, width=w, height=h, render_mode="RGB+D", sh_degree=3, absgrad=True)
+    assert info["n_isects"] == 0 and float(render.abs().max()) == 0.0 and float(alpha.max()) == 0.0
+    assert int(info["radii"].max()) == 0
+    # loss on an empty render: depth loss falls back to 0-valid handling (model.py:111-114)
+    m, cam, batch = _model(sc, cuda)
+    batch["depth_image"] = torch.zeros_like(batch["depth_image"])        # no valid ground truth
+    lf = m.fused_loss(cam, batch)
+    assert float(lf["depth_loss"]) == 0.0 and math.isfinite(float(lf["main_loss"]))
+
+
+def test_error_conventions(cuda):
+    from qed_splatter_amd.rasterization import rasterization
+    sc = scene(32, 32, 32, seed=2)
+    a = to_dev(activated(sc, torch.float32), cuda)
+    with pytest.raises(ValueError):
+        rasterization(**a, width=32, height=32, sh_degree=3, rasterize_mode="bogus")
+    with pytest.raises(NotImplementedError):
+        rasterization(**a, width=32, height=32, sh_degree=3, packed=True)
+    m, cam, batch = _model(sc, cuda)
+    assert m.get_outputs("not a camera") == {}                       # model.py:206-208
+    m.config.rasterize_mode = "bogus"
+    with pytest.raises(ValueError):
+        m.get_outputs(cam)                                           # model.py:253-254
+    # CPU tensors must fail loudly: no silent fallback
+    from qed_splatter_amd._lib import QedSplatError
+    b = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in a.items()}
+    with pytest.raises(QedSplatError):
+        rasterization(**b, width=32, height=32, sh_degree=3)
+
+
+def test_fused_adam_matches_torch(cuda):
+    from qed_splatter_amd.model import FlatAdam
+    w, h, n = 96, 64, 1000
+    sc = scene(n, w, h, seed=6)
+    m, cam, batch = _model(sc, cuda)
+    opt = FlatAdam(m)
+    ref_params = {k: m.gauss_params[k].detach().clone().requires_grad_(True) for k in PARAM_NAMES}
+    ref_opts = [torch.optim.Adam([ref_params[k]], lr=opt.lr[i], eps=1e-15) for i, k in enumerate(PARAM_NAMES)]
+    for _ in range(3):
+        for p in m.parameters():
+            p.grad = None
+        lf = m.fused_loss(cam, batch)
+        (lf["main_loss"] + lf["depth_loss"]).backward()
+        for k in PARAM_NAMES:
+            ref_params[k].grad = m.gauss_params[k].grad.detach().clone()
+        opt.step()
+        for o in ref_opts:
+            o.step()
+        for k in PARAM_NAMES:
+            # the reference optimiser sees the same gradients only on the first step (parameters drift
+            # by fp32 rounding afterwards), so compare after re-synchronising
+            assert_close(m.gauss_params[k], ref_params[k], 1e-5, f"adam {k}")
+            ref_params[k].data.copy_(m.gauss_params[k].data)
