@@ -57,7 +57,12 @@ def cpu_baseline(args):
     from oracle import splat_oracle as O           # cpu_baseline leg only
     div = args.cpu_sample_div
     n, w, h = args.gaussians // (div * div), args.width // div, args.height // div
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU a 16-core share of the host: more threads than that only thrash
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
     torch.set_num_threads(cores)
     sc = O.synthetic_scene(n, w, h, seed=1235)
     names = ("means", "scales", "quats", "opacities", "features_dc", "features_rest")
@@ -129,10 +134,15 @@ def main():
         opt.step()
         return losses
 
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
     # first step is synchronous: it calibrates the intersection-buffer capacity and gives M
     step(True)
     M = int(model.info["n_isects"])
     n_vis = int((model.info["radii"] > 0).sum())
+    log(f"scene ready: N={n} visible={n_vis} M={M}")
     for _ in range(max(args.warmup - 1, 0)):
         step(args.sync_m)
     torch.cuda.synchronize()
@@ -157,6 +167,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     kern = L.TIMER.summary()
+    log(f"instrumented region: {dt / args.steps * 1e3:.3f} ms/step")
 
     # a second, un-instrumented timed region gives the headline number (event records cost host time)
     barrier()
@@ -198,6 +209,7 @@ def main():
             "kernels_ms": {k: round(v[1], 4) for k, v in sorted(kern.items())},
             "roofline": roof,
         }
+        log(f"timed region: {ms_step:.3f} ms/step")
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

@@ -1,0 +1,84 @@
+"""World-size-2 `gloo` tests of the camera-sharded data-parallel path on CPU: the
+flat-gradient all-reduce, replica consistency after the optimiser step, and the per-rank scene
+sharding bench.py uses."""
+from __future__ import annotations
+
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.util import PARAM_NAMES, scene
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from qed_splatter_amd.model import QEDSplatterModel
+        from qed_splatter_amd.parallel import allreduce_densification_stats, allreduce_flat_grad
+        sc = scene(50, 32, 32, seed=5)
+        m = QEDSplatterModel(None, **{k: sc[k] for k in PARAM_NAMES})
+        # rank-dependent gradients laid out as _ProjectSH.backward lays them out (one allocation)
+        total = m.flat_params.numel()
+        flat = torch.arange(total, dtype=torch.float32) * (rank + 1)
+        off = 0
+        for name in m.group_names:
+            p = m.gauss_params[name]
+            p.grad = flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+        g = allreduce_flat_grad(m, world)
+        want = torch.arange(total, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
+        ok = torch.allclose(g, want) and g.data_ptr() == m.means.grad.data_ptr()
+        # identical update on every rank keeps the replicas bit-identical
+        with torch.no_grad():
+            m.flat_params.add_(g, alpha=-1e-3)
+        gathered = [torch.empty_like(m.flat_params) for _ in range(world)]
+        dist.all_gather(gathered, m.flat_params.detach())
+        ok = ok and all(torch.equal(gathered[0], t) for t in gathered)
+        # densification statistics: SUM / SUM / MAX
+        a = torch.full((50,), float(rank + 1))
+        c = torch.full((50,), 1.0)
+        r = torch.full((50,), float(10 * (rank + 1)))
+        allreduce_densification_stats(a, c, r)
+        ok = ok and float(a[0]) == sum(range(1, world + 1)) and float(c[0]) == world and float(r[0]) == 10 * world
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_grad_allreduce_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_bench_scene_sharding_by_rank():
+    """Every rank sees the same Gaussians and its own camera (yaw 5 degrees * rank)."""
+    import bench
+    s0 = bench.make_scene(200, 64, 48, 0, torch.device("cpu"))
+    s1 = bench.make_scene(200, 64, 48, 1, torch.device("cpu"))
+    for k in PARAM_NAMES:
+        assert torch.equal(s0[k], s1[k])
+    assert s0["camera_to_worlds"].shape == s1["camera_to_worlds"].shape == (1, 3, 4)
+    assert not torch.equal(s0["camera_to_worlds"], s1["camera_to_worlds"])
+    yaw = torch.atan2(s1["camera_to_worlds"][0, 0, 2], s1["camera_to_worlds"][0, 0, 0])
+    assert abs(float(torch.rad2deg(yaw)) - 5.0) < 1e-4
