@@ -319,6 +319,19 @@ def _model(sc, dev, **cfg_kw):
     return m, cam, batch
 
 
+def _gaussians_in_tiles_of(info, pix_mask, n):
+    """Boolean [N]: Gaussians listed in any tile that contains a pixel of `pix_mask` [H,W] (camera 0)."""
+    out = torch.zeros(n, dtype=torch.bool)
+    ys, xs = torch.nonzero(pix_mask, as_tuple=True)
+    if ys.numel() == 0:
+        return out
+    tw = info["tile_width"]
+    offs = info["isect_offsets"].reshape(-1).tolist() + [info["flatten_ids"].numel()]
+    for t in set((ys // 16 * tw + xs // 16).tolist()):
+        out[info["flatten_ids"][offs[t]:offs[t + 1]].long() % n] = True
+    return out
+
+
 def _oracle_step(sc, w, h, cfg, mask=None, radii=None):
     """fp64 oracle step.  `radii` = the radii of the run under test (ceil() near an integer is a coin
     toss between fp32 and fp64; the radius is non-differentiable)."""
@@ -352,10 +365,12 @@ def test_end_to_end_api_path(cuda, w, h, n):
     assert_close(out["depth"].cpu()[safe], ref["depth"][safe], REL_TOL, "depth")
     assert abs(float(ld["main_loss"].detach()) - float(l_rgb)) <= 1e-4 * float(l_rgb)
     assert abs(float(ld["depth_loss"].detach()) - float(l_d)) <= 1e-4 * float(l_d)
-    # gradients integrate over all pixels, the (rare) flipped ones included, hence the looser bound
-    # here; the stage tests above hold every gradient to 1e-4 with flips masked out
+    # a flipped decision at a pixel changes the gradient of every Gaussian in that pixel's tile list:
+    # those (few) Gaussians are left out of the gradient comparison
+    keep = ~_gaussians_in_tiles_of(ref["info"], ~safe, n)
+    assert float(keep.float().mean()) > 0.97
     for name in PARAM_NAMES:
-        assert_close(m.gauss_params[name].grad, ps[name].grad, 1e-3, f"grad {name}")
+        assert_close(m.gauss_params[name].grad.cpu()[keep], ps[name].grad[keep], REL_TOL, f"grad {name}")
     # side effects the densifier reads (model.py:249,289-292)
     assert m.last_size == (h, w) and m.xys.shape == (1, n, 2) and m.radii.shape == (n,)
     assert m.xys.grad is not None and m.xys.absgrad.shape == (1, n, 2)
