@@ -65,7 +65,7 @@ const char* qed_last_error(void);
  *
  * outputs: radii[C,N] i32, means2d[C,N,2], depths[C,N], conics[C,N,3], opac_out[C,N],
  *   colors_out[C,N,3], tiles_per_gauss[C,N] i32 and the packed record splats[C*N][12] =
- *   {x, y, conic_a, conic_b | conic_c, opacity, r, g | b, depth, 0, 0} read by the
+ *   {x, y, conic_a, conic_b | conic_c, opacity, r, g | b, depth, ln(255 opacity), 0} read by the
  *   compositing kernels; block_sums[ceil(C*N/256)] i32 = tile counts summed per 256
  *   consecutive (camera,Gaussian) slots (input of qed_isect_scan).
  * Culled Gaussians get radius 0 and zeros everywhere. */

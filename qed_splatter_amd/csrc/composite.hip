@@ -25,6 +25,65 @@ __device__ __forceinline__ void pixel_of_thread(int tid, int& lx, int& ly) {
     ly = ((w >> 1) << 3) | (l >> 3);
 }
 
+
+// ---- exact-conservative quadrant culling ---------------------------------------------------------
+// A Gaussian contributes to a pixel only if alpha = min(.999, o e^-sigma) >= 1/255, i.e.
+// sigma <= tau = ln(255 o).  For each 8x8 quadrant (= one wave) the staging thread minimises the
+// quadratic form sigma over the quadrant's pixel-centre rectangle (convex: the minimum is 0 if the
+// mean lies inside, otherwise it is on one of the four edges) and drops the Gaussian for that wave
+// when sigma_min > tau + margin.  The margin covers fp32 rounding of both this bound and the
+// per-pixel evaluation, so a culled Gaussian is one every pixel of the quadrant would have
+// skipped anyway: results are bit-identical to the unculled loop.
+__device__ __forceinline__ float rect_min_sigma(float a, float b, float c, float x0, float x1, float y0, float y1,
+                                                float& scale) {
+    const float ax = fmaxf(fabsf(x0), fabsf(x1)), ay = fmaxf(fabsf(y0), fabsf(y1));
+    scale = a * ax * ax + c * ay * ay + fabsf(b) * ax * ay;
+    if (x0 <= 0.f && x1 >= 0.f && y0 <= 0.f && y1 >= 0.f) return 0.f;
+    const float ia = 1.f / a, ic = 1.f / c;
+    float m;
+    {
+        const float y = fminf(fmaxf(-b * x0 * ic, y0), y1);
+        m = 0.5f * (a * x0 * x0 + c * y * y) + b * x0 * y;
+    }
+    {
+        const float y = fminf(fmaxf(-b * x1 * ic, y0), y1);
+        m = fminf(m, 0.5f * (a * x1 * x1 + c * y * y) + b * x1 * y);
+    }
+    {
+        const float x = fminf(fmaxf(-b * y0 * ia, x0), x1);
+        m = fminf(m, 0.5f * (a * x * x + c * y0 * y0) + b * x * y0);
+    }
+    {
+        const float x = fminf(fmaxf(-b * y1 * ia, x0), x1);
+        m = fminf(m, 0.5f * (a * x * x + c * y1 * y1) + b * x * y1);
+    }
+    return m;
+}
+
+// Ballot, for each of the 4 quadrants of the tile at pixel origin (ox, oy), which of this wave's 64
+// staged records can contribute; lane 0 stores the 4 masks to s_mask[q][wave].
+__device__ __forceinline__ void stage_cull_masks(bool present, const float4& r0, const float4& r1, float tau,
+                                                 float ox, float oy, unsigned long long (*s_mask)[4], int wid,
+                                                 int lane) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        // pixel centres of quadrant q relative to the mean
+        const float x0 = ox + (float)((q & 1) << 3) + 0.5f - r0.x, x1 = x0 + 7.f;
+        const float y0 = oy + (float)((q >> 1) << 3) + 0.5f - r0.y, y1 = y0 + 7.f;
+        float scale;
+        const float smin = rect_min_sigma(r0.z, r0.w, r1.x, x0, x1, y0, y1, scale);
+        const bool keep = present && !(smin > tau + 1e-3f + 8e-6f * scale);
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) s_mask[q][wid] = m;
+    }
+}
+
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 // ================================================================================================
 // forward
 // ================================================================================================
@@ -37,6 +96,7 @@ composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
     __shared__ float4 s_q0[kBatch];   // x, y, conic_a, conic_b
     __shared__ float4 s_q1[kBatch];   // conic_c, opacity, r, g
     __shared__ float2 s_q2[kBatch];   // b, depth
+    __shared__ unsigned long long s_mask[4][4];       // [quadrant = consuming wave][staging wave]
     __shared__ int s_done[4];
 
     const int tile = blockIdx.x;                      // cam * T + ty * tile_w + tx
@@ -44,12 +104,13 @@ composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
     const int cam = tile / n_tiles;
     const int t_in = tile - cam * n_tiles;
     const int ty = t_in / tile_w, tx = t_in - ty * tile_w;
-    const int tid = threadIdx.x, wid = tid >> 6;
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
     int lx, ly;
     pixel_of_thread(tid, lx, ly);
     const int ix = tx * QED_TILE + lx, iy = ty * QED_TILE + ly;
     const float px = (float)ix + 0.5f, py = (float)iy + 0.5f;
     const bool inside = ix < width && iy < height;
+    const float ox = (float)(tx * QED_TILE), oy = (float)(ty * QED_TILE);
 
     const int start = offsets[tile], end = offsets[tile + 1];
     const int nb = (end - start + kBatch - 1) / kBatch;
@@ -63,9 +124,11 @@ composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
 
     // prefetch batch 0
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+    bool present = false;
     {
         const int idx = start + tid;
-        if (idx < end) {
+        present = idx < end;
+        if (present) {
             const size_t g = (size_t)flatten_ids[idx];
             r0 = splats[3 * g]; r1 = splats[3 * g + 1]; r2 = splats[3 * g + 2];
         }
@@ -73,22 +136,29 @@ composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
     for (int b = 0; b < nb; ++b) {
         __syncthreads();                               // LDS of the previous batch fully consumed
         s_q0[tid] = r0; s_q1[tid] = r1; s_q2[tid] = make_float2(r2.x, r2.y);
+        stage_cull_masks(present, r0, r1, r2.z, ox, oy, s_mask, wid, lane);
         const bool wave_done = __all(done);
-        if ((tid & 63) == 0) s_done[wid] = wave_done;
+        if (lane == 0) s_done[wid] = wave_done;
         __syncthreads();
         if (s_done[0] && s_done[1] && s_done[2] && s_done[3]) break;
         // issue the gather of the next batch; it lands while this batch is composited
         if (b + 1 < nb) {
             const int idx = start + (b + 1) * kBatch + tid;
-            if (idx < end) {
+            present = idx < end;
+            if (present) {
                 const size_t g = (size_t)flatten_ids[idx];
                 r0 = splats[3 * g]; r1 = splats[3 * g + 1]; r2 = splats[3 * g + 2];
             }
         }
         if (wave_done) continue;
         const int batch_start = start + b * kBatch;
-        const int bn = min(kBatch, end - batch_start);
-        for (int t = 0; t < bn; ++t) {
+        bool wave_finished = false;
+#pragma unroll 1
+        for (int sw = 0; sw < 4 && !wave_finished; ++sw) {
+          unsigned long long m = uniform_u64(s_mask[wid][sw]);
+          while (m) {
+            const int t = (sw << 6) + __builtin_ctzll(m);
+            m &= m - 1;
             const float4 q0 = s_q0[t];
             const float4 q1 = s_q1[t];
             const float dx = q0.x - px, dy = q0.y - py;
@@ -106,7 +176,8 @@ composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
             if constexpr (CH == 4) out[3] += q2.y * w;
             T = acc ? nT : T;
             cur = acc ? batch_start + t : cur;
-            if (__all(done)) break;
+            if (__all(done)) { wave_finished = true; break; }
+          }
         }
     }
     if (inside) {
@@ -171,6 +242,7 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
     __shared__ int s_id[kBatch];
     __shared__ float s_acc[kBatch][12];
     __shared__ int s_touched[kBatch];
+    __shared__ unsigned long long s_mask[4][4];       // [quadrant = consuming wave][staging wave]
     __shared__ int s_wmax[4];
 
     const int tile = blockIdx.x;
@@ -185,6 +257,7 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
     const float px = (float)ix + 0.5f, py = (float)iy + 0.5f;
     const bool inside = ix < width && iy < height;
     const size_t pix = ((size_t)cam * height + (inside ? iy : 0)) * width + (inside ? ix : 0);
+    const float ox = (float)(tx * QED_TILE), oy = (float)(ty * QED_TILE);
 
     const int start = offsets[tile], end = offsets[tile + 1];
     if (end <= start) return;
@@ -242,6 +315,7 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
 #pragma unroll
         for (int k = 0; k < 12; ++k) s_acc[tid][k] = 0.f;
         s_touched[tid] = 0;
+        stage_cull_masks(rid >= 0, r0, r1, r2.z, ox, oy, s_mask, wid, lane);
         __syncthreads();
         const int batch_hi = eff_end - 1 - b * kBatch;            // sorted index of slot 0
         const int bn = min(kBatch, batch_hi - start + 1);
@@ -255,7 +329,13 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
         }
         // slots whose index is beyond every pixel of this wave can be skipped wholesale
         const int t0 = max(0, batch_hi - wave_last);
-        for (int t = t0; t < bn; ++t) {
+#pragma unroll 1
+        for (int sw = t0 >> 6; sw < 4; ++sw) {
+          unsigned long long m = uniform_u64(s_mask[wid][sw]);
+          if (sw == (t0 >> 6)) m &= ~0ull << (t0 & 63);
+          while (m) {
+            const int t = (sw << 6) + __builtin_ctzll(m);
+            m &= m - 1;
             const int idx = batch_hi - t;
             const float4 q0 = s_q0[t];
             const float4 q1 = s_q1[t];
@@ -306,6 +386,7 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
                 atomicAdd(&s_acc[t][vbase + 8], w[2]);
                 if (lane == 0) s_touched[t] = 1;
             }
+          }
         }
         __syncthreads();
         // flush: 16 lanes per Gaussian -> one 64-byte row per atomic request

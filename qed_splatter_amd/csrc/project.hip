@@ -291,7 +291,8 @@ project_fwd_kernel(int N, int C, const float* __restrict__ means, const float* _
             ntiles = (x1 - x0) * (y1 - y0);
             r0 = make_float4(mx, my, ca, cb);
             r1 = make_float4(cc, op, rgb[0], rgb[1]);
-            r2 = make_float4(rgb[2], (flags & QED_F_DEPTH_CHANNEL) ? z : 0.f, 0.f, 0.f);
+            // tau = ln(255 o): alpha >= 1/255  <=>  sigma <= tau (used by the compositing kernels' quadrant culling)
+            r2 = make_float4(rgb[2], (flags & QED_F_DEPTH_CHANNEL) ? z : 0.f, logf(255.f * op), 0.f);
         }
         radii[slot] = rad;
         means2d[2 * slot] = mx; means2d[2 * slot + 1] = my;
