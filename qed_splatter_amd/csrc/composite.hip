@@ -2,38 +2,42 @@
 //
 // Replaces gsplat rasterize_to_pixels fwd/bwd behind model.py:267-288.
 //
-// One 256-thread workgroup per 16x16 tile = 4 waves, each wave owning one 8x8 pixel quadrant (so a
-// wave's early-out and "nobody touches this Gaussian" tests see a compact pixel block).  The
-// tile's run of the depth-sorted list is streamed in batches of 256: every thread gathers one
-// 48-byte splat record (three 16-byte loads) for the NEXT batch into registers while the current
-// batch, staged in LDS, is consumed with wave-uniform (broadcast) LDS reads.
-//
-// Backward: per-pixel gradients of one Gaussian are reduced over the 64 lanes with
-// v_permlane32_swap / v_permlane16_swap (which halve the number of live values at each level)
-// plus one DPP row reduction, then accumulated per tile in LDS and flushed with ONE 64-byte-row
-// atomic add per (tile, Gaussian).
+// Design (CDNA4-first, not a warp-32 translation):
+//   * ONE 64-lane wave per 16x16 tile.  Lane l owns four pixels, the same (l & 7, l >> 3) position
+//     in each of the tile's four 8x8 quadrants.  A workgroup is a single wave, so the kernel is
+//     wave-synchronous: no workgroup barriers, no inter-wave imbalance, early-out per tile.
+//   * The tile's run of the depth-sorted list is streamed in batches of 64: every lane gathers one
+//     48-byte splat record (three 16-byte loads) for the NEXT batch into registers while the
+//     current batch, staged in LDS, is consumed.  One broadcast LDS read of a record now feeds 256
+//     pixel evaluations (4 per lane) instead of 64, which takes the LDS pipe off the critical path,
+//     and the four independent pixel chains per lane give the VALU instruction-level parallelism.
+//   * Exact-conservative quadrant culling: at staging time each lane bounds, for each quadrant, the
+//     minimum of its Gaussian's quadratic form over the quadrant's pixel-centre rectangle; 64-bit
+//     ballots turn that into four scalar bit masks, and the consuming loop walks set bits with
+//     scalar instructions.  A culled (Gaussian, quadrant) pair is one whose 64 pixels would all
+//     have failed the alpha >= 1/255 test, so results are identical to the unculled loop.
+//   * Backward: the per-pixel gradients of one Gaussian are first summed over the lane's four
+//     pixels, then reduced over the 64 lanes with v_permlane32_swap / v_permlane16_swap (the
+//     number of live values halves per level) + one DPP row reduction, parked in LDS and flushed
+//     with ONE 64-byte-row atomic request per (tile, Gaussian) that actually contributed.
 #include "qed_common.h"
 
 namespace qed {
 
-constexpr int kBatch = 256;
+constexpr int kBatch = 64;
 
-__device__ __forceinline__ void pixel_of_thread(int tid, int& lx, int& ly) {
-    // wave w -> quadrant (w & 1, w >> 1); lane l -> (l & 7, l >> 3) inside the quadrant
-    const int w = tid >> 6, l = tid & 63;
-    lx = ((w & 1) << 3) | (l & 7);
-    ly = ((w >> 1) << 3) | (l >> 3);
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
+// contiguous range of tiles (whole image rows): neighbouring tiles share splat records in one L2.
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+    const int q = n >> 3, r = n & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
-
 // ---- exact-conservative quadrant culling ---------------------------------------------------------
-// A Gaussian contributes to a pixel only if alpha = min(.999, o e^-sigma) >= 1/255, i.e.
-// sigma <= tau = ln(255 o).  For each 8x8 quadrant (= one wave) the staging thread minimises the
-// quadratic form sigma over the quadrant's pixel-centre rectangle (convex: the minimum is 0 if the
-// mean lies inside, otherwise it is on one of the four edges) and drops the Gaussian for that wave
-// when sigma_min > tau + margin.  The margin covers fp32 rounding of both this bound and the
-// per-pixel evaluation, so a culled Gaussian is one every pixel of the quadrant would have
-// skipped anyway: results are bit-identical to the unculled loop.
+// alpha = min(.999, o e^-sigma) >= 1/255  <=>  sigma <= tau = ln(255 o).  sigma is a convex quadratic
+// form: its minimum over the quadrant's pixel-centre rectangle is 0 if the mean lies inside,
+// otherwise it is attained on one of the four edges.  The margin covers fp32 rounding of this
+// bound and of the per-pixel evaluation.
 __device__ __forceinline__ float rect_min_sigma(float a, float b, float c, float x0, float x1, float y0, float y1,
                                                 float& scale) {
     const float ax = fmaxf(fabsf(x0), fabsf(x1)), ay = fmaxf(fabsf(y0), fabsf(y1));
@@ -60,35 +64,20 @@ __device__ __forceinline__ float rect_min_sigma(float a, float b, float c, float
     return m;
 }
 
-// Ballot, for each of the 4 quadrants of the tile at pixel origin (ox, oy), which of this wave's 64
-// staged records can contribute; lane 0 stores the 4 masks to s_mask[q][wave].
-__device__ __forceinline__ void stage_cull_masks(bool present, const float4& r0, const float4& r1, float tau,
-                                                 float ox, float oy, unsigned long long (*s_mask)[4], int wid,
-                                                 int lane) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        // pixel centres of quadrant q relative to the mean
-        const float x0 = ox + (float)((q & 1) << 3) + 0.5f - r0.x, x1 = x0 + 7.f;
-        const float y0 = oy + (float)((q >> 1) << 3) + 0.5f - r0.y, y1 = y0 + 7.f;
-        float scale;
-        const float smin = rect_min_sigma(r0.z, r0.w, r1.x, x0, x1, y0, y1, scale);
-        const bool keep = present && !(smin > tau + 1e-3f + 8e-6f * scale);
-        const unsigned long long m = __ballot(keep);
-        if (lane == 0) s_mask[q][wid] = m;
-    }
-}
-
-__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
-    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return ((unsigned long long)hi << 32) | lo;
+__device__ __forceinline__ bool quadrant_may_touch(const float4& r0, const float4& r1, float tau, float ox, float oy,
+                                                   int q) {
+    const float x0 = ox + (float)((q & 1) << 3) + 0.5f - r0.x, x1 = x0 + 7.f;
+    const float y0 = oy + (float)((q >> 1) << 3) + 0.5f - r0.y, y1 = y0 + 7.f;
+    float scale;
+    const float smin = rect_min_sigma(r0.z, r0.w, r1.x, x0, x1, y0, y1, scale);
+    return !(smin > tau + 1e-3f + 8e-6f * scale);
 }
 
 // ================================================================================================
 // forward
 // ================================================================================================
 template <int CH>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __restrict__ flatten_ids,
                      const int* __restrict__ offsets, int width, int height, int tile_w, int tile_h,
                      const float* __restrict__ backgrounds, float* __restrict__ render, float* __restrict__ alpha_out,
@@ -96,103 +85,113 @@ composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
     __shared__ float4 s_q0[kBatch];   // x, y, conic_a, conic_b
     __shared__ float4 s_q1[kBatch];   // conic_c, opacity, r, g
     __shared__ float2 s_q2[kBatch];   // b, depth
-    __shared__ unsigned long long s_mask[4][4];       // [quadrant = consuming wave][staging wave]
-    __shared__ int s_done[4];
 
-    const int tile = blockIdx.x;                      // cam * T + ty * tile_w + tx
     const int n_tiles = tile_w * tile_h;
+    const int tile = xcd_remap(blockIdx.x, C * n_tiles);   // cam * T + ty * tile_w + tx
     const int cam = tile / n_tiles;
     const int t_in = tile - cam * n_tiles;
     const int ty = t_in / tile_w, tx = t_in - ty * tile_w;
-    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
-    int lx, ly;
-    pixel_of_thread(tid, lx, ly);
-    const int ix = tx * QED_TILE + lx, iy = ty * QED_TILE + ly;
-    const float px = (float)ix + 0.5f, py = (float)iy + 0.5f;
-    const bool inside = ix < width && iy < height;
+    const int lane = threadIdx.x;
+    const int lx = lane & 7, ly = lane >> 3;
     const float ox = (float)(tx * QED_TILE), oy = (float)(ty * QED_TILE);
+    const float pxs[2] = {ox + (float)lx + 0.5f, ox + (float)lx + 8.5f};
+    const float pys[2] = {oy + (float)ly + 0.5f, oy + (float)ly + 8.5f};
 
     const int start = offsets[tile], end = offsets[tile + 1];
     const int nb = (end - start + kBatch - 1) / kBatch;
 
-    float T = 1.f;
-    float out[CH];
+    float T[4], out[4][CH];
+    int cur[4];
+    bool done[4], inside[4];
+    bool live[4];                                       // wave-uniform: quadrant still has unfinished pixels
 #pragma unroll
-    for (int k = 0; k < CH; ++k) out[k] = 0.f;
-    int cur = 0;
-    bool done = !inside;
+    for (int q = 0; q < 4; ++q) {
+        const int ix = tx * QED_TILE + ((q & 1) << 3) + lx, iy = ty * QED_TILE + ((q >> 1) << 3) + ly;
+        inside[q] = ix < width && iy < height;
+        done[q] = !inside[q];
+        live[q] = !__all(done[q]);
+        T[q] = 1.f;
+        cur[q] = 0;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) out[q][k] = 0.f;
+    }
 
     // prefetch batch 0
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
-    bool present = false;
-    {
-        const int idx = start + tid;
-        present = idx < end;
-        if (present) {
-            const size_t g = (size_t)flatten_ids[idx];
-            r0 = splats[3 * g]; r1 = splats[3 * g + 1]; r2 = splats[3 * g + 2];
-        }
+    bool present = start + lane < end;
+    if (present) {
+        const size_t g = (size_t)flatten_ids[start + lane];
+        r0 = splats[3 * g]; r1 = splats[3 * g + 1]; r2 = splats[3 * g + 2];
     }
     for (int b = 0; b < nb; ++b) {
-        __syncthreads();                               // LDS of the previous batch fully consumed
-        s_q0[tid] = r0; s_q1[tid] = r1; s_q2[tid] = make_float2(r2.x, r2.y);
-        stage_cull_masks(present, r0, r1, r2.z, ox, oy, s_mask, wid, lane);
-        const bool wave_done = __all(done);
-        if (lane == 0) s_done[wid] = wave_done;
+        if (!(live[0] || live[1] || live[2] || live[3])) break;
+        __syncthreads();                               // single wave: orders LDS reuse, costs nothing
+        s_q0[lane] = r0; s_q1[lane] = r1; s_q2[lane] = make_float2(r2.x, r2.y);
+        unsigned long long mq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            mq[q] = __ballot(present && live[q] && quadrant_may_touch(r0, r1, r2.z, ox, oy, q));
         __syncthreads();
-        if (s_done[0] && s_done[1] && s_done[2] && s_done[3]) break;
         // issue the gather of the next batch; it lands while this batch is composited
         if (b + 1 < nb) {
-            const int idx = start + (b + 1) * kBatch + tid;
+            const int idx = start + (b + 1) * kBatch + lane;
             present = idx < end;
             if (present) {
                 const size_t g = (size_t)flatten_ids[idx];
                 r0 = splats[3 * g]; r1 = splats[3 * g + 1]; r2 = splats[3 * g + 2];
             }
         }
-        if (wave_done) continue;
         const int batch_start = start + b * kBatch;
-        bool wave_finished = false;
-#pragma unroll 1
-        for (int sw = 0; sw < 4 && !wave_finished; ++sw) {
-          unsigned long long m = uniform_u64(s_mask[wid][sw]);
-          while (m) {
-            const int t = (sw << 6) + __builtin_ctzll(m);
-            m &= m - 1;
+        unsigned long long many = mq[0] | mq[1] | mq[2] | mq[3];
+        while (many) {
+            const int t = __builtin_ctzll(many);
+            const unsigned long long bit = 1ull << t;
+            many &= ~bit;
             const float4 q0 = s_q0[t];
             const float4 q1 = s_q1[t];
-            const float dx = q0.x - px, dy = q0.y - py;
-            const float sigma = 0.5f * (q0.z * dx * dx + q1.x * dy * dy) + q0.w * dx * dy;
-            const float a = fminf(kAlphaMax, q1.y * __expf(-sigma));
-            const bool ok = !done && sigma >= 0.f && a >= kAlphaMin;
-            if (!__any(ok)) continue;
-            const float nT = T * (1.f - a);
-            const bool term = ok && nT <= kTMin;
-            done = done || term;
-            const bool acc = ok && !term;
-            const float w = acc ? a * T : 0.f;
             const float2 q2 = s_q2[t];
-            out[0] += q1.z * w; out[1] += q1.w * w; out[2] += q2.x * w;
-            if constexpr (CH == 4) out[3] += q2.y * w;
-            T = acc ? nT : T;
-            cur = acc ? batch_start + t : cur;
-            if (__all(done)) { wave_finished = true; break; }
-          }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (mq[q] & bit) {                      // wave-uniform
+                    const float dx = q0.x - pxs[q & 1], dy = q0.y - pys[q >> 1];
+                    const float sigma = 0.5f * (q0.z * dx * dx + q1.x * dy * dy) + q0.w * dx * dy;
+                    const float a = fminf(kAlphaMax, q1.y * __expf(-sigma));
+                    const bool ok = !done[q] && sigma >= 0.f && a >= kAlphaMin;
+                    const float nT = T[q] * (1.f - a);
+                    const bool term = ok && nT <= kTMin;
+                    done[q] = done[q] || term;
+                    const bool acc = ok && !term;
+                    const float w = acc ? a * T[q] : 0.f;
+                    out[q][0] += q1.z * w; out[q][1] += q1.w * w; out[q][2] += q2.x * w;
+                    if constexpr (CH == 4) out[q][3] += q2.y * w;
+                    T[q] = acc ? nT : T[q];
+                    cur[q] = acc ? batch_start + t : cur[q];
+                    if (__all(done[q])) {               // quadrant finished: drop it from the masks
+                        live[q] = false;
+                        mq[q] = 0;
+                        many &= mq[0] | mq[1] | mq[2] | mq[3];
+                    }
+                }
+            }
         }
     }
-    if (inside) {
-        const size_t pix = ((size_t)cam * height + iy) * width + ix;
-        if (backgrounds != nullptr) {
 #pragma unroll
-            for (int k = 0; k < CH; ++k) out[k] += T * backgrounds[cam * CH + k];
+    for (int q = 0; q < 4; ++q) {
+        if (inside[q]) {
+            const int ix = tx * QED_TILE + ((q & 1) << 3) + lx, iy = ty * QED_TILE + ((q >> 1) << 3) + ly;
+            const size_t pix = ((size_t)cam * height + iy) * width + ix;
+            if (backgrounds != nullptr) {
+#pragma unroll
+                for (int k = 0; k < CH; ++k) out[q][k] += T[q] * backgrounds[cam * CH + k];
+            }
+            if constexpr (CH == 4) {
+                *reinterpret_cast<float4*>(render + 4 * pix) = make_float4(out[q][0], out[q][1], out[q][2], out[q][3]);
+            } else {
+                render[3 * pix] = out[q][0]; render[3 * pix + 1] = out[q][1]; render[3 * pix + 2] = out[q][2];
+            }
+            alpha_out[pix] = 1.f - T[q];
+            last_ids[pix] = cur[q];
         }
-        if constexpr (CH == 4) {
-            *reinterpret_cast<float4*>(render + 4 * pix) = make_float4(out[0], out[1], out[2], out[3]);
-        } else {
-            render[3 * pix] = out[0]; render[3 * pix + 1] = out[1]; render[3 * pix + 2] = out[2];
-        }
-        alpha_out[pix] = 1.f - T;
-        last_ids[pix] = cur;
     }
 }
 
@@ -229,8 +228,10 @@ __device__ __forceinline__ void wave_reduce12(const float* v, float* w) {
 
 // vsplat row layout (QED_VSPLAT_FLOATS = 16):
 //  0 v_x  1 v_y  2 |v_x|  3 |v_y|  4 v_conic_a  5 v_conic_b  6 v_conic_c  7 v_opacity  8 v_r  9 v_g  10 v_b  11 v_depth
+// Values 4, 6 and 7 are accumulated un-scaled (sum v_sigma dx^2, sum v_sigma dy^2, sum v_sigma) and
+// scaled by 0.5, 0.5 and -1/opacity once per (tile, Gaussian) at flush time.
 template <int CH>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __restrict__ flatten_ids,
                      const int* __restrict__ offsets, int width, int height, int tile_w, int tile_h,
                      const float* __restrict__ backgrounds, const float* __restrict__ render_alpha,
@@ -241,160 +242,172 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
     __shared__ float2 s_q2[kBatch];
     __shared__ int s_id[kBatch];
     __shared__ float s_acc[kBatch][12];
-    __shared__ int s_touched[kBatch];
-    __shared__ unsigned long long s_mask[4][4];       // [quadrant = consuming wave][staging wave]
-    __shared__ int s_wmax[4];
 
-    const int tile = blockIdx.x;
     const int n_tiles = tile_w * tile_h;
+    const int tile = xcd_remap(blockIdx.x, C * n_tiles);
     const int cam = tile / n_tiles;
     const int t_in = tile - cam * n_tiles;
     const int ty = t_in / tile_w, tx = t_in - ty * tile_w;
-    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
-    int lx, ly;
-    pixel_of_thread(tid, lx, ly);
-    const int ix = tx * QED_TILE + lx, iy = ty * QED_TILE + ly;
-    const float px = (float)ix + 0.5f, py = (float)iy + 0.5f;
-    const bool inside = ix < width && iy < height;
-    const size_t pix = ((size_t)cam * height + (inside ? iy : 0)) * width + (inside ? ix : 0);
+    const int lane = threadIdx.x;
+    const int lx = lane & 7, ly = lane >> 3;
     const float ox = (float)(tx * QED_TILE), oy = (float)(ty * QED_TILE);
+    const float pxs[2] = {ox + (float)lx + 0.5f, ox + (float)lx + 8.5f};
+    const float pys[2] = {oy + (float)ly + 0.5f, oy + (float)ly + 8.5f};
 
     const int start = offsets[tile], end = offsets[tile + 1];
     if (end <= start) return;
 
-    float T_final = 1.f, vra = 0.f;
-    float vr[CH];
+    float T[4], bufv[4], vr[4][CH];
+    int bin_final[4], quad_last[4];
+    int tile_last = -1;
 #pragma unroll
-    for (int k = 0; k < CH; ++k) vr[k] = 0.f;
-    int bin_final = -1;
-    if (inside) {
-        T_final = 1.f - render_alpha[pix];
-        bin_final = last_ids[pix];
-        vra = v_alpha[pix];
-        if constexpr (CH == 4) {
-            const float4 t4 = *reinterpret_cast<const float4*>(v_render + 4 * pix);
-            vr[0] = t4.x; vr[1] = t4.y; vr[2] = t4.z; vr[3] = t4.w;
-        } else {
-            vr[0] = v_render[3 * pix]; vr[1] = v_render[3 * pix + 1]; vr[2] = v_render[3 * pix + 2];
-        }
-        if (backgrounds != nullptr) {
-            // render = sum + T_final * bg  ->  d render / d T_final folds into the alpha gradient
-            float acc = 0.f;
+    for (int q = 0; q < 4; ++q) {
+        const int ix = tx * QED_TILE + ((q & 1) << 3) + lx, iy = ty * QED_TILE + ((q >> 1) << 3) + ly;
+        const bool inside = ix < width && iy < height;
+        float T_final = 1.f, vra = 0.f;
+        bin_final[q] = -1;
 #pragma unroll
-            for (int k = 0; k < CH; ++k) acc += backgrounds[cam * CH + k] * vr[k];
-            vra -= acc;
+        for (int k = 0; k < CH; ++k) vr[q][k] = 0.f;
+        if (inside) {
+            const size_t pix = ((size_t)cam * height + iy) * width + ix;
+            T_final = 1.f - render_alpha[pix];
+            bin_final[q] = last_ids[pix];
+            vra = v_alpha[pix];
+            if constexpr (CH == 4) {
+                const float4 t4 = *reinterpret_cast<const float4*>(v_render + 4 * pix);
+                vr[q][0] = t4.x; vr[q][1] = t4.y; vr[q][2] = t4.z; vr[q][3] = t4.w;
+            } else {
+                vr[q][0] = v_render[3 * pix]; vr[q][1] = v_render[3 * pix + 1]; vr[q][2] = v_render[3 * pix + 2];
+            }
+            if (backgrounds != nullptr) {
+                // render = sum + T_final * bg  ->  d render / d T_final folds into the alpha gradient
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < CH; ++k) acc += backgrounds[cam * CH + k] * vr[q][k];
+                vra -= acc;
+            }
         }
+        T[q] = T_final;
+        // v_alpha = sum_k (c_k T - buf_k / (1-a)) v_k + T_final / (1-a) v_render_alpha is evaluated as
+        // T (c . v) - (buf . v - T_final v_render_alpha) / (1-a): one scalar accumulator per pixel
+        bufv[q] = -T_final * vra;
+        // a pixel that composited nothing has last_id 0 and T_final 1: it only "owns" index 0
+        quad_last[q] = __builtin_amdgcn_readfirstlane(wave_max_i(bin_final[q]));
+        tile_last = max(tile_last, quad_last[q]);
     }
-    // a pixel that composited nothing has last_id 0 and T_final 1: it only "owns" index 0
-    const int wave_last = wave_max_i(bin_final);
-    if (lane == 0) s_wmax[wid] = wave_last;
-    __syncthreads();
-    const int tile_last = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
     const int eff_end = min(end, tile_last + 1);
     if (eff_end <= start) return;
     const int nb = (eff_end - start + kBatch - 1) / kBatch;
-
-    float T = T_final;
-    float buf[CH];
-#pragma unroll
-    for (int k = 0; k < CH; ++k) buf[k] = 0.f;
 
     // batches run back to front; inside a batch slot t holds sorted index (batch_hi - t)
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
     int rid = -1;
     {
-        const int idx = eff_end - 1 - tid;
+        const int idx = eff_end - 1 - lane;
         if (idx >= start) {
             rid = flatten_ids[idx];
             r0 = splats[3 * (size_t)rid]; r1 = splats[3 * (size_t)rid + 1]; r2 = splats[3 * (size_t)rid + 2];
         }
     }
     for (int b = 0; b < nb; ++b) {
-        __syncthreads();                               // previous batch consumed and flushed
-        s_q0[tid] = r0; s_q1[tid] = r1; s_q2[tid] = make_float2(r2.x, r2.y); s_id[tid] = rid;
-#pragma unroll
-        for (int k = 0; k < 12; ++k) s_acc[tid][k] = 0.f;
-        s_touched[tid] = 0;
-        stage_cull_masks(rid >= 0, r0, r1, r2.z, ox, oy, s_mask, wid, lane);
         __syncthreads();
+        s_q0[lane] = r0; s_q1[lane] = r1; s_q2[lane] = make_float2(r2.x, r2.y); s_id[lane] = rid;
         const int batch_hi = eff_end - 1 - b * kBatch;            // sorted index of slot 0
-        const int bn = min(kBatch, batch_hi - start + 1);
+        unsigned long long mq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            mq[q] = __ballot(rid >= 0 && quadrant_may_touch(r0, r1, r2.z, ox, oy, q));
+            // slots whose index is beyond every pixel of the quadrant cannot be valid
+            const int t0 = batch_hi - quad_last[q];
+            if (t0 >= kBatch) mq[q] = 0;
+            else if (t0 > 0) mq[q] &= ~0ull << t0;
+        }
+        __syncthreads();
         if (b + 1 < nb) {
-            const int idx = batch_hi - kBatch - tid;
+            const int idx = batch_hi - kBatch - lane;
             rid = -1;
             if (idx >= start) {
                 rid = flatten_ids[idx];
                 r0 = splats[3 * (size_t)rid]; r1 = splats[3 * (size_t)rid + 1]; r2 = splats[3 * (size_t)rid + 2];
             }
         }
-        // slots whose index is beyond every pixel of this wave can be skipped wholesale
-        const int t0 = max(0, batch_hi - wave_last);
-#pragma unroll 1
-        for (int sw = t0 >> 6; sw < 4; ++sw) {
-          unsigned long long m = uniform_u64(s_mask[wid][sw]);
-          if (sw == (t0 >> 6)) m &= ~0ull << (t0 & 63);
-          while (m) {
-            const int t = (sw << 6) + __builtin_ctzll(m);
-            m &= m - 1;
+        unsigned long long many = mq[0] | mq[1] | mq[2] | mq[3];
+        unsigned long long touched = 0;
+        while (many) {
+            const int t = __builtin_ctzll(many);
+            const unsigned long long bit = 1ull << t;
+            many &= ~bit;
             const int idx = batch_hi - t;
             const float4 q0 = s_q0[t];
             const float4 q1 = s_q1[t];
-            const float dx = q0.x - px, dy = q0.y - py;
-            const float sigma = 0.5f * (q0.z * dx * dx + q1.x * dy * dy) + q0.w * dx * dy;
-            const float vis = __expf(-sigma);
-            const float opv = q1.y * vis;
-            const float a = fminf(kAlphaMax, opv);
-            const bool valid = idx <= bin_final && sigma >= 0.f && a >= kAlphaMin;
-            if (!__any(valid)) continue;
             const float2 q2 = s_q2[t];
+            const float col[4] = {q1.z, q1.w, q2.x, q2.y};
             float g[12];
 #pragma unroll
             for (int k = 0; k < 12; ++k) g[k] = 0.f;
-            if (valid) {
-                const float ra = 1.f / (1.f - a);
-                T *= ra;
-                const float fac = a * T;
-                float col[4] = {q1.z, q1.w, q2.x, q2.y};
-                float v_a = 0.f;
+            bool any_valid = false;
 #pragma unroll
-                for (int k = 0; k < CH; ++k) {
-                    g[8 + k] = fac * vr[k];
-                    v_a += (col[k] * T - buf[k] * ra) * vr[k];
-                    buf[k] += col[k] * fac;
-                }
-                v_a += T_final * ra * vra;
-                if (opv <= kAlphaMax) {
-                    const float v_sigma = -opv * v_a;
-                    g[4] = 0.5f * v_sigma * dx * dx;
-                    g[5] = v_sigma * dx * dy;
-                    g[6] = 0.5f * v_sigma * dy * dy;
-                    g[0] = v_sigma * (q0.z * dx + q0.w * dy);
-                    g[1] = v_sigma * (q0.w * dx + q1.x * dy);
-                    g[2] = fabsf(g[0]);
-                    g[3] = fabsf(g[1]);
-                    g[7] = vis * v_a;
+            for (int q = 0; q < 4; ++q) {
+                if (mq[q] & bit) {                      // wave-uniform
+                    const float dx = q0.x - pxs[q & 1], dy = q0.y - pys[q >> 1];
+                    const float sigma = 0.5f * (q0.z * dx * dx + q1.x * dy * dy) + q0.w * dx * dy;
+                    const float vis = __expf(-sigma);
+                    const float opv = q1.y * vis;
+                    const float a = fminf(kAlphaMax, opv);
+                    const bool valid = idx <= bin_final[q] && sigma >= 0.f && a >= kAlphaMin;
+                    any_valid = any_valid || __any(valid);
+                    if (valid) {
+                        const float ra = 1.f / (1.f - a);
+                        T[q] *= ra;
+                        const float fac = a * T[q];
+                        float cv = 0.f;
+#pragma unroll
+                        for (int k = 0; k < CH; ++k) {
+                            cv += col[k] * vr[q][k];
+                            g[8 + k] += fac * vr[q][k];
+                        }
+                        const float v_a = T[q] * cv - ra * bufv[q];
+                        bufv[q] += fac * cv;
+                        if (opv <= kAlphaMax) {
+                            const float v_sigma = -opv * v_a;
+                            const float sx = v_sigma * dx, sy = v_sigma * dy;
+                            const float gx = q0.z * sx + q0.w * sy, gy = q0.w * sx + q1.x * sy;
+                            g[0] += gx; g[1] += gy;
+                            g[2] += fabsf(gx); g[3] += fabsf(gy);
+                            g[4] += sx * dx; g[5] += sx * dy; g[6] += sy * dy;
+                            g[7] += v_sigma;
+                        }
+                    }
                 }
             }
+            if (!any_valid) continue;
             float w[3];
             wave_reduce12(g, w);
-            // lanes 0,16,32,48 publish: row r holds value (r==0?0 : r==1?2 : r==2?1 : 3) + 4j
+            // lanes 0,16,32,48 park the totals: row r holds value (r==0?0 : r==1?2 : r==2?1 : 3) + 4j
             if ((lane & 15) == 0) {
                 const int r = lane >> 4;
                 const int vbase = ((r & 1) << 1) | (r >> 1);
-                atomicAdd(&s_acc[t][vbase], w[0]);
-                atomicAdd(&s_acc[t][vbase + 4], w[1]);
-                atomicAdd(&s_acc[t][vbase + 8], w[2]);
-                if (lane == 0) s_touched[t] = 1;
+                s_acc[t][vbase] = w[0];
+                s_acc[t][vbase + 4] = w[1];
+                s_acc[t][vbase + 8] = w[2];
             }
-          }
+            touched |= bit;
         }
         __syncthreads();
-        // flush: 16 lanes per Gaussian -> one 64-byte row per atomic request
-        for (int t = tid >> 4; t < bn; t += 16) {
-            if (!s_touched[t]) continue;
-            const int k = tid & 15;
-            if (k < 12) {
-                const float v = s_acc[t][k];
+        // flush: 16 lanes per Gaussian, 4 Gaussians per instruction -> one 64-byte row per request
+        while (touched) {
+            int ts[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ts[j] = touched ? __builtin_ctzll(touched) : -1;
+                touched &= touched - 1;                 // no-op when already zero
+            }
+            const int grp = lane >> 4, k = lane & 15;
+            const int t = grp == 0 ? ts[0] : grp == 1 ? ts[1] : grp == 2 ? ts[2] : ts[3];
+            if (t >= 0 && k < 12) {
+                float v = s_acc[t][k];
+                if (k == 4 || k == 6) v *= 0.5f;
+                if (k == 7) v = -v / s_q1[t].y;
                 if (v != 0.f) atomicAdd(&vsplat[(size_t)s_id[t] * QED_VSPLAT_FLOATS + k], v);
             }
         }
@@ -420,10 +433,10 @@ extern "C" int qed_composite_fwd(int32_t C, int32_t N, const float* splats, cons
     QED_REQUIRE(grid < (1ll << 31), "too many tiles");
     hipStream_t st = (hipStream_t)stream;
     if (channels == 4)
-        hipLaunchKernelGGL(composite_fwd_kernel<4>, dim3((unsigned)grid), dim3(256), 0, st, C, (const float4*)splats,
+        hipLaunchKernelGGL(composite_fwd_kernel<4>, dim3((unsigned)grid), dim3(64), 0, st, C, (const float4*)splats,
                            flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render, alpha, last_ids);
     else
-        hipLaunchKernelGGL(composite_fwd_kernel<3>, dim3((unsigned)grid), dim3(256), 0, st, C, (const float4*)splats,
+        hipLaunchKernelGGL(composite_fwd_kernel<3>, dim3((unsigned)grid), dim3(64), 0, st, C, (const float4*)splats,
                            flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render, alpha, last_ids);
     return check_launch("qed_composite_fwd");
 }
@@ -444,11 +457,11 @@ extern "C" int qed_composite_bwd(int32_t C, int32_t N, const float* splats, cons
     QED_REQUIRE(grid < (1ll << 31), "too many tiles");
     hipStream_t st = (hipStream_t)stream;
     if (channels == 4)
-        hipLaunchKernelGGL(composite_bwd_kernel<4>, dim3((unsigned)grid), dim3(256), 0, st, C, (const float4*)splats,
+        hipLaunchKernelGGL(composite_bwd_kernel<4>, dim3((unsigned)grid), dim3(64), 0, st, C, (const float4*)splats,
                            flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render_alpha, last_ids,
                            v_render, v_alpha, vsplat);
     else
-        hipLaunchKernelGGL(composite_bwd_kernel<3>, dim3((unsigned)grid), dim3(256), 0, st, C, (const float4*)splats,
+        hipLaunchKernelGGL(composite_bwd_kernel<3>, dim3((unsigned)grid), dim3(64), 0, st, C, (const float4*)splats,
                            flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render_alpha, last_ids,
                            v_render, v_alpha, vsplat);
     return check_launch("qed_composite_bwd");
