@@ -7,24 +7,32 @@
 //     in each of the tile's four 8x8 quadrants.  A workgroup is a single wave, so the kernel is
 //     wave-synchronous: no workgroup barriers, no inter-wave imbalance, early-out per tile.
 //   * The tile's run of the depth-sorted list is streamed in batches of 64: every lane gathers one
-//     48-byte splat record (three 16-byte loads) for the NEXT batch into registers while the
-//     current batch, staged in LDS, is consumed.  One broadcast LDS read of a record now feeds 256
-//     pixel evaluations (4 per lane) instead of 64, which takes the LDS pipe off the critical path,
-//     and the four independent pixel chains per lane give the VALU instruction-level parallelism.
-//   * Exact-conservative quadrant culling: at staging time each lane bounds, for each quadrant, the
-//     minimum of its Gaussian's quadratic form over the quadrant's pixel-centre rectangle; 64-bit
-//     ballots turn that into four scalar bit masks, and the consuming loop walks set bits with
-//     scalar instructions.  A culled (Gaussian, quadrant) pair is one whose 64 pixels would all
-//     have failed the alpha >= 1/255 test, so results are identical to the unculled loop.
-//   * Backward: the per-pixel gradients of one Gaussian are first summed over the lane's four
-//     pixels, then reduced over the 64 lanes with v_permlane32_swap / v_permlane16_swap (the
-//     number of live values halves per level) + one DPP row reduction, parked in LDS and flushed
-//     with ONE 64-byte-row atomic request per (tile, Gaussian) that actually contributed.
+//     48-byte splat record (three 16-byte loads) for the NEXT batch while the current batch is
+//     consumed.  Records never go through LDS: the current Gaussian's ten scalars are broadcast
+//     with v_readlane into SGPRs and enter the VALU as scalar operands.
+//   * Exact-conservative cull by ballot: each lane bounds the minimum of its Gaussian's quadratic
+//     form sigma over the tile's pixel-centre rectangle (convex: 0 if the mean is inside, else
+//     attained on an edge).  alpha >= 1/255 needs sigma <= ln(255 o), so a Gaussian whose bound
+//     exceeds that (plus an fp32 rounding margin) cannot pass the alpha test at any pixel of the
+//     tile.  A 64-bit ballot gives the survivors; the loop walks its set bits front to back with
+//     scalar instructions.  Results are identical to walking the whole list, but typically more
+//     than half of the 3-sigma-bounding-box list entries never reach the inner loop.
+//   * The inner loop is branch-free: 4 independent pixel chains per lane; every predicate ("done",
+//     "accepted", "valid") is a 64-bit scalar mask fed straight to v_cndmask.  The conic is
+//     pre-scaled by -log2(e) at staging so the exponent is a bare v_exp_f32 of a 5-instruction
+//     polynomial.
+//   * Backward: the per-pixel gradients of one Gaussian are summed over the lane's four pixels,
+//     reduced over the 64 lanes with v_permlane32_swap / v_permlane16_swap (the number of live
+//     values halves per level) + one DPP row reduction, parked in LDS and flushed with ONE
+//     64-byte-row atomic request per (tile, Gaussian) that actually contributed.
 #include "qed_common.h"
 
 namespace qed {
 
+typedef unsigned long long u64;
+
 constexpr int kBatch = 64;
+constexpr float kLog2e = 1.4426950408889634f;
 
 // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
 // contiguous range of tiles (whole image rows): neighbouring tiles share splat records in one L2.
@@ -33,11 +41,23 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
-// ---- exact-conservative quadrant culling ---------------------------------------------------------
-// alpha = min(.999, o e^-sigma) >= 1/255  <=>  sigma <= tau = ln(255 o).  sigma is a convex quadratic
-// form: its minimum over the quadrant's pixel-centre rectangle is 0 if the mean lies inside,
-// otherwise it is attained on one of the four edges.  The margin covers fp32 rounding of this
-// bound and of the per-pixel evaluation.
+// per-lane select by a wave-uniform 64-bit mask held in an SGPR pair: bit set -> a, else b
+__device__ __forceinline__ float sel(u64 m, float a, float b) {
+    float d;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(a), "s"(m));
+    return d;
+}
+__device__ __forceinline__ int sel(u64 m, int a, int b) {
+    int d;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(a), "s"(m));
+    return d;
+}
+// broadcast lane `t` (wave-uniform) of v into an SGPR
+__device__ __forceinline__ float bcast(float v, int t) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), t));
+}
+
+// ---- exact-conservative tile culling ---------------------------------------------------------------
 __device__ __forceinline__ float rect_min_sigma(float a, float b, float c, float x0, float x1, float y0, float y1,
                                                 float& scale) {
     const float ax = fmaxf(fabsf(x0), fabsf(x1)), ay = fmaxf(fabsf(y0), fabsf(y1));
@@ -64,6 +84,17 @@ __device__ __forceinline__ float rect_min_sigma(float a, float b, float c, float
     return m;
 }
 
+// Can the Gaussian (record r0 = {x,y,ca,cb}, r1.x = cc, tau = ln(255 o)) reach alpha >= 1/255 at any
+// pixel centre of the tile whose pixel origin is (ox, oy)?  The margin covers fp32 rounding of this
+// bound and of the per-pixel evaluation, so "false" implies every pixel would have skipped it.
+__device__ __forceinline__ bool tile_may_touch(const float4& r0, const float4& r1, float tau, float ox, float oy) {
+    const float x0 = ox + 0.5f - r0.x, x1 = x0 + 15.f;
+    const float y0 = oy + 0.5f - r0.y, y1 = y0 + 15.f;
+    float scale;
+    const float smin = rect_min_sigma(r0.z, r0.w, r1.x, x0, x1, y0, y1, scale);
+    return !(smin > tau + 1e-3f + 8e-6f * scale);
+}
+// the same for one 8x8 quadrant (q & 1 = right half, q >> 1 = lower half)
 __device__ __forceinline__ bool quadrant_may_touch(const float4& r0, const float4& r1, float tau, float ox, float oy,
                                                    int q) {
     const float x0 = ox + (float)((q & 1) << 3) + 0.5f - r0.x, x1 = x0 + 7.f;
@@ -71,6 +102,18 @@ __device__ __forceinline__ bool quadrant_may_touch(const float4& r0, const float
     float scale;
     const float smin = rect_min_sigma(r0.z, r0.w, r1.x, x0, x1, y0, y1, scale);
     return !(smin > tau + 1e-3f + 8e-6f * scale);
+}
+// four per-quadrant survivor masks of the 64 staged Gaussians (one per lane)
+__device__ __forceinline__ void quadrant_masks(bool present, const float4& r0, const float4& r1, float tau, float ox,
+                                               float oy, u64* mq) {
+    const bool tile_keep = present && tile_may_touch(r0, r1, tau, ox, oy);
+    bool k[4] = {false, false, false, false};
+    if (tile_keep) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) k[q] = quadrant_may_touch(r0, r1, tau, ox, oy, q);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mq[q] = __ballot(k[q]);
 }
 
 // ================================================================================================
@@ -82,10 +125,6 @@ composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
                      const int* __restrict__ offsets, int width, int height, int tile_w, int tile_h,
                      const float* __restrict__ backgrounds, float* __restrict__ render, float* __restrict__ alpha_out,
                      int* __restrict__ last_ids) {
-    __shared__ float4 s_q0[kBatch];   // x, y, conic_a, conic_b
-    __shared__ float4 s_q1[kBatch];   // conic_c, opacity, r, g
-    __shared__ float2 s_q2[kBatch];   // b, depth
-
     const int n_tiles = tile_w * tile_h;
     const int tile = xcd_remap(blockIdx.x, C * n_tiles);   // cam * T + ty * tile_w + tx
     const int cam = tile / n_tiles;
@@ -102,14 +141,13 @@ composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
 
     float T[4], out[4][CH];
     int cur[4];
-    bool done[4], inside[4];
-    bool live[4];                                       // wave-uniform: quadrant still has unfinished pixels
+    u64 done[4];                                        // wave-uniform masks
+    bool inside[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int ix = tx * QED_TILE + ((q & 1) << 3) + lx, iy = ty * QED_TILE + ((q >> 1) << 3) + ly;
         inside[q] = ix < width && iy < height;
-        done[q] = !inside[q];
-        live[q] = !__all(done[q]);
+        done[q] = __ballot(!inside[q]);
         T[q] = 1.f;
         cur[q] = 0;
 #pragma unroll
@@ -123,15 +161,18 @@ composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
         const size_t g = (size_t)flatten_ids[start + lane];
         r0 = splats[3 * g]; r1 = splats[3 * g + 1]; r2 = splats[3 * g + 2];
     }
-    for (int b = 0; b < nb; ++b) {
-        if (!(live[0] || live[1] || live[2] || live[3])) break;
-        __syncthreads();                               // single wave: orders LDS reuse, costs nothing
-        s_q0[lane] = r0; s_q1[lane] = r1; s_q2[lane] = make_float2(r2.x, r2.y);
-        unsigned long long mq[4];
+    bool all_done = (done[0] & done[1] & done[2] & done[3]) == ~0ull;
+    for (int b = 0; b < nb && !all_done; ++b) {
+        // ---- stage this lane's Gaussian: cull, pre-scale the conic by -log2(e) ----
+        u64 mq[4];
+        quadrant_masks(present, r0, r1, r2.z, ox, oy, mq);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            mq[q] = __ballot(present && live[q] && quadrant_may_touch(r0, r1, r2.z, ox, oy, q));
-        __syncthreads();
+            if (done[q] == ~0ull) mq[q] = 0;            // finished quadrant
+        u64 km = mq[0] | mq[1] | mq[2] | mq[3];
+        const float gx = r0.x, gy = r0.y;
+        const float gA = -0.5f * kLog2e * r0.z, gB = -kLog2e * r0.w, gC = -0.5f * kLog2e * r1.x;
+        const float gop = r1.y, gr = r1.z, gg = r1.w, gb = r2.x, gd = r2.y;
         // issue the gather of the next batch; it lands while this batch is composited
         if (b + 1 < nb) {
             const int idx = start + (b + 1) * kBatch + lane;
@@ -142,36 +183,40 @@ composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
             }
         }
         const int batch_start = start + b * kBatch;
-        unsigned long long many = mq[0] | mq[1] | mq[2] | mq[3];
-        while (many) {
-            const int t = __builtin_ctzll(many);
-            const unsigned long long bit = 1ull << t;
-            many &= ~bit;
-            const float4 q0 = s_q0[t];
-            const float4 q1 = s_q1[t];
-            const float2 q2 = s_q2[t];
+        while (km) {
+            const int t = __builtin_ctzll(km);
+            const u64 bit = 1ull << t;
+            km &= ~bit;
+            // broadcast Gaussian t: ten v_readlane -> SGPRs
+            const float X = bcast(gx, t), Y = bcast(gy, t), A = bcast(gA, t), B = bcast(gB, t), Cc = bcast(gC, t);
+            const float op = bcast(gop, t);
+            float col[4] = {bcast(gr, t), bcast(gg, t), bcast(gb, t), 0.f};
+            if constexpr (CH == 4) col[3] = bcast(gd, t);
+            const int idx_v = batch_start + t;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (mq[q] & bit) {                      // wave-uniform
-                    const float dx = q0.x - pxs[q & 1], dy = q0.y - pys[q >> 1];
-                    const float sigma = 0.5f * (q0.z * dx * dx + q1.x * dy * dy) + q0.w * dx * dy;
-                    const float a = fminf(kAlphaMax, q1.y * __expf(-sigma));
-                    const bool ok = !done[q] && sigma >= 0.f && a >= kAlphaMin;
-                    const float nT = T[q] * (1.f - a);
-                    const bool term = ok && nT <= kTMin;
-                    done[q] = done[q] || term;
-                    const bool acc = ok && !term;
-                    const float w = acc ? a * T[q] : 0.f;
-                    out[q][0] += q1.z * w; out[q][1] += q1.w * w; out[q][2] += q2.x * w;
-                    if constexpr (CH == 4) out[q][3] += q2.y * w;
-                    T[q] = acc ? nT : T[q];
-                    cur[q] = acc ? batch_start + t : cur[q];
-                    if (__all(done[q])) {               // quadrant finished: drop it from the masks
-                        live[q] = false;
-                        mq[q] = 0;
-                        many &= mq[0] | mq[1] | mq[2] | mq[3];
-                    }
+                if (!(mq[q] & bit)) continue;           // wave-uniform: this quadrant cannot see Gaussian t
+                const float dx = X - pxs[q & 1], dy = Y - pys[q >> 1];
+                const float p = dx * (A * dx + B * dy) + (Cc * dy) * dy;        // -sigma log2(e)
+                const float a = fminf(kAlphaMax, op * __builtin_amdgcn_exp2f(p));
+                const u64 m_ok = __ballot(p <= 0.f) & __ballot(a >= kAlphaMin) & ~done[q];
+                const float nT = T[q] - T[q] * a;
+                const u64 m_term = m_ok & __ballot(nT <= kTMin);
+                done[q] |= m_term;
+                const u64 m_acc = m_ok & ~m_term;
+                const float w = sel(m_acc, a * T[q], 0.f);
+#pragma unroll
+                for (int k = 0; k < CH; ++k) out[q][k] += col[k] * w;
+                T[q] = sel(m_acc, nT, T[q]);
+                cur[q] = sel(m_acc, idx_v, cur[q]);
+                if (done[q] == ~0ull) {                 // quadrant finished: drop it from the masks
+                    mq[q] = 0;
+                    km &= mq[0] | mq[1] | mq[2] | mq[3];
                 }
+            }
+            if ((done[0] & done[1] & done[2] & done[3]) == ~0ull) {
+                all_done = true;
+                break;
             }
         }
     }
@@ -237,10 +282,6 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
                      const float* __restrict__ backgrounds, const float* __restrict__ render_alpha,
                      const int* __restrict__ last_ids, const float* __restrict__ v_render,
                      const float* __restrict__ v_alpha, float* __restrict__ vsplat) {
-    __shared__ float4 s_q0[kBatch];
-    __shared__ float4 s_q1[kBatch];
-    __shared__ float2 s_q2[kBatch];
-    __shared__ int s_id[kBatch];
     __shared__ float s_acc[kBatch][12];
 
     const int n_tiles = tile_w * tile_h;
@@ -299,7 +340,7 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
     if (eff_end <= start) return;
     const int nb = (eff_end - start + kBatch - 1) / kBatch;
 
-    // batches run back to front; inside a batch slot t holds sorted index (batch_hi - t)
+    // batches run back to front; lane l of batch b gathers sorted index (eff_end - 1 - 64 b - l)
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
     int rid = -1;
     {
@@ -310,19 +351,20 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
         }
     }
     for (int b = 0; b < nb; ++b) {
-        __syncthreads();
-        s_q0[lane] = r0; s_q1[lane] = r1; s_q2[lane] = make_float2(r2.x, r2.y); s_id[lane] = rid;
-        const int batch_hi = eff_end - 1 - b * kBatch;            // sorted index of slot 0
-        unsigned long long mq[4];
+        const int batch_hi = eff_end - 1 - b * kBatch;            // sorted index gathered by lane 0
+        u64 mq[4];
+        quadrant_masks(rid >= 0, r0, r1, r2.z, ox, oy, mq);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            mq[q] = __ballot(rid >= 0 && quadrant_may_touch(r0, r1, r2.z, ox, oy, q));
-            // slots whose index is beyond every pixel of the quadrant cannot be valid
+            // lane t holds sorted index batch_hi - t: beyond every pixel of the quadrant -> cannot be valid
             const int t0 = batch_hi - quad_last[q];
             if (t0 >= kBatch) mq[q] = 0;
             else if (t0 > 0) mq[q] &= ~0ull << t0;
         }
-        __syncthreads();
+        u64 km = mq[0] | mq[1] | mq[2] | mq[3];
+        const float gx = r0.x, gy = r0.y, gca = r0.z, gcb = r0.w, gcc = r1.x;
+        const float gop = r1.y, gr = r1.z, gg = r1.w, gb = r2.x, gd = r2.y;
+        const int gid = rid;
         if (b + 1 < nb) {
             const int idx = batch_hi - kBatch - lane;
             rid = -1;
@@ -331,56 +373,54 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
                 r0 = splats[3 * (size_t)rid]; r1 = splats[3 * (size_t)rid + 1]; r2 = splats[3 * (size_t)rid + 2];
             }
         }
-        unsigned long long many = mq[0] | mq[1] | mq[2] | mq[3];
-        unsigned long long touched = 0;
-        while (many) {
-            const int t = __builtin_ctzll(many);
-            const unsigned long long bit = 1ull << t;
-            many &= ~bit;
+        u64 touched = 0;
+        while (km) {
+            const int t = __builtin_ctzll(km);
+            const u64 bit = 1ull << t;
+            km &= ~bit;
+            const float X = bcast(gx, t), Y = bcast(gy, t);
+            const float ca = bcast(gca, t), cb = bcast(gcb, t), cc = bcast(gcc, t), op = bcast(gop, t);
+            const float A = -0.5f * kLog2e * ca, B = -kLog2e * cb, Cc = -0.5f * kLog2e * cc;
+            float col[4] = {bcast(gr, t), bcast(gg, t), bcast(gb, t), 0.f};
+            if constexpr (CH == 4) col[3] = bcast(gd, t);
             const int idx = batch_hi - t;
-            const float4 q0 = s_q0[t];
-            const float4 q1 = s_q1[t];
-            const float2 q2 = s_q2[t];
-            const float col[4] = {q1.z, q1.w, q2.x, q2.y};
             float g[12];
 #pragma unroll
             for (int k = 0; k < 12; ++k) g[k] = 0.f;
-            bool any_valid = false;
+            u64 any_valid = 0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (mq[q] & bit) {                      // wave-uniform
-                    const float dx = q0.x - pxs[q & 1], dy = q0.y - pys[q >> 1];
-                    const float sigma = 0.5f * (q0.z * dx * dx + q1.x * dy * dy) + q0.w * dx * dy;
-                    const float vis = __expf(-sigma);
-                    const float opv = q1.y * vis;
-                    const float a = fminf(kAlphaMax, opv);
-                    const bool valid = idx <= bin_final[q] && sigma >= 0.f && a >= kAlphaMin;
-                    any_valid = any_valid || __any(valid);
-                    if (valid) {
-                        const float ra = 1.f / (1.f - a);
-                        T[q] *= ra;
-                        const float fac = a * T[q];
-                        float cv = 0.f;
+                if (!(mq[q] & bit)) continue;           // wave-uniform: this quadrant cannot see Gaussian t
+                const float dx = X - pxs[q & 1], dy = Y - pys[q >> 1];
+                const float p = dx * (A * dx + B * dy) + (Cc * dy) * dy;        // -sigma log2(e)
+                const float vis = __builtin_amdgcn_exp2f(p);
+                const float opv = op * vis;
+                const float a = fminf(kAlphaMax, opv);
+                const u64 m_valid = __ballot(bin_final[q] >= idx) & __ballot(p <= 0.f) & __ballot(a >= kAlphaMin);
+                any_valid |= m_valid;
+                // branch-free: an invalid pixel contributes zeros and keeps its state
+                const float ra = __builtin_amdgcn_rcpf(1.f - a);
+                const float Tn = sel(m_valid, T[q] * ra, T[q]);
+                T[q] = Tn;
+                const float fac = sel(m_valid, a * Tn, 0.f);
+                float cv = 0.f;
 #pragma unroll
-                        for (int k = 0; k < CH; ++k) {
-                            cv += col[k] * vr[q][k];
-                            g[8 + k] += fac * vr[q][k];
-                        }
-                        const float v_a = T[q] * cv - ra * bufv[q];
-                        bufv[q] += fac * cv;
-                        if (opv <= kAlphaMax) {
-                            const float v_sigma = -opv * v_a;
-                            const float sx = v_sigma * dx, sy = v_sigma * dy;
-                            const float gx = q0.z * sx + q0.w * sy, gy = q0.w * sx + q1.x * sy;
-                            g[0] += gx; g[1] += gy;
-                            g[2] += fabsf(gx); g[3] += fabsf(gy);
-                            g[4] += sx * dx; g[5] += sx * dy; g[6] += sy * dy;
-                            g[7] += v_sigma;
-                        }
-                    }
+                for (int k = 0; k < CH; ++k) {
+                    cv += col[k] * vr[q][k];
+                    g[8 + k] += fac * vr[q][k];
                 }
+                const float v_a = Tn * cv - ra * bufv[q];
+                bufv[q] += fac * cv;
+                const u64 m_vs = m_valid & __ballot(opv <= kAlphaMax);
+                const float v_sigma = sel(m_vs, -opv * v_a, 0.f);
+                const float sx = v_sigma * dx, sy = v_sigma * dy;
+                const float vx = ca * sx + cb * sy, vy = cb * sx + cc * sy;
+                g[0] += vx; g[1] += vy;
+                g[2] += fabsf(vx); g[3] += fabsf(vy);
+                g[4] += sx * dx; g[5] += sx * dy; g[6] += sy * dy;
+                g[7] += v_sigma;
             }
-            if (!any_valid) continue;
+            if (any_valid == 0) continue;
             float w[3];
             wave_reduce12(g, w);
             // lanes 0,16,32,48 park the totals: row r holds value (r==0?0 : r==1?2 : r==2?1 : 3) + 4j
@@ -391,9 +431,9 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
                 s_acc[t][vbase + 4] = w[1];
                 s_acc[t][vbase + 8] = w[2];
             }
-            touched |= bit;
+            touched |= 1ull << t;
         }
-        __syncthreads();
+        __syncthreads();                                // single wave: orders the LDS parking vs the flush
         // flush: 16 lanes per Gaussian, 4 Gaussians per instruction -> one 64-byte row per request
         while (touched) {
             int ts[4];
@@ -404,13 +444,17 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
             }
             const int grp = lane >> 4, k = lane & 15;
             const int t = grp == 0 ? ts[0] : grp == 1 ? ts[1] : grp == 2 ? ts[2] : ts[3];
+            // all lanes take part in the shuffles (the source lane must be active)
+            const int id = __shfl(gid, max(t, 0), 64);
+            const float opac = __shfl(gop, max(t, 0), 64);
             if (t >= 0 && k < 12) {
                 float v = s_acc[t][k];
                 if (k == 4 || k == 6) v *= 0.5f;
-                if (k == 7) v = -v / s_q1[t].y;
-                if (v != 0.f) atomicAdd(&vsplat[(size_t)s_id[t] * QED_VSPLAT_FLOATS + k], v);
+                if (k == 7) v = -v / opac;
+                if (v != 0.f) atomicAdd(&vsplat[(size_t)id * QED_VSPLAT_FLOATS + k], v);
             }
         }
+        __syncthreads();
     }
 }
 
