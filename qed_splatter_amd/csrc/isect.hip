@@ -50,22 +50,30 @@ isect_scan_kernel(const int* __restrict__ block_sums, int n_blocks, int* __restr
 // One wave owns 64 consecutive (camera,Gaussian) slots and writes their intersections
 // cooperatively: output slot j of the wave's range belongs to the Gaussian found by binary search
 // over the wave's prefix sums, so consecutive lanes write consecutive addresses.
+// KeyT = u64: key = (cam|tile) << 32 | depth bits (one-stage sort).  KeyT = u32: key = cam|tile only;
+// then `order` lists the slots in depth order, so emission order already carries the depth order
+// (two-stage binning, qed_bin_tiles).
+template <typename KeyT>
 __global__ void __launch_bounds__(256)
 isect_emit_kernel(int N, int C, const float* __restrict__ means2d, const int* __restrict__ radii,
                   const float* __restrict__ depths, const int* __restrict__ tiles_per_gauss,
                   const int* __restrict__ block_offsets, int tile_w, int tile_h, int tile_bits,
-                  const int* __restrict__ n_isect, unsigned long long* __restrict__ keys, int* __restrict__ vals) {
+                  const int* __restrict__ n_isect, const int* __restrict__ order, KeyT* __restrict__ keys,
+                  int* __restrict__ vals) {
     __shared__ int s_pref[4][65];   // per wave: exclusive prefix of counts (+ total)
     __shared__ int s_x0[4][64], s_y0[4][64], s_w[4][64];
     __shared__ unsigned s_depth[4][64];
+    __shared__ int s_slot[4][64];
     __shared__ int s_wave_tot[4];
     if (n_isect[0] == 0) return;    // nothing to do (or capacity exceeded)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const long long total = (long long)C * N;
-    const long long slot = (long long)blockIdx.x * 256 + tid;
+    const long long pos = (long long)blockIdx.x * 256 + tid;
+    long long slot = pos;
+    if (order != nullptr && pos < total) slot = order[pos];
     int cnt = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0;
     unsigned dbits = 0;
-    if (slot < total) {
+    if (pos < total) {
         cnt = tiles_per_gauss[slot];
         if (cnt > 0) {
             tile_rect(means2d[2 * slot], means2d[2 * slot + 1], (float)radii[slot], tile_w, tile_h, x0, y0, x1, y1);
@@ -82,11 +90,11 @@ isect_emit_kernel(int N, int C, const float* __restrict__ means2d, const int* __
     s_pref[wid][lane] = x - cnt;
     if (lane == 63) { s_pref[wid][64] = x; s_wave_tot[wid] = x; }
     s_x0[wid][lane] = x0; s_y0[wid][lane] = y0; s_w[wid][lane] = x1 - x0; s_depth[wid][lane] = dbits;
+    s_slot[wid][lane] = (int)slot;
     __syncthreads();
     int wave_base = block_offsets[blockIdx.x];
     for (int w = 0; w < wid; ++w) wave_base += s_wave_tot[w];
     const int wtot = s_pref[wid][64];
-    const long long slot0 = (long long)blockIdx.x * 256 + wid * 64;
     for (int j = lane; j < wtot; j += 64) {
         // largest g with pref[g] <= j
         int lo = 0, hi = 63;
@@ -100,17 +108,20 @@ isect_emit_kernel(int N, int C, const float* __restrict__ means2d, const int* __
         const int w = s_w[wid][g];
         const int ty = s_y0[wid][g] + local / w;
         const int tx = s_x0[wid][g] + local % w;
-        const long long sl = slot0 + g;
+        const int sl = s_slot[wid][g];
         const unsigned long long cam = (unsigned long long)(sl / N);
         const unsigned long long tile = (unsigned long long)(ty * tile_w + tx);
-        keys[wave_base + j] = (((cam << tile_bits) | tile) << 32) | (unsigned long long)s_depth[wid][g];
-        vals[wave_base + j] = (int)sl;
+        const unsigned long long ct = (cam << tile_bits) | tile;
+        if constexpr (sizeof(KeyT) == 8) keys[wave_base + j] = (KeyT)((ct << 32) | (unsigned long long)s_depth[wid][g]);
+        else keys[wave_base + j] = (KeyT)ct;
+        vals[wave_base + j] = sl;
     }
 }
 
 // ---- tile offsets ------------------------------------------------------------------------------
+template <typename KeyT>
 __global__ void __launch_bounds__(256)
-tile_offsets_kernel(const unsigned long long* __restrict__ keys, const int* __restrict__ n_dev, int n_tiles_total,
+tile_offsets_kernel(const KeyT* __restrict__ keys, const int* __restrict__ n_dev, int n_tiles_total,
                     int n_tiles, int tile_bits, int* __restrict__ offsets) {
     const int n = n_dev[0];
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -119,8 +130,8 @@ tile_offsets_kernel(const unsigned long long* __restrict__ keys, const int* __re
         return;
     }
     if (i >= n) return;
-    auto lin = [&](unsigned long long k) -> int {
-        const unsigned long long ct = k >> 32;
+    auto lin = [&](KeyT k) -> int {
+        const unsigned long long ct = sizeof(KeyT) == 8 ? ((unsigned long long)k >> 32) : (unsigned long long)k;
         return (int)((ct >> tile_bits) * (unsigned long long)n_tiles + (ct & ((1ull << tile_bits) - 1ull)));
     };
     const int cur = lin(keys[i]);
@@ -135,9 +146,145 @@ tile_offsets_kernel(const unsigned long long* __restrict__ keys, const int* __re
     }
 }
 
+// ---- two-stage binning helpers (qed_bin_tiles) ----------------------------------------------------
+// stage A input: key = depth bits of visible slots (0xFFFFFFFF sorts culled slots last), value = slot
+__global__ void __launch_bounds__(256)
+depth_keys_kernel(int n_slots, const int* __restrict__ radii, const float* __restrict__ depths,
+                  unsigned* __restrict__ keys, int* __restrict__ vals, int* __restrict__ n_slots_dev) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) n_slots_dev[0] = n_slots;
+    if (i < n_slots) {
+        keys[i] = radii[i] > 0 ? __float_as_uint(depths[i]) : 0xFFFFFFFFu;
+        vals[i] = i;
+    }
+}
+
+// tile counts of the depth-ordered slots, summed per 256 (input of the intersection scan)
+__global__ void __launch_bounds__(256)
+count_sorted_kernel(int n_slots, const int* __restrict__ order, const int* __restrict__ tiles_per_gauss,
+                    int* __restrict__ block_sums) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int v = i < n_slots ? tiles_per_gauss[order[i]] : 0;
+    __shared__ int wsum[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// gsplat-style 64-bit keys of the sorted list (info["isect_ids"]), rebuilt on demand
+__global__ void __launch_bounds__(256)
+isect_ids_kernel(const unsigned* __restrict__ tile_keys, const int* __restrict__ flatten_ids,
+                 const float* __restrict__ depths, const int* __restrict__ n_dev, unsigned long long* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_dev[0])
+        out[i] = ((unsigned long long)tile_keys[i] << 32) | (unsigned long long)__float_as_uint(depths[flatten_ids[i]]);
+}
+
 }  // namespace qed
 
 using namespace qed;
+
+static long long align256(long long x) { return (x + 255) & ~255ll; }
+
+struct BinLayout {
+    long long n_slots_dev, keysA0, keysA1, valsA0, valsA1, block_sums, block_offsets, keysB0, keysB1, valsB, sort_ws,
+        total;
+    long long sort_ws_bytes;
+};
+
+static BinLayout bin_layout(long long S, long long cap) {
+    BinLayout L;
+    long long o = 0;
+    const long long nblk = (S + 255) / 256 + 1;
+    L.n_slots_dev = o; o += 256;
+    L.keysA0 = o; o += align256(4 * S);
+    L.keysA1 = o; o += align256(4 * S);
+    L.valsA0 = o; o += align256(4 * S);
+    L.valsA1 = o; o += align256(4 * S);
+    L.block_sums = o; o += align256(4 * nblk);
+    L.block_offsets = o; o += align256(4 * nblk);
+    L.keysB0 = o; o += align256(4 * cap);
+    L.keysB1 = o; o += align256(4 * cap);
+    L.valsB = o; o += align256(4 * cap);
+    L.sort_ws_bytes = sort32_workspace_bytes(S > cap ? S : cap);
+    L.sort_ws = o; o += align256(L.sort_ws_bytes);
+    L.total = o;
+    return L;
+}
+
+extern "C" int64_t qed_bin_workspace_bytes(int64_t n_slots, int64_t capacity) {
+    if (n_slots < 0 || capacity < 0) return QED_E_INVALID_ARG;
+    return bin_layout(n_slots, capacity).total;
+}
+
+extern "C" int qed_bin_tiles(int32_t N, int32_t C, const float* means2d, const int32_t* radii, const float* depths,
+                             const int32_t* tiles_per_gauss, int32_t tile_w, int32_t tile_h, int64_t capacity,
+                             int32_t* flatten_ids, int32_t* offsets, int32_t* n_isect, uint64_t* isect_ids,
+                             void* workspace, int64_t workspace_bytes, int32_t* status, void* stream) {
+    QED_REQUIRE(N >= 0 && C >= 1 && tile_w > 0 && tile_h > 0, "bad extents");
+    QED_REQUIRE(capacity >= 0 && capacity < (1ll << 31), "capacity out of range");
+    QED_REQUIRE(offsets && n_isect && status && workspace, "null buffers");
+    const long long S = (long long)C * N;
+    QED_REQUIRE(S < (1ll << 31), "too many (camera, Gaussian) slots");
+    const long long n_tot = (long long)C * tile_w * tile_h;
+    int tile_bits = 1;
+    while ((1ll << tile_bits) <= (long long)tile_w * tile_h) ++tile_bits;      // floor(log2 T) + 1
+    int cam_bits = 0;
+    while ((1 << cam_bits) < C) ++cam_bits;
+    QED_REQUIRE(tile_bits + cam_bits <= 32, "camera/tile key does not fit 32 bits");
+    const BinLayout L = bin_layout(S, capacity);
+    if (workspace_bytes < L.total) {
+        set_error("qed_bin_tiles: workspace too small (%lld < %lld)", (long long)workspace_bytes, L.total);
+        return QED_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    char* w = (char*)workspace;
+    int* n_slots_dev = (int*)(w + L.n_slots_dev);
+    unsigned* kA0 = (unsigned*)(w + L.keysA0); unsigned* kA1 = (unsigned*)(w + L.keysA1);
+    int* vA0 = (int*)(w + L.valsA0); int* vA1 = (int*)(w + L.valsA1);
+    int* block_sums = (int*)(w + L.block_sums); int* block_offsets = (int*)(w + L.block_offsets);
+    unsigned* kB0 = (unsigned*)(w + L.keysB0); unsigned* kB1 = (unsigned*)(w + L.keysB1);
+    int* vB = (int*)(w + L.valsB);
+    void* sort_ws = w + L.sort_ws;
+    if (S == 0 || capacity == 0) {
+        hipError_t e = hipMemsetAsync(offsets, 0, (size_t)(n_tot + 1) * 4, st);
+        if (e == hipSuccess) e = hipMemsetAsync(n_isect, 0, 4, st);
+        if (e != hipSuccess) { set_error("qed_bin_tiles: memset failed"); return QED_E_LAUNCH; }
+        return QED_OK;
+    }
+    QED_REQUIRE(means2d && radii && depths && tiles_per_gauss && flatten_ids, "null buffers");
+    const unsigned gridS = (unsigned)((S + 255) / 256);
+    // stage A: (camera, Gaussian) slots into depth order
+    hipLaunchKernelGGL(depth_keys_kernel, dim3(gridS), dim3(256), 0, st, (int)S, radii, depths, kA0, vA0, n_slots_dev);
+    int which = sort_pairs_u32(kA0, vA0, kA1, vA1, n_slots_dev, S, 32, sort_ws, L.sort_ws_bytes, st);
+    if (which < 0) return which;
+    const int* order = which ? vA1 : vA0;
+    // intersection counts in depth order -> offsets, M
+    hipLaunchKernelGGL(count_sorted_kernel, dim3(gridS), dim3(256), 0, st, (int)S, order, tiles_per_gauss, block_sums);
+    hipLaunchKernelGGL(isect_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)block_sums, (int)gridS, block_offsets,
+                       n_isect, (long long)capacity, status);
+    // stage B: emit (cam|tile, slot) in depth order, then a STABLE sort on the tile bits only.  The pass
+    // count decides which buffer to emit into so that the sorted values land in `flatten_ids`.
+    const int end_bit = tile_bits + cam_bits;
+    const int passes = (end_bit + 7) / 8;
+    int* v_first = (passes & 1) ? vB : flatten_ids;
+    int* v_alt = (passes & 1) ? flatten_ids : vB;
+    hipLaunchKernelGGL(isect_emit_kernel<unsigned>, dim3(gridS), dim3(256), 0, st, N, C, means2d, radii, depths,
+                       tiles_per_gauss, (const int*)block_offsets, tile_w, tile_h, tile_bits, (const int*)n_isect, order,
+                       kB0, v_first);
+    which = sort_pairs_u32(kB0, v_first, kB1, v_alt, n_isect, capacity, end_bit, sort_ws, L.sort_ws_bytes, st);
+    if (which < 0) return which;
+    const unsigned* tile_keys = which ? kB1 : kB0;
+    const long long work = capacity > n_tot + 1 ? capacity : n_tot + 1;
+    hipLaunchKernelGGL(tile_offsets_kernel<unsigned>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, tile_keys,
+                       (const int*)n_isect, (int)n_tot, tile_w * tile_h, tile_bits, offsets);
+    if (isect_ids != nullptr)
+        hipLaunchKernelGGL(isect_ids_kernel, dim3((unsigned)((capacity + 255) / 256)), dim3(256), 0, st, tile_keys,
+                           (const int*)flatten_ids, depths, (const int*)n_isect, (unsigned long long*)isect_ids);
+    return check_launch("qed_bin_tiles");
+}
 
 extern "C" int qed_isect_scan(const int32_t* block_sums, int32_t n_blocks, int32_t* block_offsets, int32_t* n_isect,
                               int64_t capacity, int32_t* status, void* stream) {
@@ -159,9 +306,9 @@ extern "C" int qed_isect_emit(int32_t N, int32_t C, const float* means2d, const 
                 "null buffers");
     const long long total = (long long)C * N;
     const unsigned grid = (unsigned)((total + 255) / 256);
-    hipLaunchKernelGGL(isect_emit_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, N, C, means2d, radii, depths,
-                       tiles_per_gauss, block_offsets, tile_w, tile_h, tile_bits, n_isect,
-                       (unsigned long long*)keys, vals);
+    hipLaunchKernelGGL(isect_emit_kernel<unsigned long long>, dim3(grid), dim3(256), 0, (hipStream_t)stream, N, C,
+                       means2d, radii, depths, tiles_per_gauss, block_offsets, tile_w, tile_h, tile_bits, n_isect,
+                       (const int*)nullptr, (unsigned long long*)keys, vals);
     return check_launch("qed_isect_emit");
 }
 
@@ -172,7 +319,7 @@ extern "C" int qed_tile_offsets(const uint64_t* sorted_keys, const int32_t* n_de
     const long long n_tot = (long long)C * n_tiles;
     const long long work = capacity > n_tot + 1 ? capacity : n_tot + 1;
     const unsigned grid = (unsigned)((work + 255) / 256);
-    hipLaunchKernelGGL(tile_offsets_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(tile_offsets_kernel<unsigned long long>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned long long*)sorted_keys, n_dev, (int)n_tot, n_tiles, tile_bits, offsets);
     return check_launch("qed_tile_offsets");
 }

@@ -242,6 +242,20 @@ static int sort_pairs_impl(KeyT* keys, int* vals, KeyT* keys_alt, int* vals_alt,
 }
 
 constexpr int kKpt64 = 8;   // 2048 pairs per workgroup: >= 1400 workgroups at M = 3e6
+constexpr int kKpt32 = 8;
+
+// 32-bit-key flavour used by the two-stage tile binning (qed_bin_tiles, isect.hip)
+long long sort32_workspace_bytes(long long capacity) {
+    const long long items = SortCfg<unsigned, kKpt32>::kItems;
+    const long long nb = (capacity + items - 1) / items;
+    return ((long long)kRadix * nb + kRadix) * (long long)sizeof(int) + 256;
+}
+
+int sort_pairs_u32(unsigned* keys, int* vals, unsigned* keys_alt, int* vals_alt, const int* n_dev, long long capacity,
+                   int end_bit, void* workspace, long long workspace_bytes, hipStream_t st) {
+    return sort_pairs_impl<unsigned, kKpt32>(keys, vals, keys_alt, vals_alt, n_dev, capacity, end_bit, workspace,
+                                             workspace_bytes, st);
+}
 
 }  // namespace qed
 

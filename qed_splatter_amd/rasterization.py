@@ -228,21 +228,17 @@ def _packed_vsplat(C, N, v_means2d, v_depths, v_conics, v_opac, v_rgb, dev) -> T
 # tile binning + sort + compositing
 # ==================================================================================================
 def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, tile_w, tile_h, sync=True):
-    """isect scan -> emit -> radix sort -> tile offsets.
+    """Two-stage tile binning (qed_bin_tiles): depth sort of the slots, emit in depth order, stable
+    sort on the tile bits, tile offsets -- one C call.
 
     Returns (isect_ids, flatten_ids, offsets, M).  With ``sync=False`` (after a first calibrating
-    call) nothing is read back: M is None and the id tensors keep their full capacity length.
+    call) nothing is read back: M and isect_ids are None and flatten_ids keeps its capacity length.
     """
     lib = L.load()
     dev = means2d.device
     ws = _workspace(dev)
     n_tiles = tile_w * tile_h
-    tb = tile_bits_for(n_tiles)
-    cam_bits = int(math.ceil(math.log2(C))) if C > 1 else 0
-    end_bit = 32 + tb + cam_bits
-    n_blocks = (C * N + 255) // 256
-    block_offsets = torch.empty(max(n_blocks, 1), dtype=torch.int32, device=dev)
-    n_isect = torch.zeros(1, dtype=torch.int32, device=dev)
+    n_isect = torch.empty(1, dtype=torch.int32, device=dev)
     offsets = torch.empty(C * n_tiles + 1, dtype=torch.int32, device=dev)
     ws.poll_pending()
     if ws.capacity == 0:
@@ -250,23 +246,12 @@ def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, til
         ws.capacity = max(1 << 16, 8 * C * N)
     for _attempt in range(2):
         cap = ws.capacity
-        keys_a = torch.empty(cap, dtype=torch.int64, device=dev)
-        keys_b = torch.empty(cap, dtype=torch.int64, device=dev)
-        vals_a = torch.empty(cap, dtype=torch.int32, device=dev)
-        vals_b = torch.empty(cap, dtype=torch.int32, device=dev)
-        sort_ws = torch.empty(int(lib.qed_sort_workspace_bytes(cap)), dtype=torch.uint8, device=dev)
-        st = _stream()
-        L.check(lib.qed_isect_scan(L.ptr(block_sums), n_blocks, L.ptr(block_offsets), L.ptr(n_isect), cap,
-                                   L.ptr(ws.status), st), "qed_isect_scan")
-        L.check(lib.qed_isect_emit(N, C, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(tiles_per_gauss),
-                                   L.ptr(block_offsets), tile_w, tile_h, tb, L.ptr(n_isect), cap, L.ptr(keys_a),
-                                   L.ptr(vals_a), st), "qed_isect_emit")
-        which = L.check(lib.qed_sort_pairs(L.ptr(keys_a), L.ptr(vals_a), L.ptr(keys_b), L.ptr(vals_b),
-                                           L.ptr(n_isect), cap, end_bit, L.ptr(sort_ws), sort_ws.numel(),
-                                           L.ptr(ws.status), st), "qed_sort_pairs")
-        keys, vals = (keys_b, vals_b) if which == 1 else (keys_a, vals_a)
-        L.check(lib.qed_tile_offsets(L.ptr(keys), L.ptr(n_isect), cap, C, n_tiles, tb, L.ptr(offsets), st),
-                "qed_tile_offsets")
+        flatten_ids = torch.empty(cap, dtype=torch.int32, device=dev)
+        isect_ids = torch.empty(cap, dtype=torch.int64, device=dev) if sync else None
+        scratch = torch.empty(int(lib.qed_bin_workspace_bytes(C * N, cap)), dtype=torch.uint8, device=dev)
+        L.check(lib.qed_bin_tiles(N, C, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(tiles_per_gauss), tile_w,
+                                  tile_h, cap, L.ptr(flatten_ids), L.ptr(offsets), L.ptr(n_isect), L.ptr(isect_ids),
+                                  L.ptr(scratch), scratch.numel(), L.ptr(ws.status), _stream()), "qed_bin_tiles")
         if not sync:
             host = torch.empty(2, dtype=torch.int32, pin_memory=True)
             host[0:1].copy_(n_isect, non_blocking=True)
@@ -274,13 +259,13 @@ def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, til
             ev = torch.cuda.Event()
             ev.record()
             ws.pending = (host, ev)
-            return keys, vals, offsets, None
+            return None, flatten_ids, offsets, None
         # one host read: M and the overflow word
         host = torch.stack([n_isect[0], ws.status[0]]).tolist()
         M, overflow = int(host[0]), int(host[1])
         if overflow == 0:
             ws.capacity = max(ws.capacity, int(M * 1.25) + 4096)
-            return keys[:M], vals[:M], offsets, M
+            return isect_ids[:M], flatten_ids[:M], offsets, M
         ws.status.zero_()
         ws.capacity = int(overflow * 1.25) + 4096
     raise L.QedSplatError("intersection buffer overflow persisted after regrowth")
