@@ -224,10 +224,10 @@ extern "C" int qed_bin_tiles(int32_t N, int32_t C, const float* means2d, const i
                              int32_t* flatten_ids, int32_t* offsets, int32_t* n_isect, uint64_t* isect_ids,
                              void* workspace, int64_t workspace_bytes, int32_t* status, void* stream) {
     QED_REQUIRE(N >= 0 && C >= 1 && tile_w > 0 && tile_h > 0, "bad extents");
-    QED_REQUIRE(capacity >= 0 && capacity < (1ll << 31), "capacity out of range");
+    QED_REQUIRE(capacity >= 0 && capacity < (1ll << 30), "capacity out of range");
     QED_REQUIRE(offsets && n_isect && status && workspace, "null buffers");
     const long long S = (long long)C * N;
-    QED_REQUIRE(S < (1ll << 31), "too many (camera, Gaussian) slots");
+    QED_REQUIRE(S < (1ll << 30), "too many (camera, Gaussian) slots");
     const long long n_tot = (long long)C * tile_w * tile_h;
     int tile_bits = 1;
     while ((1ll << tile_bits) <= (long long)tile_w * tile_h) ++tile_bits;      // floor(log2 T) + 1
@@ -258,7 +258,7 @@ extern "C" int qed_bin_tiles(int32_t N, int32_t C, const float* means2d, const i
     const unsigned gridS = (unsigned)((S + 255) / 256);
     // stage A: (camera, Gaussian) slots into depth order
     hipLaunchKernelGGL(depth_keys_kernel, dim3(gridS), dim3(256), 0, st, (int)S, radii, depths, kA0, vA0, n_slots_dev);
-    int which = sort_pairs_u32(kA0, vA0, kA1, vA1, n_slots_dev, S, 32, sort_ws, L.sort_ws_bytes, st);
+    int which = sort_pairs_u32(kA0, vA0, kA1, vA1, n_slots_dev, S, 32, sort_ws, L.sort_ws_bytes, status, st);
     if (which < 0) return which;
     const int* order = which ? vA1 : vA0;
     // intersection counts in depth order -> offsets, M
@@ -274,7 +274,7 @@ extern "C" int qed_bin_tiles(int32_t N, int32_t C, const float* means2d, const i
     hipLaunchKernelGGL(isect_emit_kernel<unsigned>, dim3(gridS), dim3(256), 0, st, N, C, means2d, radii, depths,
                        tiles_per_gauss, (const int*)block_offsets, tile_w, tile_h, tile_bits, (const int*)n_isect, order,
                        kB0, v_first);
-    which = sort_pairs_u32(kB0, v_first, kB1, v_alt, n_isect, capacity, end_bit, sort_ws, L.sort_ws_bytes, st);
+    which = sort_pairs_u32(kB0, v_first, kB1, v_alt, n_isect, capacity, end_bit, sort_ws, L.sort_ws_bytes, status, st);
     if (which < 0) return which;
     const unsigned* tile_keys = which ? kB1 : kB0;
     const long long work = capacity > n_tot + 1 ? capacity : n_tot + 1;

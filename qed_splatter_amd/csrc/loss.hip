@@ -209,12 +209,14 @@ using namespace qed;
 extern "C" int qed_version(void) { return 1; }
 extern "C" const char* qed_last_error(void) { return g_err; }
 
-static unsigned stream_grid(long long n_items) {
+static unsigned stream_grid(long long n_items, long long cap = 2048) {
     long long g = (n_items + 255) / 256;
-    if (g > 2048) g = 2048;      // 256 CUs x 8 workgroups, grid-stride the rest
+    if (g > cap) g = cap;        // 256 CUs x 8 workgroups, grid-stride the rest
     if (g < 1) g = 1;
     return (unsigned)g;
 }
+// the loss kernels end with same-address atomics (one per workgroup): keep the grid at 2 per CU
+static unsigned reduce_grid(long long n_items) { return stream_grid(n_items, 512); }
 
 extern "C" int qed_loss_reduce(int32_t n_pix, int32_t channels, const float* render, const float* alpha,
                                const float* background, const float* gt_rgb, const float* gt_depth,
@@ -228,10 +230,10 @@ extern "C" int qed_loss_reduce(int32_t n_pix, int32_t channels, const float* ren
     if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(sums + 3), (int)0x80800000, 1, st);
     if (e != hipSuccess) { set_error("qed_loss_reduce: memset failed: %s", hipGetErrorString(e)); return QED_E_LAUNCH; }
     if (channels == 4)
-        hipLaunchKernelGGL(loss_reduce_kernel<4>, dim3(stream_grid(n_pix)), dim3(256), 0, st, n_pix, render, alpha,
+        hipLaunchKernelGGL(loss_reduce_kernel<4>, dim3(reduce_grid(n_pix)), dim3(256), 0, st, n_pix, render, alpha,
                            background, gt_rgb, gt_depth, mask, sums);
     else
-        hipLaunchKernelGGL(loss_reduce_kernel<3>, dim3(stream_grid(n_pix)), dim3(256), 0, st, n_pix, render, alpha,
+        hipLaunchKernelGGL(loss_reduce_kernel<3>, dim3(reduce_grid(n_pix)), dim3(256), 0, st, n_pix, render, alpha,
                            background, gt_rgb, gt_depth, mask, sums);
     return check_launch("qed_loss_reduce");
 }
@@ -246,10 +248,10 @@ extern "C" int qed_loss_grad(int32_t n_pix, int32_t channels, const float* rende
     hipStream_t st = (hipStream_t)stream;
     float* sums_rw = const_cast<float*>(sums);     // slot [1] is accumulated by this pass
     if (channels == 4)
-        hipLaunchKernelGGL(loss_grad_kernel<4>, dim3(stream_grid(n_pix)), dim3(256), 0, st, n_pix, render, alpha,
+        hipLaunchKernelGGL(loss_grad_kernel<4>, dim3(reduce_grid(n_pix)), dim3(256), 0, st, n_pix, render, alpha,
                            background, gt_rgb, gt_depth, mask, sums_rw, rgb_weight, depth_lambda, v_render, v_alpha);
     else
-        hipLaunchKernelGGL(loss_grad_kernel<3>, dim3(stream_grid(n_pix)), dim3(256), 0, st, n_pix, render, alpha,
+        hipLaunchKernelGGL(loss_grad_kernel<3>, dim3(reduce_grid(n_pix)), dim3(256), 0, st, n_pix, render, alpha,
                            background, gt_rgb, gt_depth, mask, sums_rw, rgb_weight, depth_lambda, v_render, v_alpha);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, n_pix, sums, rgb_weight, depth_lambda, losses);
     return check_launch("qed_loss_grad");

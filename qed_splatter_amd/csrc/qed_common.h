@@ -13,7 +13,7 @@ void set_error(const char* fmt, ...);
 // radix_sort.hip: 32-bit-key stable LSD sort of (key, value) pairs; same contract as qed_sort_pairs
 long long sort32_workspace_bytes(long long capacity);
 int sort_pairs_u32(unsigned* keys, int* vals, unsigned* keys_alt, int* vals_alt, const int* n_dev, long long capacity,
-                   int end_bit, void* workspace, long long workspace_bytes, hipStream_t st);
+                   int end_bit, void* workspace, long long workspace_bytes, int* status, hipStream_t st);
 
 // constants of the operator behind model.py:267-288
 constexpr float kAlphaMax = 0.999f;

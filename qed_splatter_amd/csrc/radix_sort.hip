@@ -89,14 +89,32 @@ sort_scan_kernel(const int* __restrict__ n_dev, int nblocks_max, int* __restrict
 }
 
 // ---- (3) stable rank + scatter --------------------------------------------------------------------------
-template <typename KeyT, int KPT>
+// LOOKBACK = false: per-block digit bases come from the histogram + scan kernels above.
+// LOOKBACK = true ("onesweep"): one kernel per pass.  Workgroups take tiles in ticket order; each
+// publishes its per-digit count in a 32-bit word {2-bit state, 30-bit value} with a relaxed
+// agent-scope store (payload and flag travel in ONE word, so no other ordering is needed -- the
+// granule hand-off of the CDNA4 guide) and sums its predecessors' words (decoupled look-back).  A
+// tile only ever waits for tiles with smaller tickets, which are already running; every spin is
+// bounded and reports through status[1] instead of hanging.
+constexpr unsigned kLbPartial = 1u << 30, kLbInclusive = 2u << 30, kLbValue = (1u << 30) - 1u;
+constexpr int kLbSpinLimit = 1 << 18;
+
+template <typename KeyT, int KPT, bool LOOKBACK>
 __global__ void __launch_bounds__(kSortThreads)
 sort_scatter_kernel(const KeyT* __restrict__ keys_in, const int* __restrict__ vals_in, KeyT* __restrict__ keys_out,
                     int* __restrict__ vals_out, const int* __restrict__ n_dev, int shift, unsigned mask,
-                    int nblocks_max, const int* __restrict__ hist, const int* __restrict__ digit_tot) {
+                    int nblocks_max, const int* __restrict__ hist, const int* __restrict__ digit_tot,
+                    unsigned* __restrict__ lookback, int* __restrict__ ticket, int* __restrict__ status) {
     constexpr int kItems = SortCfg<KeyT, KPT>::kItems;
     const int n = n_dev[0];
-    const long long base = (long long)blockIdx.x * kItems;
+    int tile = blockIdx.x;
+    if constexpr (LOOKBACK) {
+        __shared__ int s_tile;
+        if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1);
+        __syncthreads();
+        tile = s_tile;
+    }
+    const long long base = (long long)tile * kItems;
     if (base >= n) return;
     const int block_n = (int)min((long long)kItems, (long long)n - base);
 
@@ -177,7 +195,32 @@ sort_scatter_kernel(const KeyT* __restrict__ keys_in, const int* __restrict__ va
         int wb = 0, gwb = 0;
         for (int w = 0; w < wid; ++w) { wb += s_wsum[w]; gwb += s_gw[w]; }
         const int lbase = wb + x - tot;
-        const int gbase = gwb + gx - g + hist[(long long)tid * nblocks_max + blockIdx.x];
+        int block_prefix;
+        if constexpr (LOOKBACK) {
+            unsigned* mine = lookback + (long long)tile * kRadix + tid;
+            __hip_atomic_store(mine, (unsigned)tot | (tile == 0 ? kLbInclusive : kLbPartial), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            unsigned excl = 0;
+            for (int j = tile - 1; j >= 0; --j) {
+                const unsigned* theirs = lookback + (long long)j * kRadix + tid;
+                unsigned v;
+                int spins = 0;
+                while (((v = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 30) == 0u) {
+                    if (++spins > kLbSpinLimit) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if ((v >> 30) == 0u) { status[1] = 1; break; }        // watchdog: never hang the GPU
+                excl += v & kLbValue;
+                if ((v >> 30) == 2u) break;
+            }
+            if (tile != 0)
+                __hip_atomic_store(mine, (excl + (unsigned)tot) | kLbInclusive, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            block_prefix = (int)excl;
+        } else {
+            block_prefix = hist[(long long)tid * nblocks_max + blockIdx.x];
+        }
+        const int gbase = gwb + gx - g + block_prefix;
         s_lbase[tid] = lbase;
         s_gofs[tid] = gbase - lbase;
     }
@@ -208,13 +251,69 @@ sort_scatter_kernel(const KeyT* __restrict__ keys_in, const int* __restrict__ va
     }
 }
 
+// ---- (0) onesweep: global digit histograms of ALL passes in one read of the keys -----------------------
+template <typename KeyT, int PASSES>
+__global__ void __launch_bounds__(kSortThreads)
+sort_global_hist_kernel(const KeyT* __restrict__ keys, const int* __restrict__ n_dev, int end_bit,
+                        int* __restrict__ ghist) {
+    __shared__ int s_h[PASSES][kRadix];
+    const int n = n_dev[0];
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) s_h[p][threadIdx.x] = 0;
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * kSortThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kSortThreads) {
+        const KeyT k = keys[i];
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int shift = p * kRadixBits;
+            if (shift < end_bit) {
+                const int bits = min(kRadixBits, end_bit - shift);
+                atomicAdd(&s_h[p][digit_of<KeyT>(k, shift, (1u << bits) - 1u)], 1);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const int c = s_h[p][threadIdx.x];
+        if (c != 0) atomicAdd(&ghist[p * kRadix + threadIdx.x], c);
+    }
+}
+
+// Measured on MI355X at M = 4.7e6 (round 1): the decoupled look-back pass takes 33 us against 28 us
+// for histogram + scan + scatter (its per-digit look-back walks predecessors one ~1.5 us global load
+// at a time), so the three-kernel pass is the default; QED_SORT_LOOKBACK=1 selects the look-back pass.
+static bool sort_use_lookback() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("QED_SORT_LOOKBACK");
+        v = (e != nullptr && e[0] == '1') ? 1 : 0;
+    }
+    return v == 1;
+}
+
+template <typename KeyT>
+constexpr int max_passes() { return (int)sizeof(KeyT); }
+
+// workspace: [reduce-then-scan] hist[256][nb] + digit_tot[256]  |  [onesweep] ghist[P][256] + tickets[P(+pad)]
+// + lookback[P][nb][256]; sized for whichever is larger
+template <typename KeyT, int KPT>
+static long long sort_workspace_need(long long capacity) {
+    constexpr int kItems = SortCfg<KeyT, KPT>::kItems;
+    const long long nb = (capacity + kItems - 1) / kItems;
+    const long long a = ((long long)kRadix * nb + kRadix) * 4;
+    const long long P = max_passes<KeyT>();
+    const long long b = (P * kRadix + 64 + P * nb * kRadix) * 4;
+    return (a > b ? a : b) + 256;
+}
+
 template <typename KeyT, int KPT>
 static int sort_pairs_impl(KeyT* keys, int* vals, KeyT* keys_alt, int* vals_alt, const int* n_dev, long long capacity,
-                           int end_bit, void* workspace, long long workspace_bytes, hipStream_t st) {
+                           int end_bit, void* workspace, long long workspace_bytes, int* status, hipStream_t st) {
     constexpr int kItems = SortCfg<KeyT, KPT>::kItems;
     const int nblocks_max = (int)((capacity + kItems - 1) / kItems);
     if (nblocks_max == 0) return 0;
-    const long long need = ((long long)kRadix * nblocks_max + kRadix) * (long long)sizeof(int);
+    const long long need = sort_workspace_need<KeyT, KPT>(capacity);
     if (workspace_bytes < need) {
         set_error("qed_sort_pairs: workspace too small (%lld < %lld)", workspace_bytes, need);
         return QED_E_WORKSPACE;
@@ -223,6 +322,34 @@ static int sort_pairs_impl(KeyT* keys, int* vals, KeyT* keys_alt, int* vals_alt,
     int* digit_tot = hist + (long long)kRadix * nblocks_max;
     const int passes = (end_bit + kRadixBits - 1) / kRadixBits;
     KeyT* kin = keys; int* vin = vals; KeyT* kout = keys_alt; int* vout = vals_alt;
+    if (sort_use_lookback()) {
+        constexpr int P = max_passes<KeyT>();
+        int* ghist = (int*)workspace;                        // [P][256]
+        int* tickets = ghist + P * kRadix;                   // [64]
+        unsigned* lookback = (unsigned*)(tickets + 64);      // [passes][nblocks_max][256]
+        const size_t zero_bytes = ((size_t)P * kRadix + 64 + (size_t)passes * nblocks_max * kRadix) * 4;
+        if (hipMemsetAsync(workspace, 0, zero_bytes, st) != hipSuccess) {
+            set_error("qed_sort_pairs: memset failed");
+            return QED_E_LAUNCH;
+        }
+        const int hist_grid = nblocks_max < 256 ? nblocks_max : 256;
+        hipLaunchKernelGGL((sort_global_hist_kernel<KeyT, P>), dim3(hist_grid), dim3(kSortThreads), 0, st, kin, n_dev,
+                           end_bit, ghist);
+        for (int p = 0; p < passes; ++p) {
+            const int shift = p * kRadixBits;
+            const int bits = min(kRadixBits, end_bit - shift);
+            const unsigned mask = (1u << bits) - 1u;
+            hipLaunchKernelGGL((sort_scatter_kernel<KeyT, KPT, true>), dim3(nblocks_max), dim3(kSortThreads), 0, st, kin,
+                               vin, kout, vout, n_dev, shift, mask, nblocks_max, (const int*)nullptr,
+                               (const int*)(ghist + p * kRadix), lookback + (size_t)p * nblocks_max * kRadix,
+                               tickets + p, status);
+            KeyT* tk = kin; kin = kout; kout = tk;
+            int* tv = vin; vin = vout; vout = tv;
+        }
+        const int rc = check_launch("qed_sort_pairs");
+        if (rc != QED_OK) return rc;
+        return passes & 1;
+    }
     for (int p = 0; p < passes; ++p) {
         const int shift = p * kRadixBits;
         const int bits = min(kRadixBits, end_bit - shift);
@@ -231,8 +358,9 @@ static int sort_pairs_impl(KeyT* keys, int* vals, KeyT* keys_alt, int* vals_alt,
                            shift, mask, nblocks_max, hist);
         hipLaunchKernelGGL((sort_scan_kernel<kItems>), dim3(kRadix), dim3(kSortThreads), 0, st, n_dev, nblocks_max,
                            hist, digit_tot);
-        hipLaunchKernelGGL((sort_scatter_kernel<KeyT, KPT>), dim3(nblocks_max), dim3(kSortThreads), 0, st, kin, vin,
-                           kout, vout, n_dev, shift, mask, nblocks_max, hist, digit_tot);
+        hipLaunchKernelGGL((sort_scatter_kernel<KeyT, KPT, false>), dim3(nblocks_max), dim3(kSortThreads), 0, st, kin,
+                           vin, kout, vout, n_dev, shift, mask, nblocks_max, (const int*)hist, (const int*)digit_tot,
+                           (unsigned*)nullptr, (int*)nullptr, (int*)nullptr);
         KeyT* tk = kin; kin = kout; kout = tk;
         int* tv = vin; vin = vout; vout = tv;
     }
@@ -245,16 +373,12 @@ constexpr int kKpt64 = 8;   // 2048 pairs per workgroup: >= 1400 workgroups at M
 constexpr int kKpt32 = 8;
 
 // 32-bit-key flavour used by the two-stage tile binning (qed_bin_tiles, isect.hip)
-long long sort32_workspace_bytes(long long capacity) {
-    const long long items = SortCfg<unsigned, kKpt32>::kItems;
-    const long long nb = (capacity + items - 1) / items;
-    return ((long long)kRadix * nb + kRadix) * (long long)sizeof(int) + 256;
-}
+long long sort32_workspace_bytes(long long capacity) { return sort_workspace_need<unsigned, kKpt32>(capacity); }
 
 int sort_pairs_u32(unsigned* keys, int* vals, unsigned* keys_alt, int* vals_alt, const int* n_dev, long long capacity,
-                   int end_bit, void* workspace, long long workspace_bytes, hipStream_t st) {
+                   int end_bit, void* workspace, long long workspace_bytes, int* status, hipStream_t st) {
     return sort_pairs_impl<unsigned, kKpt32>(keys, vals, keys_alt, vals_alt, n_dev, capacity, end_bit, workspace,
-                                             workspace_bytes, st);
+                                             workspace_bytes, status, st);
 }
 
 }  // namespace qed
@@ -263,9 +387,7 @@ using namespace qed;
 
 extern "C" int64_t qed_sort_workspace_bytes(int64_t capacity) {
     if (capacity < 0) return QED_E_INVALID_ARG;
-    const long long items = SortCfg<unsigned long long, kKpt64>::kItems;
-    const long long nb = (capacity + items - 1) / items;
-    return ((long long)kRadix * nb + kRadix) * (long long)sizeof(int) + 256;
+    return sort_workspace_need<unsigned long long, kKpt64>(capacity);
 }
 
 extern "C" int qed_sort_pairs(uint64_t* keys, int32_t* vals, uint64_t* keys_alt, int32_t* vals_alt,
@@ -273,10 +395,10 @@ extern "C" int qed_sort_pairs(uint64_t* keys, int32_t* vals, uint64_t* keys_alt,
                               int64_t workspace_bytes, int32_t* status, void* stream) {
     QED_REQUIRE(capacity >= 0 && capacity < (1ll << 31), "capacity out of range");
     QED_REQUIRE(end_bit >= 1 && end_bit <= 64, "end_bit must be in [1, 64]");
-    (void)status;
+    QED_REQUIRE(capacity < (1ll << 30), "capacity must be below 2^30 (30-bit look-back words)");
     if (capacity == 0) return 0;
-    QED_REQUIRE(keys && vals && keys_alt && vals_alt && n_dev && workspace, "null buffers");
+    QED_REQUIRE(keys && vals && keys_alt && vals_alt && n_dev && workspace && status, "null buffers");
     return sort_pairs_impl<unsigned long long, kKpt64>((unsigned long long*)keys, vals, (unsigned long long*)keys_alt,
                                                       vals_alt, n_dev, capacity, end_bit, workspace, workspace_bytes,
-                                                      (hipStream_t)stream);
+                                                      status, (hipStream_t)stream);
 }
