@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-div", type=int, default=4, help="CPU sample = config / div^2 (area and N)")
     ap.add_argument("--sync-m", action="store_true", help="read the intersection count back every step")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=None,
+                    help="replay the step from a captured hipGraph (default at 1 GPU)")
+    ap.add_argument("--no-graph", dest="graph", action="store_false", help="eager dispatch")
     return ap.parse_args()
 
 
@@ -107,6 +110,11 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
+    # Work on an explicit (non-legacy) stream from the start: autograd pins each leaf's gradient
+    # accumulation to the stream it first ran on, and nothing may touch the legacy default stream
+    # while the step is being captured into a hipGraph.
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+
     from qed_splatter_amd import _lib as L
     from qed_splatter_amd.model import FlatAdam, PinholeCameras, QEDSplatterModel, QEDSplatterModelConfig
     from qed_splatter_amd.parallel import allreduce_flat_grad
@@ -169,13 +177,39 @@ def main():
     kern = L.TIMER.summary()
     log(f"instrumented region: {dt / args.steps * 1e3:.3f} ms/step")
 
-    # a second, un-instrumented timed region gives the headline number (event records cost host time)
+    # a second, un-instrumented timed region gives the headline number (event records cost host time).
+    # Default at N = 1: the whole step replayed from one captured hipGraph (same kernels, same work;
+    # only the host dispatch cost is removed).  --no-graph times eager dispatch instead.
+    use_graph = args.graph if args.graph is not None else (world == 1)
+    run = lambda: step(args.sync_m)
+    if use_graph:
+        from qed_splatter_amd.graph import GraphedTrainStep
+
+        def graph_step():
+            for p in model.parameters():
+                p.grad = None
+            losses = model.fused_loss(cam, batch, background=bg, sync=False)
+            (losses["main_loss"] + losses["depth_loss"]).backward()
+            if world > 1:
+                allreduce_flat_grad(model, world)
+            opt.step(device_state=True)
+            return losses
+
+        opt.dev_state[0] = float(opt.t)               # hand the step counter over to the device-side state
+        graphed = GraphedTrainStep(graph_step, dev, warmup=3, check_every=0)
+        run = graphed.replay
+        for _ in range(3):
+            run()
+        graphed.check()
+        log("step captured into a hipGraph")
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(args.sync_m)
+        run()
     barrier()
     dt2 = time.perf_counter() - t0
+    if use_graph:
+        graphed.check()                                # no intersection overflow during the timed replays
     if dist is not None:
         t = torch.tensor([dt2], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -203,7 +237,8 @@ def main():
                                    f"depth-L1 + L1-RGB loss + fused Adam (SSIM term not built yet)",
                        "gaussians": n, "visible": n_vis, "intersections": M, "width": w, "height": h,
                        "parallelism": f"dp{world} (camera-sharded, flat-gradient all-reduce)" if world > 1 else "single",
-                       "async_intersection_count": not args.sync_m},
+                       "async_intersection_count": not args.sync_m,
+                       "dispatch": "hipGraph replay of the whole step" if use_graph else "eager"},
             "msplats_per_s": n_vis * world / (dt2 / args.steps) / 1e6,
             "ms_per_step_instrumented": dt / args.steps * 1e3,
             "kernels_ms": {k: round(v[1], 4) for k, v in sorted(kern.items())},

@@ -180,6 +180,13 @@ int qed_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
                   int32_t n_groups, const int64_t* h_group_begin, const float* h_lr, float beta1,
                   float beta2, float eps, int32_t step, void* stream);
 
+/* Same update with the step state and learning rates in DEVICE memory, so that a captured hipGraph
+ * can be replayed: dev_state[3] = {step, 1/(1-beta1^step), 1/sqrt(1-beta2^step)} is advanced by one
+ * (zero it before the first step), dev_lr[8] holds the per-group learning rates. */
+int qed_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                      int32_t n_groups, const int64_t* h_group_begin, const float* dev_lr, float beta1,
+                      float beta2, float eps, float* dev_state, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,7 @@ SIGNATURES = {
     "qed_loss_reduce": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qed_loss_grad": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P]),
     "qed_adam_step": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _F, _F, _F, _I, _P]),
+    "qed_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _F, _F, _F, _P, _P]),
 }
 
 # flags (include/qed_splat.h)

@@ -163,7 +163,14 @@ struct AdamGroups {
 
 __global__ void __launch_bounds__(256)
 adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-            AdamGroups grp, float beta1, float beta2, float eps, float inv_bc1, float inv_bc2_sqrt) {
+            AdamGroups grp, float beta1, float beta2, float eps, float inv_bc1, float inv_bc2_sqrt,
+            const float* __restrict__ dev_state, const float* __restrict__ dev_lr) {
+    // device-resident step state / learning rates (hipGraph replays cannot change kernel arguments)
+    if (dev_state != nullptr) { inv_bc1 = dev_state[1]; inv_bc2_sqrt = dev_state[2]; }
+    if (dev_lr != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) grp.lr[k] = dev_lr[k];
+    }
     const long long total = grp.begin[grp.n];
     const long long nvec = total >> 2;
     auto lr_of = [&](long long i) {
@@ -199,6 +206,16 @@ adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restric
         float mm = m[e], vv = v[e];
         p[e] = upd(p[e], g[e], mm, vv, lr_of(e));
         m[e] = mm; v[e] = vv;
+    }
+}
+
+// state = {step (as float), 1 / (1 - beta1^step), 1 / sqrt(1 - beta2^step)}; advances the step by one
+__global__ void adam_tick_kernel(float* __restrict__ state, float beta1, float beta2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float t = state[0] + 1.f;
+        state[0] = t;
+        state[1] = 1.f / (1.f - powf(beta1, t));
+        state[2] = 1.f / sqrtf(1.f - powf(beta2, t));
     }
 }
 
@@ -257,17 +274,38 @@ extern "C" int qed_loss_grad(int32_t n_pix, int32_t channels, const float* rende
     return check_launch("qed_loss_grad");
 }
 
+static int adam_launch(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t n_groups,
+                       const int64_t* h_group_begin, const float* h_lr, float beta1, float beta2, float eps,
+                       int32_t step, float* dev_state, const float* dev_lr, void* stream);
+
 extern "C" int qed_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t n_groups,
                              const int64_t* h_group_begin, const float* h_lr, float beta1, float beta2, float eps,
                              int32_t step, void* stream) {
+    QED_REQUIRE(h_lr && step >= 1, "bad arguments");
+    return adam_launch(params, grads, exp_avg, exp_avg_sq, n_groups, h_group_begin, h_lr, beta1, beta2, eps, step,
+                       nullptr, nullptr, stream);
+}
+
+extern "C" int qed_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                                 int32_t n_groups, const int64_t* h_group_begin, const float* dev_lr, float beta1,
+                                 float beta2, float eps, float* dev_state, void* stream) {
+    QED_REQUIRE(dev_lr && dev_state, "device lr / state required");
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dev_state, beta1, beta2);
+    return adam_launch(params, grads, exp_avg, exp_avg_sq, n_groups, h_group_begin, nullptr, beta1, beta2, eps, 1,
+                       dev_state, dev_lr, stream);
+}
+
+static int adam_launch(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t n_groups,
+                       const int64_t* h_group_begin, const float* h_lr, float beta1, float beta2, float eps,
+                       int32_t step, float* dev_state, const float* dev_lr, void* stream) {
     QED_REQUIRE(n_groups >= 1 && n_groups <= 8, "1..8 parameter groups");
-    QED_REQUIRE(params && grads && exp_avg && exp_avg_sq && h_group_begin && h_lr && step >= 1, "bad arguments");
+    QED_REQUIRE(params && grads && exp_avg && exp_avg_sq && h_group_begin && step >= 1, "bad arguments");
     QED_REQUIRE((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
                 "buffers must be 16-byte aligned");
     AdamGroups grp;
     for (int i = 0; i <= n_groups; ++i) grp.begin[i] = h_group_begin[i];
     for (int i = n_groups + 1; i < 9; ++i) grp.begin[i] = h_group_begin[n_groups];
-    for (int i = 0; i < 8; ++i) grp.lr[i] = i < n_groups ? h_lr[i] : 0.f;
+    for (int i = 0; i < 8; ++i) grp.lr[i] = (h_lr != nullptr && i < n_groups) ? h_lr[i] : 0.f;
     grp.n = n_groups;
     QED_REQUIRE(grp.begin[0] == 0, "group 0 must start at element 0");
     const long long total = grp.begin[n_groups];
@@ -275,6 +313,7 @@ extern "C" int qed_adam_step(float* params, const float* grads, float* exp_avg, 
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(total / 4 + 1)), dim3(256), 0, (hipStream_t)stream, params, grads,
-                       exp_avg, exp_avg_sq, grp, beta1, beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+                       exp_avg, exp_avg_sq, grp, beta1, beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)),
+                       (const float*)dev_state, dev_lr);
     return check_launch("qed_adam_step");
 }

@@ -1,0 +1,64 @@
+"""hipGraph capture of one whole training step (forward + fused loss + backward + Adam).
+
+The step is ~45 short kernels; eager PyTorch dispatch costs more host time than the GPU needs to run
+them.  Every kernel behind the C ABI reads data-dependent sizes (the intersection count M) from
+device memory and sizes its grid by a calibrated capacity, and the Adam step keeps its counter in
+device memory (qed_adam_step_dev), so the step can be captured once and replayed.  Inputs are
+static tensors: copy a new camera / ground truth into them before ``replay()``.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional
+
+import torch
+
+from . import _lib as L
+from .rasterization import _workspace
+
+
+class GraphedTrainStep:
+    """Capture ``step_fn`` (any callable that runs one full step on static tensors and returns a dict
+    of scalar loss tensors) after a few eager warm-up runs on a side stream; ``replay()`` re-runs it.
+
+    ``check_every``: every that many replays the intersection-overflow word is read back (one small
+    D2H copy); an overflow raises, because that frame rendered empty.
+    """
+
+    def __init__(self, step_fn: Callable[[], Dict[str, torch.Tensor]], device, warmup: int = 3, check_every: int = 50):
+        self.device = torch.device(device)
+        self.step_fn = step_fn
+        self.check_every = check_every
+        self.n_replays = 0
+        ws = _workspace(self.device)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 1)):
+                step_fn()                       # also calibrates the intersection capacity (first call syncs)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        ws.poll_pending()
+        # headroom: the captured buffers can never grow
+        ws.capacity = int(ws.capacity * 1.25) + 4096
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.outputs = step_fn()
+        self.ws = ws
+
+    def replay(self) -> Dict[str, torch.Tensor]:
+        self.graph.replay()
+        self.n_replays += 1
+        if self.check_every and self.n_replays % self.check_every == 0:
+            self.check()
+        return self.outputs
+
+    def check(self) -> None:
+        status = self.ws.status.tolist()        # synchronises
+        if status[0]:
+            need = int(status[0])
+            self.ws.status.zero_()
+            raise L.QedSplatError(
+                f"a graphed step needed {need} tile intersections, more than the captured capacity "
+                f"{self.ws.capacity}; re-capture with a larger capacity")
+        if status[1]:
+            raise L.QedSplatError("radix-sort look-back watchdog fired")

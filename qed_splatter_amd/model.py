@@ -32,11 +32,19 @@ from . import _lib as L
 from .rasterization import rasterization, _stream
 
 
+_FLIP_CACHE: Dict = {}
+
+
 def get_viewmat(optimized_camera_to_world: Tensor) -> Tensor:
     """c2w [C,3,4] (OpenGL) -> gsplat world2camera [C,4,4]  (model.py:22-38)."""
     R = optimized_camera_to_world[:, :3, :3]
     T = optimized_camera_to_world[:, :3, 3:4]
-    flip = torch.tensor([[[1.0, -1.0, -1.0]]], device=R.device, dtype=R.dtype)
+    # pre-created per device (the reference keeps _FLIP_GSPLAT at module level, model.py:19-20): a
+    # host-to-device copy per call would also be illegal inside a hipGraph capture
+    key = (R.device, R.dtype)
+    flip = _FLIP_CACHE.get(key)
+    if flip is None:
+        flip = _FLIP_CACHE[key] = torch.tensor([[[1.0, -1.0, -1.0]]], device=R.device, dtype=R.dtype)
     R = R * flip
     R_inv = R.transpose(1, 2)
     T_inv = -torch.bmm(R_inv, T)
@@ -439,14 +447,21 @@ class FlatAdam:
         self.exp_avg = torch.zeros_like(model.flat_params)
         self.exp_avg_sq = torch.zeros_like(model.flat_params)
         self.t = 0
+        # device-resident step state + learning rates: what a captured hipGraph replays against
+        self.dev_state = torch.zeros(4, dtype=torch.float32, device=model.device)
+        self.dev_lr = torch.zeros(8, dtype=torch.float32, device=model.device)
+        self.dev_lr[:len(self.lr)] = torch.tensor(self.lr)
 
     def set_lr(self, name: str, lr: float) -> None:
         i = self.model.group_names.index(name)
         self.lr[i] = float(lr)
         self._lr[i] = float(lr)
+        self.dev_lr[i] = float(lr)
 
     @torch.no_grad()
-    def step(self) -> None:
+    def step(self, device_state: bool = False) -> None:
+        """One Adam step.  ``device_state=True`` keeps the step counter / bias corrections in device
+        memory (qed_adam_step_dev), which is what makes the step replayable from a hipGraph."""
         import ctypes as C
         p = self.model.flat_params
         g = self.model.flat_grad()
@@ -454,6 +469,12 @@ class FlatAdam:
             return
         self.t += 1
         lib = L.load()
+        if device_state:
+            L.check(lib.qed_adam_step_dev(L.ptr(p), L.ptr(g), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
+                                          len(self.lr), C.cast(self._begin, C.c_void_p), L.ptr(self.dev_lr),
+                                          self.betas[0], self.betas[1], self.eps, L.ptr(self.dev_state), _stream()),
+                    "qed_adam_step_dev")
+            return
         L.check(lib.qed_adam_step(L.ptr(p), L.ptr(g), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
                                   len(self.lr), C.cast(self._begin, C.c_void_p), C.cast(self._lr, C.c_void_p),
                                   self.betas[0], self.betas[1], self.eps, self.t, _stream()), "qed_adam_step")

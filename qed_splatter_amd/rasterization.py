@@ -240,7 +240,15 @@ def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, til
     n_tiles = tile_w * tile_h
     n_isect = torch.empty(1, dtype=torch.int32, device=dev)
     offsets = torch.empty(C * n_tiles + 1, dtype=torch.int32, device=dev)
-    ws.poll_pending()
+    capturing = torch.cuda.is_current_stream_capturing()
+    if capturing:
+        # inside a hipGraph capture nothing may touch the host: capacity is frozen at its calibrated
+        # value and the overflow word is polled by the replaying code (graph.GraphedTrainStep)
+        if ws.capacity == 0:
+            raise L.QedSplatError("run one eager call before capturing: it calibrates the intersection capacity")
+        sync = False
+    else:
+        ws.poll_pending()
     if ws.capacity == 0:
         sync = True                                   # first call calibrates the capacity
         ws.capacity = max(1 << 16, 8 * C * N)
@@ -252,6 +260,9 @@ def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, til
         L.check(lib.qed_bin_tiles(N, C, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(tiles_per_gauss), tile_w,
                                   tile_h, cap, L.ptr(flatten_ids), L.ptr(offsets), L.ptr(n_isect), L.ptr(isect_ids),
                                   L.ptr(scratch), scratch.numel(), L.ptr(ws.status), _stream()), "qed_bin_tiles")
+        if capturing:
+            ws.last_n_isect = n_isect                  # device tensor the replaying code polls
+            return None, flatten_ids, offsets, None
         if not sync:
             host = torch.empty(2, dtype=torch.int32, pin_memory=True)
             host[0:1].copy_(n_isect, non_blocking=True)
