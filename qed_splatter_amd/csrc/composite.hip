@@ -117,6 +117,55 @@ __device__ __forceinline__ void quadrant_masks(bool present, const float4& r0, c
 }
 
 // ================================================================================================
+// packed-math quadrant bodies
+// ================================================================================================
+// CDNA4's fp32 vector peak needs v_pk_* (two fp32 results per lane per issue), so the per-pixel
+// arithmetic is written on 2-vectors: (dx, dy), colour pairs, gradient pairs.  Wave-uniform Gaussian
+// data arrive as SGPR pairs.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u64 uniform_u64(u64 v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+
+// p = -sigma log2(e) = A dx^2 + B dx dy + C dy^2 with (A, C) = AC pre-scaled by -log2(e)/2 and B by -log2(e)
+__device__ __forceinline__ float neg_sigma_log2e(f2 d, f2 AC, float B) {
+    const f2 t = AC * d;                                // (A dx, C dy)
+    const float u = __builtin_fmaf(B, d.y, t.x);        // A dx + B dy
+    const f2 m = d * (f2){u, t.y};                      // (dx (A dx + B dy), C dy^2)
+    return m.x + m.y;
+}
+
+struct FwdPixel {
+    float T;
+    f2 out01, out23;
+    int cur;
+};
+
+template <int CH>
+__device__ __forceinline__ void fwd_quadrant(f2 pq, f2 XY, f2 AC, float B, float op, f2 col01, f2 col23, int idx_v,
+                                             u64& done, FwdPixel& s) {
+    const f2 d = XY - pq;
+    const float p = neg_sigma_log2e(d, AC, B);
+    const float a = fminf(kAlphaMax, op * __builtin_amdgcn_exp2f(p));
+    const u64 m_ok = __ballot(p <= 0.f) & __ballot(a >= kAlphaMin) & ~done;
+    const float at = a * s.T;
+    const float nT = s.T - at;
+    const u64 m_term = m_ok & __ballot(nT <= kTMin);
+    done |= m_term;
+    const u64 m_acc = m_ok & ~m_term;
+    const float w = sel(m_acc, at, 0.f);
+    const f2 ww = {w, w};
+    s.out01 += col01 * ww;
+    if constexpr (CH == 4) s.out23 += col23 * ww;
+    else s.out23.x += col23.x * w;
+    s.T -= w;                                           // = nT where accepted, unchanged elsewhere
+    s.cur = sel(m_acc, idx_v, s.cur);
+}
+
+// ================================================================================================
 // forward
 // ================================================================================================
 template <int CH>
@@ -133,25 +182,27 @@ composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
     const int lane = threadIdx.x;
     const int lx = lane & 7, ly = lane >> 3;
     const float ox = (float)(tx * QED_TILE), oy = (float)(ty * QED_TILE);
-    const float pxs[2] = {ox + (float)lx + 0.5f, ox + (float)lx + 8.5f};
-    const float pys[2] = {oy + (float)ly + 0.5f, oy + (float)ly + 8.5f};
 
     const int start = offsets[tile], end = offsets[tile + 1];
     const int nb = (end - start + kBatch - 1) / kBatch;
+#ifdef QED_TILE_TIMING
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
 
-    float T[4], out[4][CH];
-    int cur[4];
+    f2 pq[4];                                           // pixel centres of this lane's four pixels
+    FwdPixel px[4];
     u64 done[4];                                        // wave-uniform masks
     bool inside[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int ix = tx * QED_TILE + ((q & 1) << 3) + lx, iy = ty * QED_TILE + ((q >> 1) << 3) + ly;
+        pq[q] = (f2){(float)ix + 0.5f, (float)iy + 0.5f};
         inside[q] = ix < width && iy < height;
         done[q] = __ballot(!inside[q]);
-        T[q] = 1.f;
-        cur[q] = 0;
-#pragma unroll
-        for (int k = 0; k < CH; ++k) out[q][k] = 0.f;
+        px[q].T = 1.f;
+        px[q].cur = 0;
+        px[q].out01 = (f2){0.f, 0.f};
+        px[q].out23 = (f2){0.f, 0.f};
     }
 
     // prefetch batch 0
@@ -163,12 +214,11 @@ composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
     }
     bool all_done = (done[0] & done[1] & done[2] & done[3]) == ~0ull;
     for (int b = 0; b < nb && !all_done; ++b) {
-        // ---- stage this lane's Gaussian: cull, pre-scale the conic by -log2(e) ----
+        // ---- stage this lane's Gaussian: cull per quadrant, pre-scale the conic by -log2(e) ----
         u64 mq[4];
         quadrant_masks(present, r0, r1, r2.z, ox, oy, mq);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (done[q] == ~0ull) mq[q] = 0;            // finished quadrant
+        for (int q = 0; q < 4; ++q) mq[q] = done[q] == ~0ull ? 0ull : uniform_u64(mq[q]);
         u64 km = mq[0] | mq[1] | mq[2] | mq[3];
         const float gx = r0.x, gy = r0.y;
         const float gA = -0.5f * kLog2e * r0.z, gB = -kLog2e * r0.w, gC = -0.5f * kLog2e * r1.x;
@@ -188,27 +238,17 @@ composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
             const u64 bit = 1ull << t;
             km &= ~bit;
             // broadcast Gaussian t: ten v_readlane -> SGPRs
-            const float X = bcast(gx, t), Y = bcast(gy, t), A = bcast(gA, t), B = bcast(gB, t), Cc = bcast(gC, t);
-            const float op = bcast(gop, t);
-            float col[4] = {bcast(gr, t), bcast(gg, t), bcast(gb, t), 0.f};
-            if constexpr (CH == 4) col[3] = bcast(gd, t);
-            const int idx_v = batch_start + t;
+            const f2 XY = {bcast(gx, t), bcast(gy, t)};
+            const f2 AC = {bcast(gA, t), bcast(gC, t)};
+            const float B = bcast(gB, t), op = bcast(gop, t);
+            const f2 col01 = {bcast(gr, t), bcast(gg, t)};
+            const f2 col23 = {bcast(gb, t), CH == 4 ? bcast(gd, t) : 0.f};
+            int idx_v;                                  // one VGPR copy per Gaussian, not per quadrant
+            asm volatile("v_mov_b32 %0, %1" : "=v"(idx_v) : "s"(batch_start + t));
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (!(mq[q] & bit)) continue;           // wave-uniform: this quadrant cannot see Gaussian t
-                const float dx = X - pxs[q & 1], dy = Y - pys[q >> 1];
-                const float p = dx * (A * dx + B * dy) + (Cc * dy) * dy;        // -sigma log2(e)
-                const float a = fminf(kAlphaMax, op * __builtin_amdgcn_exp2f(p));
-                const u64 m_ok = __ballot(p <= 0.f) & __ballot(a >= kAlphaMin) & ~done[q];
-                const float nT = T[q] - T[q] * a;
-                const u64 m_term = m_ok & __ballot(nT <= kTMin);
-                done[q] |= m_term;
-                const u64 m_acc = m_ok & ~m_term;
-                const float w = sel(m_acc, a * T[q], 0.f);
-#pragma unroll
-                for (int k = 0; k < CH; ++k) out[q][k] += col[k] * w;
-                T[q] = sel(m_acc, nT, T[q]);
-                cur[q] = sel(m_acc, idx_v, cur[q]);
+                fwd_quadrant<CH>(pq[q], XY, AC, B, op, col01, col23, idx_v, done[q], px[q]);
                 if (done[q] == ~0ull) {                 // quadrant finished: drop it from the masks
                     mq[q] = 0;
                     km &= mq[0] | mq[1] | mq[2] | mq[3];
@@ -225,19 +265,30 @@ composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
         if (inside[q]) {
             const int ix = tx * QED_TILE + ((q & 1) << 3) + lx, iy = ty * QED_TILE + ((q >> 1) << 3) + ly;
             const size_t pix = ((size_t)cam * height + iy) * width + ix;
+            float out[4] = {px[q].out01.x, px[q].out01.y, px[q].out23.x, px[q].out23.y};
             if (backgrounds != nullptr) {
 #pragma unroll
-                for (int k = 0; k < CH; ++k) out[q][k] += T[q] * backgrounds[cam * CH + k];
+                for (int k = 0; k < CH; ++k) out[k] += px[q].T * backgrounds[cam * CH + k];
             }
             if constexpr (CH == 4) {
-                *reinterpret_cast<float4*>(render + 4 * pix) = make_float4(out[q][0], out[q][1], out[q][2], out[q][3]);
+                *reinterpret_cast<float4*>(render + 4 * pix) = make_float4(out[0], out[1], out[2], out[3]);
             } else {
-                render[3 * pix] = out[q][0]; render[3 * pix + 1] = out[q][1]; render[3 * pix + 2] = out[q][2];
+                render[3 * pix] = out[0]; render[3 * pix + 1] = out[1]; render[3 * pix + 2] = out[2];
             }
-            alpha_out[pix] = 1.f - T[q];
-            last_ids[pix] = cur[q];
+            alpha_out[pix] = 1.f - px[q].T;
+            last_ids[pix] = px[q].cur;
         }
     }
+#ifdef QED_TILE_TIMING
+    // diagnostic build only: duration, start, HW_ID, XCC_ID of this tile's wave in its first four alphas
+    if (lane == 0) {
+        const size_t pix = ((size_t)cam * height + ty * QED_TILE) * width + tx * QED_TILE;
+        alpha_out[pix] = (float)(__builtin_amdgcn_s_memtime() - t_start);
+        alpha_out[pix + 1] = (float)(t_start & 0xFFFFFFFull);
+        alpha_out[pix + 2] = (float)(__builtin_amdgcn_s_getreg(63492) & 0xFFFF);
+        alpha_out[pix + 3] = (float)(__builtin_amdgcn_s_getreg(63508) & 0xF);
+    }
+#endif
 }
 
 // ================================================================================================
@@ -271,6 +322,59 @@ __device__ __forceinline__ void wave_reduce12(const float* v, float* w) {
     }
 }
 
+// per-Gaussian gradient accumulators of one lane (summed over its four pixels)
+struct GradAcc {
+    f2 vxy;        // 0, 1   v_x, v_y
+    float ax, ay;  // 2, 3   |v_x|, |v_y|
+    f2 c01;        // 4, 5   sum v_sigma dx^2 (x 1/2 at flush), sum v_sigma dx dy
+    float c2;      // 6      sum v_sigma dy^2 (x 1/2 at flush)
+    float s0;      // 7      sum v_sigma      (x -1/opacity at flush)
+    f2 rg, bd;     // 8..11  v_r, v_g, v_b, v_depth
+};
+
+struct BwdPixel {
+    float T, bufv;
+    f2 vr01, vr23;
+    int bin_final;
+};
+
+template <int CH>
+__device__ __forceinline__ void bwd_quadrant(f2 pq, f2 XY, f2 AC, float B, float op, f2 cab, f2 cbc, f2 col01, f2 col23,
+                                             int idx, BwdPixel& s, u64& any_valid, GradAcc& g) {
+    const f2 d = XY - pq;
+    const float p = neg_sigma_log2e(d, AC, B);
+    const float vis = __builtin_amdgcn_exp2f(p);
+    const float opv = op * vis;
+    const float a = fminf(kAlphaMax, opv);
+    const u64 m_valid = __ballot(s.bin_final >= idx) & __ballot(p <= 0.f) & __ballot(a >= kAlphaMin);
+    any_valid |= m_valid;
+    // branch-free: an invalid pixel contributes zeros and keeps its state
+    const float ra = __builtin_amdgcn_rcpf(1.f - a);
+    const float Tn = sel(m_valid, s.T * ra, s.T);
+    s.T = Tn;
+    const float fac = sel(m_valid, a * Tn, 0.f);
+    const f2 ff = {fac, fac};
+    f2 cvv = col01 * s.vr01;
+    if constexpr (CH == 4) cvv += col23 * s.vr23;
+    else cvv.x += col23.x * s.vr23.x;
+    const float cv = cvv.x + cvv.y;
+    g.rg += s.vr01 * ff;
+    if constexpr (CH == 4) g.bd += s.vr23 * ff;
+    else g.bd.x += s.vr23.x * fac;
+    const float v_a = Tn * cv - ra * s.bufv;
+    s.bufv = __builtin_fmaf(fac, cv, s.bufv);
+    const u64 m_vs = m_valid & __ballot(opv <= kAlphaMax);
+    const float vs = sel(m_vs, -opv * v_a, 0.f);
+    const f2 sv = d * (f2){vs, vs};                     // (v_sigma dx, v_sigma dy)
+    const f2 v = cab * (f2){sv.x, sv.x} + cbc * (f2){sv.y, sv.y};   // (ca sx + cb sy, cb sx + cc sy)
+    g.vxy += v;
+    g.ax += fabsf(v.x);
+    g.ay += fabsf(v.y);
+    g.c01 += d * (f2){sv.x, sv.x};                      // (sx dx, sx dy)
+    g.c2 = __builtin_fmaf(sv.y, d.y, g.c2);
+    g.s0 += vs;
+}
+
 // vsplat row layout (QED_VSPLAT_FLOATS = 16):
 //  0 v_x  1 v_y  2 |v_x|  3 |v_y|  4 v_conic_a  5 v_conic_b  6 v_conic_c  7 v_opacity  8 v_r  9 v_g  10 v_b  11 v_depth
 // Values 4, 6 and 7 are accumulated un-scaled (sum v_sigma dx^2, sum v_sigma dy^2, sum v_sigma) and
@@ -292,48 +396,49 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
     const int lane = threadIdx.x;
     const int lx = lane & 7, ly = lane >> 3;
     const float ox = (float)(tx * QED_TILE), oy = (float)(ty * QED_TILE);
-    const float pxs[2] = {ox + (float)lx + 0.5f, ox + (float)lx + 8.5f};
-    const float pys[2] = {oy + (float)ly + 0.5f, oy + (float)ly + 8.5f};
 
     const int start = offsets[tile], end = offsets[tile + 1];
     if (end <= start) return;
 
-    float T[4], bufv[4], vr[4][CH];
-    int bin_final[4], quad_last[4];
+    f2 pq[4];
+    BwdPixel px[4];
+    int quad_last[4];
     int tile_last = -1;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int ix = tx * QED_TILE + ((q & 1) << 3) + lx, iy = ty * QED_TILE + ((q >> 1) << 3) + ly;
+        pq[q] = (f2){(float)ix + 0.5f, (float)iy + 0.5f};
         const bool inside = ix < width && iy < height;
         float T_final = 1.f, vra = 0.f;
-        bin_final[q] = -1;
-#pragma unroll
-        for (int k = 0; k < CH; ++k) vr[q][k] = 0.f;
+        float vr[4] = {0.f, 0.f, 0.f, 0.f};
+        px[q].bin_final = -1;
         if (inside) {
             const size_t pix = ((size_t)cam * height + iy) * width + ix;
             T_final = 1.f - render_alpha[pix];
-            bin_final[q] = last_ids[pix];
+            px[q].bin_final = last_ids[pix];
             vra = v_alpha[pix];
             if constexpr (CH == 4) {
                 const float4 t4 = *reinterpret_cast<const float4*>(v_render + 4 * pix);
-                vr[q][0] = t4.x; vr[q][1] = t4.y; vr[q][2] = t4.z; vr[q][3] = t4.w;
+                vr[0] = t4.x; vr[1] = t4.y; vr[2] = t4.z; vr[3] = t4.w;
             } else {
-                vr[q][0] = v_render[3 * pix]; vr[q][1] = v_render[3 * pix + 1]; vr[q][2] = v_render[3 * pix + 2];
+                vr[0] = v_render[3 * pix]; vr[1] = v_render[3 * pix + 1]; vr[2] = v_render[3 * pix + 2];
             }
             if (backgrounds != nullptr) {
                 // render = sum + T_final * bg  ->  d render / d T_final folds into the alpha gradient
                 float acc = 0.f;
 #pragma unroll
-                for (int k = 0; k < CH; ++k) acc += backgrounds[cam * CH + k] * vr[q][k];
+                for (int k = 0; k < CH; ++k) acc += backgrounds[cam * CH + k] * vr[k];
                 vra -= acc;
             }
         }
-        T[q] = T_final;
+        px[q].vr01 = (f2){vr[0], vr[1]};
+        px[q].vr23 = (f2){vr[2], vr[3]};
+        px[q].T = T_final;
         // v_alpha = sum_k (c_k T - buf_k / (1-a)) v_k + T_final / (1-a) v_render_alpha is evaluated as
         // T (c . v) - (buf . v - T_final v_render_alpha) / (1-a): one scalar accumulator per pixel
-        bufv[q] = -T_final * vra;
+        px[q].bufv = -T_final * vra;
         // a pixel that composited nothing has last_id 0 and T_final 1: it only "owns" index 0
-        quad_last[q] = __builtin_amdgcn_readfirstlane(wave_max_i(bin_final[q]));
+        quad_last[q] = __builtin_amdgcn_readfirstlane(wave_max_i(px[q].bin_final));
         tile_last = max(tile_last, quad_last[q]);
     }
     const int eff_end = min(end, tile_last + 1);
@@ -356,6 +461,7 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
         quadrant_masks(rid >= 0, r0, r1, r2.z, ox, oy, mq);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            mq[q] = uniform_u64(mq[q]);
             // lane t holds sorted index batch_hi - t: beyond every pixel of the quadrant -> cannot be valid
             const int t0 = batch_hi - quad_last[q];
             if (t0 >= kBatch) mq[q] = 0;
@@ -378,51 +484,28 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
             const int t = __builtin_ctzll(km);
             const u64 bit = 1ull << t;
             km &= ~bit;
-            const float X = bcast(gx, t), Y = bcast(gy, t);
+            const f2 XY = {bcast(gx, t), bcast(gy, t)};
             const float ca = bcast(gca, t), cb = bcast(gcb, t), cc = bcast(gcc, t), op = bcast(gop, t);
-            const float A = -0.5f * kLog2e * ca, B = -kLog2e * cb, Cc = -0.5f * kLog2e * cc;
-            float col[4] = {bcast(gr, t), bcast(gg, t), bcast(gb, t), 0.f};
-            if constexpr (CH == 4) col[3] = bcast(gd, t);
+            const f2 AC = {-0.5f * kLog2e * ca, -0.5f * kLog2e * cc};
+            const float B = -kLog2e * cb;
+            const f2 cab = {ca, cb}, cbc = {cb, cc};
+            const f2 col01 = {bcast(gr, t), bcast(gg, t)};
+            const f2 col23 = {bcast(gb, t), CH == 4 ? bcast(gd, t) : 0.f};
             const int idx = batch_hi - t;
-            float g[12];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) g[k] = 0.f;
+            GradAcc g;
+            g.vxy = g.c01 = g.rg = g.bd = (f2){0.f, 0.f};
+            g.ax = g.ay = g.c2 = g.s0 = 0.f;
             u64 any_valid = 0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (!(mq[q] & bit)) continue;           // wave-uniform: this quadrant cannot see Gaussian t
-                const float dx = X - pxs[q & 1], dy = Y - pys[q >> 1];
-                const float p = dx * (A * dx + B * dy) + (Cc * dy) * dy;        // -sigma log2(e)
-                const float vis = __builtin_amdgcn_exp2f(p);
-                const float opv = op * vis;
-                const float a = fminf(kAlphaMax, opv);
-                const u64 m_valid = __ballot(bin_final[q] >= idx) & __ballot(p <= 0.f) & __ballot(a >= kAlphaMin);
-                any_valid |= m_valid;
-                // branch-free: an invalid pixel contributes zeros and keeps its state
-                const float ra = __builtin_amdgcn_rcpf(1.f - a);
-                const float Tn = sel(m_valid, T[q] * ra, T[q]);
-                T[q] = Tn;
-                const float fac = sel(m_valid, a * Tn, 0.f);
-                float cv = 0.f;
-#pragma unroll
-                for (int k = 0; k < CH; ++k) {
-                    cv += col[k] * vr[q][k];
-                    g[8 + k] += fac * vr[q][k];
-                }
-                const float v_a = Tn * cv - ra * bufv[q];
-                bufv[q] += fac * cv;
-                const u64 m_vs = m_valid & __ballot(opv <= kAlphaMax);
-                const float v_sigma = sel(m_vs, -opv * v_a, 0.f);
-                const float sx = v_sigma * dx, sy = v_sigma * dy;
-                const float vx = ca * sx + cb * sy, vy = cb * sx + cc * sy;
-                g[0] += vx; g[1] += vy;
-                g[2] += fabsf(vx); g[3] += fabsf(vy);
-                g[4] += sx * dx; g[5] += sx * dy; g[6] += sy * dy;
-                g[7] += v_sigma;
+                bwd_quadrant<CH>(pq[q], XY, AC, B, op, cab, cbc, col01, col23, idx, px[q], any_valid, g);
             }
             if (any_valid == 0) continue;
+            const float gv[12] = {g.vxy.x, g.vxy.y, g.ax, g.ay, g.c01.x, g.c01.y, g.c2, g.s0,
+                                  g.rg.x, g.rg.y, g.bd.x, g.bd.y};
             float w[3];
-            wave_reduce12(g, w);
+            wave_reduce12(gv, w);
             // lanes 0,16,32,48 park the totals: row r holds value (r==0?0 : r==1?2 : r==2?1 : 3) + 4j
             if ((lane & 15) == 0) {
                 const int r = lane >> 4;
@@ -431,7 +514,7 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
                 s_acc[t][vbase + 4] = w[1];
                 s_acc[t][vbase + 8] = w[2];
             }
-            touched |= 1ull << t;
+            touched |= bit;
         }
         __syncthreads();                                // single wave: orders the LDS parking vs the flush
         // flush: 16 lanes per Gaussian, 4 Gaussians per instruction -> one 64-byte row per request
