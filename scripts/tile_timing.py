@@ -45,3 +45,33 @@ for k in key.unique().tolist()[:4000]:
     mx.append(best)
 mx = np.array(mx)
 print("tiles per SIMD: mean %.2f" % (len(key) / key.unique().numel()), " max concurrent waves per SIMD: mean %.2f max %d hist %s" % (mx.mean(), mx.max(), np.bincount(mx).tolist()))
+# per-XCD activity profile (clocks are per XCD)
+for x in range(8):
+    m = xcc == x
+    st = t0r[m].numpy().copy()
+    med = np.median(st)
+    st[st - med > 2 ** 23] -= 2 ** 24                  # unwrap the 24-bit start stamps around the median
+    st[med - st > 2 ** 23] += 2 ** 24
+    en = st + dur[m].numpy()
+    base = st.min()
+    span = en.max() - base
+    bins = np.linspace(base, en.max(), 13)
+    act = [int(((st < b1) & (en > b0)).sum()) for b0, b1 in zip(bins[:-1], bins[1:])]
+    print(f"xcc {x}: tiles {int(m.sum())} span {span:.0f} cycles; active waves per 1/12 of the span: {act}")
+# per-CU profile: spans within one CU share a clock for sure
+cu_key = key // 4
+spans = []; occ = []
+for k in cu_key.unique().tolist():
+    m = cu_key == k
+    st = t0r[m].numpy().copy(); med = np.median(st)
+    st[st - med > 2 ** 23] -= 2 ** 24; st[med - st > 2 ** 23] += 2 ** 24
+    en = st + dur[m].numpy()
+    spans.append(en.max() - st.min()); occ.append(dur[m].sum().item() / (en.max() - st.min()))
+spans = np.array(spans); occ = np.array(occ)
+print("per-CU span: mean %.0f min %.0f max %.0f cycles; mean concurrent waves per CU %.2f (min %.2f max %.2f)" % (spans.mean(), spans.min(), spans.max(), occ.mean(), occ.min(), occ.max()))
+k0 = cu_key.unique().tolist()[5]
+m = cu_key == k0
+st = t0r[m].numpy().copy(); med = np.median(st); st[st - med > 2 ** 23] -= 2 ** 24; st[med - st > 2 ** 23] += 2 ** 24
+o = np.argsort(st)
+print("one CU: starts (relative)", (st[o] - st.min()).astype(int).tolist()[:40])
+print("one CU: durs", dur[m].numpy()[o].astype(int).tolist()[:40])
