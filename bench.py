@@ -223,11 +223,24 @@ def main():
         dom_ms = kern.get(dom, (0, float("nan")))[1]
         alg_bytes = 92.0 * M + 28.0 * P
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+        # HBM traffic of that kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
+        # cannot share a pass, and counters cannot be read from inside this process): per launch, with the
+        # guide's gfx950 correction (FETCH_SIZE doubled); null if the profile is not for this workload.
+        traffic = None
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")))
+            kk = prof["kernels"]["qed::composite_bwd_kernel<4>"]
+            if (n, w, h) == (500_000, 1920, 1080):
+                traffic = (2.0 * kk["fetch_size_kb"] + kk["write_size_kb"]) * 1024.0
+        except (OSError, KeyError, ValueError):
+            pass
         roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                "frac": achieved / 8000.0, "traffic": None,
+                "frac": achieved / 8000.0, "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": dom_ms,
-                "note": "compositing is VALU/LDS/atomic-bound (256 exp-evaluations per 44 B loaded); HBM frac "
-                        "is reported as north_star asks, see DESIGN.md"}
+                "note": "algorithmic bytes = 92 B x M + 28 B x P (SURVEY 8d).  The kernel is VALU-issue bound, not "
+                        "HBM bound: ~45 VALU instructions per pixel-Gaussian pair against 44 B per 256 pairs; "
+                        "measured traffic is BELOW the algorithmic bytes because culled / early-terminated list "
+                        "entries are never gathered.  See DESIGN.md section 7 for the VALU-side roofline."}
         out = {
             "metric": "train iters/sec @ 1080p, 500k Gaussians (fwd + loss + bwd + Adam; camera-steps/s over all GPUs)",
             "value": world * args.steps / dt2, "unit": "iters/s", "n_gpus": world, "steps": args.steps,

@@ -535,3 +535,52 @@ def test_graphed_step_matches_eager(cuda):
         torch.cuda.synchronize()
     assert_close(m2.flat_params, m1.flat_params, 1e-5, "parameters after 6 steps (graph vs eager)")
     assert math.isfinite(float(out["main_loss"])) and float(o2.dev_state[0]) == 6.0
+
+
+def test_one_stage_entry_points_match_two_stage(cuda, lib):
+    """qed_isect_scan + qed_isect_emit + qed_sort_pairs (64-bit keys) + qed_tile_offsets -- the one-stage
+    decomposition still exported by the C ABI -- give exactly the list that qed_bin_tiles produces."""
+    w, h, n, n_cam = 200, 136, 5000, 2
+    sc = scene(n, w, h, seed=13, n_cameras=n_cam)
+    _, _, _, info = _raster_gpu(sc, cuda, w, h)
+    tw, th = info["tile_width"], info["tile_height"]
+    n_tiles = tw * th
+    tb = int(math.floor(math.log2(n_tiles))) + 1
+    M = info["n_isects"]
+    cap = M + 1000
+    st = torch.cuda.current_stream().cuda_stream
+    tpg = info["tiles_per_gauss"].reshape(-1)
+    n_blocks = (n_cam * n + 255) // 256
+    block_sums = torch.nn.functional.pad(tpg, (0, n_blocks * 256 - tpg.numel())).view(n_blocks, 256).sum(1).int()
+    block_offsets = torch.empty(n_blocks, dtype=torch.int32, device=cuda)
+    n_isect = torch.zeros(1, dtype=torch.int32, device=cuda)
+    status = torch.zeros(4, dtype=torch.int32, device=cuda)
+    keys_a = torch.empty(cap, dtype=torch.int64, device=cuda)
+    keys_b = torch.empty_like(keys_a)
+    vals_a = torch.empty(cap, dtype=torch.int32, device=cuda)
+    vals_b = torch.empty_like(vals_a)
+    ws = torch.empty(int(lib.qed_sort_workspace_bytes(cap)), dtype=torch.uint8, device=cuda)
+    offsets = torch.empty(n_cam * n_tiles + 1, dtype=torch.int32, device=cuda)
+    assert lib.qed_isect_scan(block_sums.data_ptr(), n_blocks, block_offsets.data_ptr(), n_isect.data_ptr(), cap,
+                              status.data_ptr(), st) == 0
+    assert lib.qed_isect_emit(n, n_cam, info["means2d"].data_ptr(), info["radii"].data_ptr(), info["depths"].data_ptr(),
+                              tpg.data_ptr(), block_offsets.data_ptr(), tw, th, tb, n_isect.data_ptr(), cap,
+                              keys_a.data_ptr(), vals_a.data_ptr(), st) == 0
+    cam_bits = 1
+    which = lib.qed_sort_pairs(keys_a.data_ptr(), vals_a.data_ptr(), keys_b.data_ptr(), vals_b.data_ptr(),
+                               n_isect.data_ptr(), cap, 32 + tb + cam_bits, ws.data_ptr(), ws.numel(),
+                               status.data_ptr(), st)
+    assert which in (0, 1)
+    keys, vals = (keys_b, vals_b) if which else (keys_a, vals_a)
+    assert lib.qed_tile_offsets(keys.data_ptr(), n_isect.data_ptr(), cap, n_cam, n_tiles, tb, offsets.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert int(n_isect) == M and int(status[0]) == 0
+    assert torch.equal(keys[:M], info["isect_ids"])
+    assert torch.equal(vals[:M], info["flatten_ids"])
+    assert torch.equal(offsets[:-1].view(n_cam, th, tw), info["isect_offsets"]) and int(offsets[-1]) == M
+    # capacity overflow is reported, not written past the buffer
+    status.zero_()
+    assert lib.qed_isect_scan(block_sums.data_ptr(), n_blocks, block_offsets.data_ptr(), n_isect.data_ptr(), M - 1,
+                              status.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert int(status[0]) == M and int(n_isect) == 0
