@@ -136,7 +136,7 @@ def main():
         for p in model.parameters():
             p.grad = None
         losses = model.fused_loss(cam, batch, background=bg, sync=sync)
-        (losses["main_loss"] + losses["depth_loss"]).backward()
+        losses["loss"].backward()
         if world > 1:
             allreduce_flat_grad(model, world)
         opt.step()
@@ -189,7 +189,7 @@ def main():
             for p in model.parameters():
                 p.grad = None
             losses = model.fused_loss(cam, batch, background=bg, sync=False)
-            (losses["main_loss"] + losses["depth_loss"]).backward()
+            losses["loss"].backward()
             if world > 1:
                 allreduce_flat_grad(model, world)
             opt.step(device_state=True)

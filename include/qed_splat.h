@@ -51,6 +51,12 @@ const char* qed_last_error(void);
  * [1] != 0 -> radix-sort look-back watchdog fired. */
 #define QED_STATUS_WORDS 4
 
+/* ---- a1/a3: camera setup in one launch --------------------------------------------------------
+ * get_viewmat (model.py:22-38): c2w[C,3,4] (OpenGL) -> viewmats[C,4,4] = rigid inverse after flipping
+ * the y/z columns of R; intrinsics[C,4] = (fx, fy, cx, cy) -> Ks[C,3,3] (model.py:247). */
+int qed_camera_setup(int32_t C, const float* c2w, const float* intrinsics, float* viewmats, float* Ks,
+                     void* stream);
+
 /* ---- K1+K2: projection + SH colour, fused ------------------------------------------------
  * Replaces, inside rasterization() (model.py:267-288): world->camera, 3D covariance from
  * quat+scale, EWA 2D covariance + eps2d blur, conic, radius, near/far/frustum culling
@@ -164,7 +170,8 @@ int qed_composite_bwd(int32_t C, int32_t N, const float* splats, const int32_t* 
  * Pass 1 (qed_loss_reduce) produces sums[0..3] = {sum |rgb-gt|, sum |d-dgt| over valid, n_valid,
  * max depth}; pass 2 (qed_loss_grad) writes v_render[H,W,channels] and v_alpha[H,W] for
  *   loss = rgb_weight * mean|rgb - gt| + depth_lambda * sum|d - dgt| / n_valid
- * and the scalar losses -> losses[0..1].  mask[H,W] may be NULL (model.py:93-97). */
+ * and the scalar losses -> losses[0..2] = {rgb term, depth term, their sum}.  mask[H,W] may be
+ * NULL (model.py:93-97). */
 int qed_loss_reduce(int32_t n_pix, int32_t channels, const float* render, const float* alpha,
                     const float* background, const float* gt_rgb, const float* gt_depth,
                     const float* mask, float* sums, void* stream);

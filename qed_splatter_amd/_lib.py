@@ -24,6 +24,7 @@ _U = C.c_uint32
 SIGNATURES = {
     "qed_version": (C.c_int, []),
     "qed_last_error": (C.c_char_p, []),
+    "qed_camera_setup": (C.c_int, [_I, _P, _P, _P, _P, _P]),
     "qed_project_fwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _F, _F, _F,
                                   _F, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qed_project_bwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _I, _F, _U, _P, _P, _P,

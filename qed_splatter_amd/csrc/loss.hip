@@ -151,6 +151,7 @@ __global__ void loss_finalize_kernel(int n_pix, const float* __restrict__ sums, 
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         losses[0] = rgb_weight * sums[0] / (3.f * (float)n_pix);
         losses[1] = sums[2] > 0.f ? depth_lambda * sums[1] / sums[2] : 0.f;    // empty -> 0.0 (model.py:111-114)
+        losses[2] = losses[0] + losses[1];
     }
 }
 

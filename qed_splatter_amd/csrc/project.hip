@@ -582,9 +582,47 @@ project_bwd_kernel(int N, int C, const float* __restrict__ means, const float* _
     }
 }
 
+// ---- a1 + a3 in one launch: get_viewmat (model.py:22-38) and the intrinsics matrix -----------------
+// c2w[C,3,4] (OpenGL camera-to-world) -> viewmats[C,4,4]: flip the y/z columns of R, then the analytic
+// rigid inverse (R^T, -R^T t); intr[C,4] = (fx, fy, cx, cy) -> Ks[C,3,3].
+__global__ void camera_setup_kernel(int C, const float* __restrict__ c2w, const float* __restrict__ intr,
+                                    float* __restrict__ viewmats, float* __restrict__ Ks) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float* m = c2w + 12 * c;
+    float R[9], t[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        R[3 * i] = m[4 * i];
+        R[3 * i + 1] = -m[4 * i + 1];
+        R[3 * i + 2] = -m[4 * i + 2];
+        t[i] = m[4 * i + 3];
+    }
+    float* V = viewmats + 16 * c;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) V[4 * i + j] = R[3 * j + i];                     // R^T
+        V[4 * i + 3] = -(R[i] * t[0] + R[3 + i] * t[1] + R[6 + i] * t[2]);           // -R^T t
+    }
+    V[12] = 0.f; V[13] = 0.f; V[14] = 0.f; V[15] = 1.f;
+    float* K = Ks + 9 * c;
+    K[0] = intr[4 * c]; K[1] = 0.f; K[2] = intr[4 * c + 2];
+    K[3] = 0.f; K[4] = intr[4 * c + 1]; K[5] = intr[4 * c + 3];
+    K[6] = 0.f; K[7] = 0.f; K[8] = 1.f;
+}
+
 }  // namespace qed
 
 using namespace qed;
+
+extern "C" int qed_camera_setup(int32_t C, const float* c2w, const float* intrinsics, float* viewmats, float* Ks,
+                                void* stream) {
+    QED_REQUIRE(C >= 1 && c2w && intrinsics && viewmats && Ks, "bad arguments");
+    hipLaunchKernelGGL(camera_setup_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, C, c2w, intrinsics,
+                       viewmats, Ks);
+    return check_launch("qed_camera_setup");
+}
 
 extern "C" int qed_project_fwd(int32_t N, int32_t C, const float* means, const float* quats, const float* scales,
                                const float* opacities, const float* sh0, int32_t sh0_stride, const float* shN,

@@ -91,6 +91,13 @@ class PinholeCameras:
     def shape(self):
         return self.camera_to_worlds.shape[:1]
 
+    def intrinsics_fxfycxcy(self) -> Tensor:
+        """[C,4] device tensor (fx, fy, cx, cy), cached until the next rescale: the input of
+        qed_camera_setup on the fused path."""
+        if getattr(self, "_intr", None) is None:
+            self._intr = torch.cat([self.fx, self.fy, self.cx, self.cy], dim=1).to(torch.float32).contiguous()
+        return self._intr
+
     def get_intrinsics_matrices(self) -> Tensor:
         K = torch.zeros(self.shape[0], 3, 3, device=self.fx.device)
         K[:, 0, 0] = self.fx[:, 0]
@@ -107,6 +114,7 @@ class PinholeCameras:
         self.cy = self.cy * s
         self.width = (self.width * s).to(torch.int64)
         self.height = (self.height * s).to(torch.int64)
+        self._intr = None
 
 
 GROUP_ORDER = ("means", "scales", "quats", "opacities", "features_dc", "features_rest")
@@ -128,7 +136,7 @@ class _FusedImageLoss(torch.autograd.Function):
         dev = render.device
         n_pix = H * W
         sums = torch.empty(4, dtype=torch.float32, device=dev)
-        losses = torch.empty(2, dtype=torch.float32, device=dev)
+        losses = torch.empty(3, dtype=torch.float32, device=dev)       # rgb term, depth term, total
         v_render = torch.empty_like(render)
         v_alpha = torch.empty_like(alpha)
         st = _stream()
@@ -137,13 +145,15 @@ class _FusedImageLoss(torch.autograd.Function):
         L.check(lib.qed_loss_grad(*args, L.ptr(sums), rgb_weight, depth_lambda, L.ptr(v_render), L.ptr(v_alpha),
                                   L.ptr(losses), st), "qed_loss_grad")
         ctx.save_for_backward(v_render, v_alpha)
-        return losses
+        total = losses[2:3].view(())
+        parts = losses[0:2]
+        ctx.mark_non_differentiable(parts)
+        return total, parts
 
     @staticmethod
-    def backward(ctx, v_losses):
+    def backward(ctx, v_total, _v_parts):
         v_render, v_alpha = ctx.saved_tensors
-        # both loss terms enter the total with weight 1 (loss = sum of loss_dict values); a caller
-        # that scales them differently goes through the API-compatible path instead
+        # the kernel wrote d(total)/d(render, alpha); the usual upstream gradient 1.0 needs no scaling pass
         return v_render, v_alpha, None, None, None, None, None, None
 
 
@@ -394,12 +404,23 @@ class QEDSplatterModel(nn.Module):
 
     # ---- fused training step: model.py:199-321 + 73-118 in as few passes as possible ----
     def fused_loss(self, camera, batch, background: Optional[Tensor] = None, sync: bool = True) -> Dict[str, Tensor]:
-        """Forward + K8 fused loss.  Returns {"main_loss", "depth_loss"} whose sum backpropagates
-        into the parameter ``.grad``s; numerically the same quantities as get_outputs + get_loss_dict."""
+        """Forward + K8 fused loss.  Returns {"loss", "main_loss", "depth_loss"}: ``loss`` = main + depth is
+        the differentiable total (call ``.backward()`` on it as is: the kernel already wrote its gradient
+        for an upstream gradient of 1); the two parts are detached views for logging.  Numerically the
+        same quantities as get_outputs + get_loss_dict."""
         assert camera.shape[0] == 1, "Only one camera at a time"
         cfg = self.config
-        viewmat = get_viewmat(camera.camera_to_worlds).to(torch.float32)
-        K = camera.get_intrinsics_matrices().to(self.device, torch.float32)
+        intr = getattr(camera, "intrinsics_fxfycxcy", None)
+        if intr is not None and camera.camera_to_worlds.dtype == torch.float32:
+            # a1 + a3 in one launch (qed_camera_setup) instead of ~15 tiny eager kernels
+            c2w = camera.camera_to_worlds.contiguous()
+            viewmat = torch.empty(1, 4, 4, dtype=torch.float32, device=self.device)
+            K = torch.empty(1, 3, 3, dtype=torch.float32, device=self.device)
+            L.check(L.load().qed_camera_setup(1, L.ptr(c2w), L.ptr(intr()), L.ptr(viewmat), L.ptr(K), _stream()),
+                    "qed_camera_setup")
+        else:
+            viewmat = get_viewmat(camera.camera_to_worlds).to(torch.float32)
+            K = camera.get_intrinsics_matrices().to(self.device, torch.float32)
         W, H = int(camera.width[0]), int(camera.height[0])
         self.last_size = (H, W)
         flags = L.F_LOG_SCALES | L.F_LOGIT_OPAC
@@ -421,10 +442,10 @@ class QEDSplatterModel(nn.Module):
         gt_depth = batch["depth_image"]
         mask = batch.get("mask")
         assert gt_rgb.dtype == torch.float32 and gt_rgb.is_contiguous() and gt_depth.is_contiguous()
-        losses = _FusedImageLoss.apply(render, alpha, bg.contiguous(), gt_rgb, gt_depth,
-                                       mask.contiguous() if mask is not None else None,
-                                       1.0 - cfg.ssim_lambda, cfg.depth_lambda)
-        return {"main_loss": losses[0], "depth_loss": losses[1]}
+        total, parts = _FusedImageLoss.apply(render, alpha, bg.contiguous(), gt_rgb, gt_depth,
+                                             mask.contiguous() if mask is not None else None,
+                                             1.0 - cfg.ssim_lambda, cfg.depth_lambda)
+        return {"loss": total, "main_loss": parts[0], "depth_loss": parts[1]}
 
 
 class FlatAdam:

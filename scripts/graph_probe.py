@@ -34,7 +34,7 @@ def step():
         return {"x": r.sum()}
     losses = model.fused_loss(cam, batch, background=bg, sync=False)
     if variant == "fwd": return losses
-    (losses["main_loss"] + losses["depth_loss"]).backward()
+    losses["loss"].backward()
     if variant == "bwd": return losses
     opt.step(device_state=True)
     return losses

@@ -50,7 +50,7 @@ def main():
         losses = model.fused_loss(cam, batch, sync=not (a.async_m and it > 0))
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        (losses["main_loss"] + losses["depth_loss"]).backward()
+        losses["loss"].backward()
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         opt.step()

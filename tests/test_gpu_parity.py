@@ -389,7 +389,7 @@ def test_fused_path_equals_api_path(cuda):
     m2, cam2, batch2 = _model(sc, cuda)
     batch2["mask"] = mask.to(cuda)
     lf = m2.fused_loss(cam2, batch2)
-    (lf["main_loss"] + lf["depth_loss"]).backward()
+    lf["loss"].backward()
     assert abs(float(lf["main_loss"]) - float(ld["main_loss"])) <= 2e-6 * abs(float(ld["main_loss"])) + 1e-9
     assert abs(float(lf["depth_loss"]) - float(ld["depth_loss"])) <= 2e-6 * abs(float(ld["depth_loss"])) + 1e-9
     for name in PARAM_NAMES:
@@ -448,7 +448,7 @@ def test_fused_adam_matches_torch(cuda):
         for p in m.parameters():
             p.grad = None
         lf = m.fused_loss(cam, batch)
-        (lf["main_loss"] + lf["depth_loss"]).backward()
+        lf["loss"].backward()
         for k in PARAM_NAMES:
             ref_params[k].grad = m.gauss_params[k].grad.detach().clone()
         opt.step()
@@ -521,7 +521,7 @@ def test_graphed_step_matches_eager(cuda):
                 for p in m.parameters():
                     p.grad = None
                 lf = m.fused_loss(cam, batch, sync=False)
-                (lf["main_loss"] + lf["depth_loss"]).backward()
+                lf["loss"].backward()
                 opt.step(device_state=True)
                 return lf
             return step
