@@ -74,7 +74,7 @@ def cpu_baseline(args):
         ps = {k: sc[k].clone().requires_grad_(True) for k in names}
         out = O.splatfacto_outputs(ps["means"], ps["scales"], ps["quats"], ps["opacities"], ps["features_dc"],
                                    ps["features_rest"], sc["camera_to_worlds"], sc["Ks"], w, h, sc["background"])
-        loss = 0.8 * O.rgb_l1_loss(out["rgb"], sc["gt_rgb"]) + O.depth_l1_loss(out["depth"], sc["gt_depth"])
+        loss = O.main_loss(out["rgb"], sc["gt_rgb"], 0.2) + O.depth_l1_loss(out["depth"], sc["gt_depth"])
         loss.backward()
         return out["info"]["flatten_ids"].numel()
 

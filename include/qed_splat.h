@@ -167,18 +167,36 @@ int qed_composite_bwd(int32_t C, int32_t N, const float* splats, const int32_t* 
 /* ---- K8: fused image-space loss + gradient ------------------------------------------------------
  * Collapses model.py:295-297 (background composite + clamp), :304-306 (depth fix-up), :87-116
  * (masked depth-L1, depth_lambda) and the L1 part of the parent's RGB loss into one pass.
- * Pass 1 (qed_loss_reduce) produces sums[0..3] = {sum |rgb-gt|, sum |d-dgt| over valid, n_valid,
- * max depth}; pass 2 (qed_loss_grad) writes v_render[H,W,channels] and v_alpha[H,W] for
+ * Pass 1 (qed_loss_reduce) fills sums[8] (only {n_valid, max depth} are needed before gradients;
+ * the two loss sums are accumulated by pass 2); pass 2 (qed_loss_grad) writes v_render[H,W,channels] and v_alpha[H,W] for
  *   loss = rgb_weight * mean|rgb - gt| + depth_lambda * sum|d - dgt| / n_valid
  * and the scalar losses -> losses[0..2] = {rgb term, depth term, their sum}.  mask[H,W] may be
- * NULL (model.py:93-97). */
+ * NULL (model.py:93-97).  An additional term on the same clamped colour (the SSIM part of the
+ * parent's loss, qed_ssim_* below) enters through v_rgb_extra[H,W,3] = its gradient w.r.t. rgb and
+ * extra_sum: losses[0] += extra_offset + extra_scale * extra_sum[0]; both pointers may be NULL. */
 int qed_loss_reduce(int32_t n_pix, int32_t channels, const float* render, const float* alpha,
                     const float* background, const float* gt_rgb, const float* gt_depth,
                     const float* mask, float* sums, void* stream);
 int qed_loss_grad(int32_t n_pix, int32_t channels, const float* render, const float* alpha,
                   const float* background, const float* gt_rgb, const float* gt_depth,
                   const float* mask, const float* sums, float rgb_weight, float depth_lambda,
-                  float* v_render, float* v_alpha, float* losses, void* stream);
+                  float* v_render, float* v_alpha, float* losses, const float* v_rgb_extra,
+                  const float* extra_sum, float extra_scale, float extra_offset, void* stream);
+
+/* ---- SSIM term of the parent's RGB loss (reached from model.py:83-85) ----------
+ * pytorch_msssim semantics: data_range 1, 11-tap Gaussian window (sigma 1.5) applied separably with
+ * no padding, K = (0.01, 0.03), mean over the (H-10) x (W-10) map and 3 channels.
+ * pred is either a plain [H,W,3] image (alpha == NULL) or the compositor's render[H,W,channels]
+ * together with alpha[H,W] and background[3], in which case the colour clamp(render + (1-alpha) bg)
+ * of model.py:296-297 is formed on the fly.  qed_ssim_fwd writes ssim_sum[0] = sum of the SSIM map
+ * (SSIM = ssim_sum / (3 (H-10)(W-10))) and the coefficient maps (qed_ssim_maps_floats floats) that
+ * qed_ssim_bwd turns into v_pred[H,W,3] = scale * d ssim_sum / d colour. */
+int64_t qed_ssim_maps_floats(int32_t height, int32_t width);
+int qed_ssim_fwd(int32_t height, int32_t width, int32_t channels, const float* pred, const float* alpha,
+                 const float* background, const float* gt_rgb, float* maps, float* ssim_sum, void* stream);
+int qed_ssim_bwd(int32_t height, int32_t width, int32_t channels, const float* pred, const float* alpha,
+                 const float* background, const float* gt_rgb, const float* maps, float scale,
+                 float* v_pred, void* stream);
 
 /* ---- fused multi-tensor Adam over one flat parameter buffer (config.py:44-68) --
  * n_groups contiguous segments; segment g covers elements [h_group_begin[g], h_group_begin[g+1])

@@ -477,9 +477,60 @@ def depth_l1_loss(depth_out: Tensor, depth_gt: Tensor, mask: Optional[Tensor] = 
 
 
 def rgb_l1_loss(rgb: Tensor, gt: Tensor) -> Tensor:
-    """L1 part of the parent's main loss (SplatfactoModel.get_loss_dict, upstream).  The
-    (1 - SSIM) part is SURVEY section 8(f) rank 1 ("next"), not yet on the built path."""
+    """L1 part of the parent's main loss (SplatfactoModel.get_loss_dict, upstream)."""
     return torch.abs(gt - rgb).mean()
+
+
+def ssim_window(size: int = 11, sigma: float = 1.5, dtype=torch.float64) -> Tensor:
+    """pytorch_msssim _fspecial_gauss_1d: exp(-(i - size//2)^2 / (2 sigma^2)), normalised to sum 1.
+    (The library evaluates it in fp32; the oracle keeps whatever dtype it is asked for.)"""
+    coords = torch.arange(size, dtype=dtype) - size // 2
+    g = torch.exp(-(coords ** 2) / (2 * sigma ** 2))
+    return g / g.sum()
+
+
+def ssim(pred: Tensor, gt: Tensor, return_map: bool = False):
+    """SSIM term of the parent's main loss.  SplatfactoModel builds
+    ``SSIM(data_range=1.0, size_average=True, channel=3)`` from pytorch_msssim (un-vendored; the
+    reference reaches it through super().get_loss_dict at model.py:83-85), i.e.
+
+      * the 11-tap Gaussian window (sigma 1.5) applied separably along H then W with NO padding,
+      * mu = G*x, var = G*x^2 - mu^2, cov = G*xy - mu_x mu_y,
+      * ssim_map = (2 mu_x mu_y + C1)/(mu_x^2 + mu_y^2 + C1) * (2 cov + C2)/(var_x + var_y + C2),
+        C1 = 0.01^2, C2 = 0.03^2,
+      * mean over the (H-10) x (W-10) map per channel, then over channels.
+
+    pred, gt: [H,W,3].  Restated from the published definition; PARITY UNPINNED against the library
+    itself (pytorch_msssim is not installed here), pinned only by the closed-form cases in
+    tests/test_oracle_cpu.py (identical images -> 1, constant images -> luminance term)."""
+    import torch.nn.functional as F
+    H, W, C = pred.shape
+    win = ssim_window(dtype=pred.dtype)
+    x = pred.permute(2, 0, 1)[None]                       # [1,C,H,W]
+    y = gt.to(pred.dtype).permute(2, 0, 1)[None]
+
+    def gf(t):
+        k = win.view(1, 1, -1, 1).expand(C, 1, -1, 1)
+        t = F.conv2d(t, k, groups=C)                      # along H
+        return F.conv2d(t, k.transpose(2, 3), groups=C)   # along W
+
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    mu1, mu2 = gf(x), gf(y)
+    s11 = gf(x * x) - mu1 * mu1
+    s22 = gf(y * y) - mu2 * mu2
+    s12 = gf(x * y) - mu1 * mu2
+    cs = (2 * s12 + C2) / (s11 + s22 + C2)
+    smap = ((2 * mu1 * mu2 + C1) / (mu1 * mu1 + mu2 * mu2 + C1)) * cs
+    val = smap.flatten(2).mean(-1).mean()
+    return (val, smap[0].permute(1, 2, 0)) if return_map else val
+
+
+def main_loss(rgb: Tensor, gt: Tensor, ssim_lambda: float = 0.2) -> Tensor:
+    """SplatfactoModel main loss: (1 - l) * L1 + l * (1 - SSIM)."""
+    out = (1 - ssim_lambda) * rgb_l1_loss(rgb, gt)
+    if ssim_lambda > 0:
+        out = out + ssim_lambda * (1 - ssim(rgb, gt))
+    return out
 
 
 # ----------------------------------------------------------------------------------

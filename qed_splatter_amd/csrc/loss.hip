@@ -57,56 +57,57 @@ __device__ __forceinline__ PixelEval eval_pixel(const float* __restrict__ render
     return p;
 }
 
-// sums: [0] sum |rgb - gt|   [1] sum |depth - gt| over valid (filled by the grad pass)
-//       [2] n_valid           [3] max depth as ordered int (bit pattern)
+// sums: [0] sum |rgb - gt|   [1] sum |depth - gt| over valid   [2] n_valid   [3] max depth (ordered int bits)
+//       [4] workgroups of the gradient pass that have finished (last one writes the losses)
+//
+// Pass 1 only needs what must be known BEFORE a gradient can be written: the number of valid depth
+// pixels (its reciprocal scales every depth gradient) and the largest rendered depth (the value
+// alpha == 0 pixels take, model.py:306).  It reads the depth channel, the ground-truth depth and the
+// mask -- not the colours.
 template <int CH>
 __global__ void __launch_bounds__(256)
 loss_reduce_kernel(int n_pix, const float* __restrict__ render, const float* __restrict__ alpha,
                    const float* __restrict__ bg, const float* __restrict__ gt_rgb, const float* __restrict__ gt_depth,
                    const float* __restrict__ mask, float* __restrict__ sums) {
-    float l1 = 0.f, nv = 0.f;
+    if constexpr (CH != 4) return;
+    float nv = 0.f;
     float dmax = -3.0e38f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n_pix; i += (size_t)gridDim.x * 256) {
-        const PixelEval p = eval_pixel<CH>(render, alpha, bg, i);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) l1 += fabsf(p.rgb[k] - gt_rgb[3 * i + k]);
-        if constexpr (CH == 4) {
-            dmax = fmaxf(dmax, p.d_render);
-            const float m = mask ? mask[i] : 1.f;
-            const float dg = gt_depth[i] * m;
-            // the predicted depth is finite whenever the render is; NaN renders fail isfinite below
-            const float dp = p.d_render * m;
-            if (isfinite(dp) && isfinite(dg) && dg > 0.f) nv += 1.f;
-        }
+        const float d = render[4 * i + 3];
+        dmax = fmaxf(dmax, d);
+        const float m = mask ? mask[i] : 1.f;
+        const float dg = gt_depth[i] * m;
+        // the predicted depth is finite whenever the render is; NaN renders fail isfinite below
+        const float dp = d * m;
+        if (isfinite(dp) && isfinite(dg) && dg > 0.f) nv += 1.f;
     }
-    l1 = wave_sum(l1);
     nv = wave_sum(nv);
     dmax = wave_max(dmax);
-    __shared__ float s[3][4];
+    __shared__ float s[2][4];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if (lane == 0) { s[0][wid] = l1; s[1][wid] = nv; s[2][wid] = dmax; }
+    if (lane == 0) { s[0][wid] = nv; s[1][wid] = dmax; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(&sums[0], s[0][0] + s[0][1] + s[0][2] + s[0][3]);
-        if constexpr (CH == 4) {
-            atomicAdd(&sums[2], s[1][0] + s[1][1] + s[1][2] + s[1][3]);
-            const float m = fmaxf(fmaxf(s[2][0], s[2][1]), fmaxf(s[2][2], s[2][3]));
-            atomicMax(reinterpret_cast<int*>(&sums[3]), float_to_ordered(m));
-        }
+        atomicAdd(&sums[2], s[0][0] + s[0][1] + s[0][2] + s[0][3]);
+        const float m = fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3]));
+        atomicMax(reinterpret_cast<int*>(&sums[3]), float_to_ordered(m));
     }
 }
 
+// Pass 2: gradients, the two loss sums, and -- by the last workgroup to finish -- the scalar losses.
 template <int CH>
 __global__ void __launch_bounds__(256)
 loss_grad_kernel(int n_pix, const float* __restrict__ render, const float* __restrict__ alpha,
                  const float* __restrict__ bg, const float* __restrict__ gt_rgb, const float* __restrict__ gt_depth,
                  const float* __restrict__ mask, float* __restrict__ sums, float rgb_weight, float depth_lambda,
-                 float* __restrict__ v_render, float* __restrict__ v_alpha) {
+                 float* __restrict__ v_render, float* __restrict__ v_alpha, float* __restrict__ losses,
+                 const float* __restrict__ v_rgb_extra, const float* __restrict__ extra_sum, float extra_scale,
+                 float extra_offset) {
     const float w_rgb = rgb_weight / (3.f * (float)n_pix);
     const float nvalid = sums[2];
     const float w_d = nvalid > 0.f ? depth_lambda / nvalid : 0.f;
     const float dmax = CH == 4 ? ordered_to_float(*reinterpret_cast<const int*>(&sums[3])) : 0.f;
-    float dsum = 0.f;
+    float dsum = 0.f, l1 = 0.f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n_pix; i += (size_t)gridDim.x * 256) {
         const PixelEval p = eval_pixel<CH>(render, alpha, bg, i);
         float vr[4] = {0.f, 0.f, 0.f, 0.f};
@@ -114,9 +115,12 @@ loss_grad_kernel(int n_pix, const float* __restrict__ render, const float* __res
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const float diff = p.rgb[k] - gt_rgb[3 * i + k];
+            l1 += fabsf(diff);
             const float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
             const bool pass = p.pre[k] >= 0.f && p.pre[k] <= 1.f;     // torch.clamp backward (inclusive)
-            const float g = pass ? w_rgb * sg : 0.f;
+            // v_rgb_extra: gradient of an additional term on the same clamped colour (SSIM, ssim.hip)
+            const float g_in = w_rgb * sg + (v_rgb_extra ? v_rgb_extra[3 * i + k] : 0.f);
+            const float g = pass ? g_in : 0.f;
             vr[k] = g;
             va -= g * bg[k];
         }
@@ -137,21 +141,26 @@ loss_grad_kernel(int n_pix, const float* __restrict__ render, const float* __res
         }
         v_alpha[i] = va;
     }
-    if constexpr (CH == 4) {
-        dsum = wave_sum(dsum);
-        __shared__ float s[4];
-        if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = dsum;
-        __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(&sums[1], s[0] + s[1] + s[2] + s[3]);
-    }
-}
-
-__global__ void loss_finalize_kernel(int n_pix, const float* __restrict__ sums, float rgb_weight, float depth_lambda,
-                                     float* __restrict__ losses) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        losses[0] = rgb_weight * sums[0] / (3.f * (float)n_pix);
-        losses[1] = sums[2] > 0.f ? depth_lambda * sums[1] / sums[2] : 0.f;    // empty -> 0.0 (model.py:111-114)
-        losses[2] = losses[0] + losses[1];
+    dsum = wave_sum(dsum);
+    l1 = wave_sum(l1);
+    __shared__ float s[2][4];
+    __shared__ bool s_last;
+    if ((threadIdx.x & 63) == 0) { s[0][threadIdx.x >> 6] = dsum; s[1][threadIdx.x >> 6] = l1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[1], s[0][0] + s[0][1] + s[0][2] + s[0][3]);
+        atomicAdd(&sums[0], s[1][0] + s[1][1] + s[1][2] + s[1][3]);
+        // the workgroup that draws the last ticket sees every other workgroup's adds (device-scope atomics)
+        __threadfence();
+        const float ticket = atomicAdd(&sums[4], 1.f);
+        s_last = ticket == (float)(gridDim.x - 1);
+        if (s_last) {
+            const float tot_l1 = atomicAdd(&sums[0], 0.f), tot_d = atomicAdd(&sums[1], 0.f);
+            losses[0] = rgb_weight * tot_l1 / (3.f * (float)n_pix);
+            if (extra_sum != nullptr) losses[0] += extra_offset + extra_scale * extra_sum[0];
+            losses[1] = nvalid > 0.f ? depth_lambda * tot_d / nvalid : 0.f;   // empty -> 0.0 (model.py:111-114)
+            losses[2] = losses[0] + losses[1];
+        }
     }
 }
 
@@ -244,7 +253,7 @@ extern "C" int qed_loss_reduce(int32_t n_pix, int32_t channels, const float* ren
     QED_REQUIRE(channels == 3 || gt_depth, "gt_depth required with a depth channel");
     hipStream_t st = (hipStream_t)stream;
     // sums = {0, 0, 0, ordered(-FLT_MAX)}: -FLT_MAX = 0xFF7FFFFF, ordered form = bits ^ 0x7FFFFFFF
-    hipError_t e = hipMemsetAsync(sums, 0, 3 * sizeof(float), st);
+    hipError_t e = hipMemsetAsync(sums, 0, 8 * sizeof(float), st);
     if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(sums + 3), (int)0x80800000, 1, st);
     if (e != hipSuccess) { set_error("qed_loss_reduce: memset failed: %s", hipGetErrorString(e)); return QED_E_LAUNCH; }
     if (channels == 4)
@@ -259,7 +268,8 @@ extern "C" int qed_loss_reduce(int32_t n_pix, int32_t channels, const float* ren
 extern "C" int qed_loss_grad(int32_t n_pix, int32_t channels, const float* render, const float* alpha,
                              const float* background, const float* gt_rgb, const float* gt_depth, const float* mask,
                              const float* sums, float rgb_weight, float depth_lambda, float* v_render,
-                             float* v_alpha, float* losses, void* stream) {
+                             float* v_alpha, float* losses, const float* v_rgb_extra, const float* extra_sum,
+                             float extra_scale, float extra_offset, void* stream) {
     QED_REQUIRE(n_pix > 0 && (channels == 3 || channels == 4), "bad arguments");
     QED_REQUIRE(render && alpha && background && gt_rgb && sums && v_render && v_alpha && losses, "null buffers");
     QED_REQUIRE(channels == 3 || gt_depth, "gt_depth required with a depth channel");
@@ -267,11 +277,12 @@ extern "C" int qed_loss_grad(int32_t n_pix, int32_t channels, const float* rende
     float* sums_rw = const_cast<float*>(sums);     // slot [1] is accumulated by this pass
     if (channels == 4)
         hipLaunchKernelGGL(loss_grad_kernel<4>, dim3(reduce_grid(n_pix)), dim3(256), 0, st, n_pix, render, alpha,
-                           background, gt_rgb, gt_depth, mask, sums_rw, rgb_weight, depth_lambda, v_render, v_alpha);
+                           background, gt_rgb, gt_depth, mask, sums_rw, rgb_weight, depth_lambda, v_render, v_alpha,
+                           losses, v_rgb_extra, extra_sum, extra_scale, extra_offset);
     else
         hipLaunchKernelGGL(loss_grad_kernel<3>, dim3(reduce_grid(n_pix)), dim3(256), 0, st, n_pix, render, alpha,
-                           background, gt_rgb, gt_depth, mask, sums_rw, rgb_weight, depth_lambda, v_render, v_alpha);
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, n_pix, sums, rgb_weight, depth_lambda, losses);
+                           background, gt_rgb, gt_depth, mask, sums_rw, rgb_weight, depth_lambda, v_render, v_alpha,
+                           losses, v_rgb_extra, extra_sum, extra_scale, extra_offset);
     return check_launch("qed_loss_grad");
 }
 

@@ -37,7 +37,7 @@ def run_case(name):
                                ps["features_rest"], sc["camera_to_worlds"].double(), sc["Ks"].double(), w, h,
                                sc["background"].double(), sh_degree_to_use=deg, rasterize_mode=mode,
                                return_margin=True)
-    l_rgb = 0.8 * O.rgb_l1_loss(out["rgb"], sc["gt_rgb"].double())
+    l_rgb = O.main_loss(out["rgb"], sc["gt_rgb"].double(), 0.2)    # (1 - l) L1 + l (1 - SSIM)
     l_d = O.depth_l1_loss(out["depth"], sc["gt_depth"].double(), None, 0.2)
     (l_rgb + l_d).backward()
     info = out["info"]

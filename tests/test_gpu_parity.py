@@ -340,7 +340,7 @@ def _oracle_step(sc, w, h, cfg, mask=None, radii=None):
                                ps["features_rest"], sc["camera_to_worlds"][:1].double(), sc["Ks"][:1].double(), w, h,
                                sc["background"].double(), rasterize_mode=cfg.rasterize_mode,
                                radii_override=radii, return_margin=True)
-    l_rgb = (1 - cfg.ssim_lambda) * O.rgb_l1_loss(out["rgb"], sc["gt_rgb"].double())
+    l_rgb = O.main_loss(out["rgb"], sc["gt_rgb"].double(), cfg.ssim_lambda)
     l_d = O.depth_l1_loss(out["depth"], sc["gt_depth"].double(), mask, cfg.depth_lambda)
     (l_rgb + l_d).backward()
     return out, l_rgb, l_d, ps
@@ -374,6 +374,33 @@ def test_end_to_end_api_path(cuda, w, h, n):
     # side effects the densifier reads (model.py:249,289-292)
     assert m.last_size == (h, w) and m.xys.shape == (1, n, 2) and m.radii.shape == (n,)
     assert m.xys.grad is not None and m.xys.absgrad.shape == (1, n, 2)
+
+
+@pytest.mark.parametrize("h,w", [(11, 11), (27, 43), (64, 64), (130, 97)])
+def test_ssim_value_and_gradient(cuda, h, w):
+    """ssim.hip (plain-image mode) against the oracle's conv2d restatement, value and d/d pred."""
+    from qed_splatter_amd.model import ssim
+    g = torch.Generator().manual_seed(h * 1000 + w)
+    gt = torch.rand(h, w, 3, generator=g)
+    pred = (gt + 0.25 * torch.randn(h, w, 3, generator=g)).clamp(0, 1)
+    p = pred.to(cuda).requires_grad_(True)
+    v = ssim(p, gt.to(cuda))
+    v.backward()
+    pr = pred.double().requires_grad_(True)
+    vr = O.ssim(pr, gt.double())
+    vr.backward()
+    assert abs(float(v) - float(vr)) <= 1e-5 * abs(float(vr))
+    assert_close(p.grad, pr.grad, REL_TOL, "d ssim / d pred")
+
+
+def test_ssim_errors_and_symmetry(cuda):
+    from qed_splatter_amd._lib import QedSplatError
+    from qed_splatter_amd.model import ssim
+    with pytest.raises(QedSplatError):
+        ssim(torch.rand(10, 40, 3, device=cuda), torch.rand(10, 40, 3, device=cuda))
+    a, b = torch.rand(33, 33, 3, device=cuda), torch.rand(33, 33, 3, device=cuda)
+    assert float(ssim(a, a)) == pytest.approx(1.0, abs=1e-6)
+    assert float(ssim(a, b)) == pytest.approx(float(ssim(b, a)), rel=1e-6)
 
 
 def test_fused_path_equals_api_path(cuda):

@@ -57,7 +57,7 @@ def test_product_get_loss_dict_matches_reference(kats):
     from qed_splatter_amd.model import QEDSplatterModel, QEDSplatterModelConfig
     sc = scene(8, 16, 16, seed=1)
     for i in kats["dl_cases"]:
-        cfg = QEDSplatterModelConfig(depth_lambda=float(kats[f"dl{i}_lambda"]))
+        cfg = QEDSplatterModelConfig(depth_lambda=float(kats[f"dl{i}_lambda"]), ssim_lambda=0.0)   # depth term only
         m = QEDSplatterModel(cfg, **{k: sc[k] for k in PARAM_NAMES})
         d_out = torch.from_numpy(kats[f"dl{i}_depth_out"])
         d_gt = torch.from_numpy(kats[f"dl{i}_depth_gt"])
@@ -96,7 +96,7 @@ def test_oracle_reproduces_golden(gold, name):
                                ps["features_rest"], torch.from_numpy(c["in_camera_to_worlds"]).double(),
                                torch.from_numpy(c["in_Ks"]).double(), w, h, torch.zeros(3, dtype=torch.float64),
                                sh_degree_to_use=None if deg < 0 else deg, rasterize_mode=str(c["in_mode"]))
-    l_rgb = 0.8 * O.rgb_l1_loss(out["rgb"], torch.from_numpy(c["in_gt_rgb"]).double())
+    l_rgb = O.main_loss(out["rgb"], torch.from_numpy(c["in_gt_rgb"]).double(), 0.2)
     l_d = O.depth_l1_loss(out["depth"], torch.from_numpy(c["in_gt_depth"]).double(), None, 0.2)
     (l_rgb + l_d).backward()
     info = out["info"]
@@ -191,6 +191,34 @@ def test_permutation_invariance(small_run):
     r2, a2, _ = O.rasterization(**b, width=w, height=h, render_mode="RGB+D", sh_degree=3)
     torch.testing.assert_close(r2, render, rtol=1e-9, atol=1e-12)
     torch.testing.assert_close(a2, alpha, rtol=1e-9, atol=1e-12)
+
+
+def test_ssim_closed_form_cases():
+    """Pins of the SSIM restatement that need no library: identical images give exactly 1, constant
+    images reduce to the luminance term, the window sums to 1 and is symmetric, the map covers the
+    valid (H-10) x (W-10) region only, and SSIM is symmetric in its arguments."""
+    g = torch.Generator().manual_seed(3)
+    a = torch.rand(40, 37, 3, generator=g, dtype=torch.float64)
+    b = torch.rand(40, 37, 3, generator=g, dtype=torch.float64)
+    w = O.ssim_window()
+    assert w.shape == (11,) and float(w.sum()) == pytest.approx(1.0, abs=1e-15) and torch.equal(w, w.flip(0))
+    assert float(w[5] / w[4]) == pytest.approx(math.exp(1 / 4.5), rel=1e-12)
+    v, smap = O.ssim(a, a, return_map=True)
+    assert smap.shape == (30, 27, 3)
+    assert float(v) == pytest.approx(1.0, abs=1e-12)
+    assert float(O.ssim(a, b)) == pytest.approx(float(O.ssim(b, a)), rel=1e-12)
+    ca, cb = torch.full((16, 16, 3), 0.25, dtype=torch.float64), torch.full((16, 16, 3), 0.75, dtype=torch.float64)
+    lum = (2 * 0.25 * 0.75 + 1e-4) / (0.25 ** 2 + 0.75 ** 2 + 1e-4)      # variances vanish -> cs = C2/C2 = 1
+    assert float(O.ssim(ca, cb)) == pytest.approx(lum, rel=1e-9)
+    # direct (non-separable) evaluation of one map pixel
+    x, y = a[3:14, 5:16, 0], b[3:14, 5:16, 0]
+    W2 = w[:, None] * w[None, :]
+    mx, my = (W2 * x).sum(), (W2 * y).sum()
+    vx, vy, cxy = (W2 * x * x).sum() - mx * mx, (W2 * y * y).sum() - my * my, (W2 * x * y).sum() - mx * my
+    direct = (2 * mx * my + 1e-4) / (mx * mx + my * my + 1e-4) * (2 * cxy + 9e-4) / (vx + vy + 9e-4)
+    _, m2 = O.ssim(a, b, return_map=True)
+    assert float(m2[3, 5, 0]) == pytest.approx(float(direct), rel=1e-12)
+    assert float(O.main_loss(a, b, 0.2)) == pytest.approx(0.8 * float((a - b).abs().mean()) + 0.2 * (1 - float(O.ssim(a, b))), rel=1e-12)
 
 
 def test_empty_cases():
