@@ -20,6 +20,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
     "-Wall", "-Wno-unused-function",
+    *os.environ.get("QED_HIPCC_EXTRA", "").split(),     # development builds only (e.g. -DQED_SSIM_TIMING)
 ]
 
 

@@ -7,34 +7,49 @@
 // reference, so this follows the published definition; oracle/splat_oracle.py::ssim is
 // the restatement the tests compare against.
 //
-// Forward: one 256-thread workgroup per 16x16 block of the SSIM map; the 26x26 input patch of both
-// images goes through LDS, the window is applied separably (rows, then columns), and besides the
-// block's partial sum of the SSIM map the kernel stores, per map pixel q and channel, the three
-// coefficient maps the backward needs:
+// Forward: one 256-thread workgroup per TW x TH block of the SSIM map.  The (TW+10) x (TH+10) patch
+// of both images is staged in LDS; the window is applied along rows with 4 outputs per work item
+// (16-byte LDS reads, every loaded value feeds up to 4 outputs), then along columns with CB outputs
+// per thread.  Besides the block's partial sum of the SSIM map the kernel stores, per map pixel q and
+// channel, the three coefficient maps the backward needs:
 //     d ssim(q) / d x(p) = w(p-q) * [ A(q) + 2 x(p) B(q) + y(p) C(q) ]
 //     A = dS/dmu_x - 2 mu_x dS/dvar_x - mu_y dS/dcov,  B = dS/dvar_x,  C = dS/dcov
 // Backward: grad(p) = conv(A)(p) + 2 x(p) conv(B)(p) + y(p) conv(C)(p) ("full" correlation, zero
-// outside the map), again separable through LDS.  HBM-bound: ~50 MB in, ~75 MB of maps, 25 MB out.
+// outside the map), the same two passes over the three maps.
+// Both kernels are VALU-bound (55 + 55 window FMAs per map pixel and channel forward, 33 + 33
+// backward); HBM traffic is ~70 MB in + 75 MB of maps forward, 75 + 70 MB in + 25 MB out backward.
 #include "qed_common.h"
 
 namespace qed {
 
 constexpr int kWin = 11;
 constexpr int kHalo = kWin - 1;            // 10
-constexpr int kSTile = 16;
-constexpr int kSPatch = kSTile + kHalo;    // 26
 
-// pytorch_msssim _fspecial_gauss_1d(11, 1.5) evaluated in fp32 exactly as the library does
+// pytorch_msssim _fspecial_gauss_1d(11, 1.5) evaluated in fp32 exactly as the library does.
+// Symmetric: correlation and convolution coincide, which the backward pass relies on.
 __device__ __constant__ float c_win[kWin] = {
     1.028380357e-03f, 7.598758209e-03f, 3.600077331e-02f, 1.093606874e-01f, 2.130055279e-01f, 2.660117149e-01f,
     2.130055279e-01f, 1.093606874e-01f, 3.600077331e-02f, 7.598758209e-03f, 1.028380357e-03f};
+
+template <int TW_, int TH_>
+struct SsimTile {
+    static constexpr int TW = TW_, TH = TH_;
+    static constexpr int PW = TW + kHalo, PH = TH + kHalo;
+    static constexpr int SP = TW + 12;                 // patch row stride: 16-float reads stay in the row; odd multiple of 4
+    static constexpr int SH = TW + 4;                  // row-pass output stride (odd multiple of 4 floats)
+    static constexpr int ROW_ITEMS = PH * (TW / 4);    // row pass: 4 outputs per item
+    static constexpr int COL_GROUPS = 256 / TW;
+    static constexpr int CB = TH / COL_GROUPS;         // column pass: CB outputs per thread
+    static constexpr int RPP = 256 / PW;               // staging: patch rows per pass (thread -> one patch column)
+    static constexpr int LOADS = (PH + RPP - 1) / RPP; // patch pixels per staging thread
+    static_assert(TW % 4 == 0 && 256 % TW == 0 && TH % COL_GROUPS == 0, "tile shape");
+};
 
 // predicted colour channel k of pixel (iy, ix): either a plain [H,W,3] image or composited on the fly
 // from render[H,W,CH] + (1 - alpha) * background, clamped to [0,1] (model.py:296-297)
 template <bool COMPOSITE>
 __device__ __forceinline__ float pred_at(const float* __restrict__ pred, const float* __restrict__ alpha,
-                                         const float* __restrict__ bg, int channels, int W, int iy, int ix, int k) {
-    const size_t pix = (size_t)iy * W + ix;
+                                         const float* __restrict__ bg, int channels, size_t pix, int k) {
     if constexpr (COMPOSITE) {
         const float v = pred[pix * channels + k] + (1.f - alpha[pix]) * bg[k];
         return fminf(fmaxf(v, 0.f), 1.f);
@@ -43,70 +58,155 @@ __device__ __forceinline__ float pred_at(const float* __restrict__ pred, const f
     }
 }
 
+struct __attribute__((packed, aligned(4))) Float3 { float a, b, c; };
+
+// all three channels of one pixel with as few (and as wide) requests as possible: 16 B of render,
+// 4 B of alpha, 12 B of ground truth.  x = predicted colour, y = ground truth.
 template <bool COMPOSITE>
-__global__ void __launch_bounds__(256)
+__device__ __forceinline__ void load_pixel(const float* __restrict__ pred, const float* __restrict__ alpha,
+                                           const float* __restrict__ bg, const float* __restrict__ gt, int channels,
+                                           size_t pix, float (&x)[3], float (&y)[3]) {
+    const Float3 g = *reinterpret_cast<const Float3*>(gt + pix * 3);
+    y[0] = g.a; y[1] = g.b; y[2] = g.c;
+    if constexpr (COMPOSITE) {
+        float r[3];
+        if (channels == 4) {
+            const float4 v = *reinterpret_cast<const float4*>(pred + pix * 4);
+            r[0] = v.x; r[1] = v.y; r[2] = v.z;
+        } else {
+            const Float3 v = *reinterpret_cast<const Float3*>(pred + pix * 3);
+            r[0] = v.a; r[1] = v.b; r[2] = v.c;
+        }
+        const float om = 1.f - alpha[pix];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) x[k] = fminf(fmaxf(r[k] + om * bg[k], 0.f), 1.f);
+    } else {
+        const Float3 v = *reinterpret_cast<const Float3*>(pred + pix * 3);
+        x[0] = v.a; x[1] = v.b; x[2] = v.c;
+    }
+}
+
+// 4 adjacent window sums of a row: out[o] = sum_d w[d] v[o + d], o = 0..3, from 14 consecutive inputs
+__device__ __forceinline__ float4 window4(const float (&v)[16], const float (&w)[kWin]) {
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int d = 0; d < kWin; ++d) {
+        r.x += w[d] * v[d]; r.y += w[d] * v[d + 1]; r.z += w[d] * v[d + 2]; r.w += w[d] * v[d + 3];
+    }
+    return r;
+}
+
+__device__ __forceinline__ void read16(const float* __restrict__ p, float (&v)[16]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 t = *reinterpret_cast<const float4*>(p + 4 * j);
+        v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+    }
+}
+
+template <bool COMPOSITE, class T>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 ssim_fwd_kernel(int H, int W, int channels, const float* __restrict__ pred, const float* __restrict__ alpha,
                 const float* __restrict__ bg, const float* __restrict__ gt, float* __restrict__ maps,
                 float* __restrict__ ssim_sum) {
-    __shared__ float s_x[kSPatch][kSPatch + 1], s_y[kSPatch][kSPatch + 1];
-    __shared__ float s_h[5][kSPatch][kSTile + 1];
+    constexpr int TW = T::TW, PW = T::PW, PH = T::PH, SP = T::SP, SH = T::SH, CB = T::CB;
+    __shared__ __attribute__((aligned(16))) float s_x[PH * SP], s_y[PH * SP];
+    __shared__ __attribute__((aligned(16))) float s_h[4][PH * SH];
     __shared__ float s_red[4];
     const int Ho = H - kHalo, Wo = W - kHalo;
-    const int ox = blockIdx.x * kSTile, oy = blockIdx.y * kSTile;        // origin in the SSIM map
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int ox = blockIdx.x * TW, oy = blockIdx.y * T::TH;            // origin in the SSIM map
+    const int tid = threadIdx.x;
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
     const size_t n_out = (size_t)Ho * Wo;
+    float w[kWin];
+#pragma unroll
+    for (int d = 0; d < kWin; ++d) w[d] = c_win[d];
+    // Staging: thread -> patch column spx, rows spy + RPP * j.  All pixels of all three channels are
+    // fetched up front in one batch of unconditional loads from clamped coordinates (a load inside a
+    // bounds branch is waited for inside it): one exposed memory latency per workgroup, every fetched
+    // cache line fully used.
+    const int spy = tid / PW, spx = tid - spy * PW;
+    const bool stager = tid < T::RPP * PW;
+    float xs[T::LOADS][3], ys[T::LOADS][3];
+#pragma unroll
+    for (int j = 0; j < T::LOADS; ++j) {
+        const int iy = oy + spy + T::RPP * j, ix = ox + spx;
+        load_pixel<COMPOSITE>(pred, alpha, bg, gt, channels, (size_t)min(iy, H - 1) * W + min(ix, W - 1), xs[j], ys[j]);
+        if (!(iy < H && ix < W)) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { xs[j][k] = 0.f; ys[j][k] = 0.f; }
+        }
+    }
     float acc = 0.f;
+#pragma unroll
     for (int k = 0; k < 3; ++k) {
         __syncthreads();
-        for (int i = tid; i < kSPatch * kSPatch; i += 256) {
-            const int py = i / kSPatch, px = i - py * kSPatch;
-            const int iy = oy + py, ix = ox + px;
-            float x = 0.f, y = 0.f;
-            if (iy < H && ix < W) {
-                x = pred_at<COMPOSITE>(pred, alpha, bg, channels, W, iy, ix, k);
-                y = gt[((size_t)iy * W + ix) * 3 + k];
-            }
-            s_x[py][px] = x; s_y[py][px] = y;
+        if (stager) {
+#pragma unroll
+            for (int j = 0; j < T::LOADS; ++j)
+                if (spy + T::RPP * j < PH) {
+                    s_x[(spy + T::RPP * j) * SP + spx] = xs[j][k];
+                    s_y[(spy + T::RPP * j) * SP + spx] = ys[j][k];
+                }
         }
         __syncthreads();
-        // rows: 26 x 16 window sums of x, y, x^2, y^2, x y
-        for (int i = tid; i < kSPatch * kSTile; i += 256) {
-            const int py = i / kSTile, cx = i - py * kSTile;
-            float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+        // rows: window sums of x, y, x^2 + y^2, x y; consecutive lanes take consecutive rows
+        for (int i = tid; i < T::ROW_ITEMS; i += 256) {
+            const int gx = i / PH, py = i - gx * PH;
+            float x[16], y[16], p[16];
+            read16(&s_x[py * SP + 4 * gx], x);
+            read16(&s_y[py * SP + 4 * gx], y);
+            const int o = py * SH + 4 * gx;
+            *reinterpret_cast<float4*>(&s_h[0][o]) = window4(x, w);
+            *reinterpret_cast<float4*>(&s_h[1][o]) = window4(y, w);
+            // SSIM only ever needs var_x + var_y, so x^2 and y^2 share one window sum
 #pragma unroll
-            for (int d = 0; d < kWin; ++d) {
-                const float w = c_win[d], x = s_x[py][cx + d], y = s_y[py][cx + d];
-                sx += w * x; sy += w * y; sxx += w * x * x; syy += w * y * y; sxy += w * x * y;
-            }
-            s_h[0][py][cx] = sx; s_h[1][py][cx] = sy; s_h[2][py][cx] = sxx; s_h[3][py][cx] = syy; s_h[4][py][cx] = sxy;
+            for (int j = 0; j < 14; ++j) p[j] = x[j] * x[j] + y[j] * y[j];
+            *reinterpret_cast<float4*>(&s_h[2][o]) = window4(p, w);
+#pragma unroll
+            for (int j = 0; j < 14; ++j) p[j] = x[j] * y[j];
+            *reinterpret_cast<float4*>(&s_h[3][o]) = window4(p, w);
         }
         __syncthreads();
-        // columns
-        float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+        // columns: CB vertically adjacent outputs per thread
+        const int tx = tid % TW, ty0 = (tid / TW) * CB;
+        float st[4][CB];
 #pragma unroll
-        for (int d = 0; d < kWin; ++d) {
-            const float w = c_win[d];
-            mu1 += w * s_h[0][ty + d][tx]; mu2 += w * s_h[1][ty + d][tx];
-            e11 += w * s_h[2][ty + d][tx]; e22 += w * s_h[3][ty + d][tx]; e12 += w * s_h[4][ty + d][tx];
+        for (int q = 0; q < 4; ++q) {
+            float v[CB + kHalo];
+#pragma unroll
+            for (int j = 0; j < CB + kHalo; ++j) v[j] = s_h[q][(ty0 + j) * SH + tx];
+#pragma unroll
+            for (int o = 0; o < CB; ++o) {
+                float a = 0.f;
+#pragma unroll
+                for (int d = 0; d < kWin; ++d) a += w[d] * v[o + d];
+                st[q][o] = a;
+            }
         }
-        const int qx = ox + tx, qy = oy + ty;
-        if (qx < Wo && qy < Ho) {
-            const float var1 = e11 - mu1 * mu1, var2 = e22 - mu2 * mu2, cov = e12 - mu1 * mu2;
-            const float a1 = 2.f * mu1 * mu2 + C1, b1 = mu1 * mu1 + mu2 * mu2 + C1;
-            const float a2 = 2.f * cov + C2, b2 = var1 + var2 + C2;
-            const float ib1 = 1.f / b1, ib2 = 1.f / b2;
-            const float lum = a1 * ib1, cs = a2 * ib2;
-            acc += lum * cs;
-            // partial derivatives of S = lum * cs w.r.t. mu1 (holding var1, cov), var1, cov
-            const float dS_dmu1 = cs * (2.f * mu2 * ib1 - a1 * ib1 * ib1 * 2.f * mu1);
-            const float dS_dvar1 = -lum * a2 * ib2 * ib2;
-            const float dS_dcov = lum * 2.f * ib2;
-            const size_t q = (size_t)qy * Wo + qx;
-            float* m = maps + (size_t)k * 3 * n_out;
-            m[q] = dS_dmu1 - 2.f * mu1 * dS_dvar1 - mu2 * dS_dcov;       // A
-            m[n_out + q] = dS_dvar1;                                     // B
-            m[2 * n_out + q] = dS_dcov;                                  // C
+        const int qx = ox + tx;
+        float* m = maps + (size_t)k * 3 * n_out;
+#pragma unroll
+        for (int o = 0; o < CB; ++o) {
+            const int qy = oy + ty0 + o;
+            if (qx < Wo && qy < Ho) {
+                const float mu1 = st[0][o], mu2 = st[1][o];
+                const float mm = mu1 * mu1 + mu2 * mu2;
+                const float var12 = st[2][o] - mm, cov = st[3][o] - mu1 * mu2;     // var_x + var_y, cov
+                const float a1 = 2.f * mu1 * mu2 + C1, b1 = mm + C1;
+                const float a2 = 2.f * cov + C2, b2 = var12 + C2;
+                const float ib1 = __builtin_amdgcn_rcpf(b1), ib2 = __builtin_amdgcn_rcpf(b2);   // 1 ulp
+                const float lum = a1 * ib1, cs = a2 * ib2;
+                acc += lum * cs;
+                // partial derivatives of S = lum * cs w.r.t. mu1 (holding var1, cov), var1, cov
+                const float dS_dmu1 = cs * (2.f * mu2 * ib1 - a1 * ib1 * ib1 * 2.f * mu1);
+                const float dS_dvar1 = -lum * a2 * ib2 * ib2;
+                const float dS_dcov = lum * 2.f * ib2;
+                const size_t q = (size_t)qy * Wo + qx;
+                m[q] = dS_dmu1 - 2.f * mu1 * dS_dvar1 - mu2 * dS_dcov;       // A
+                m[n_out + q] = dS_dvar1;                                     // B
+                m[2 * n_out + q] = dS_dcov;                                  // C
+            }
         }
     }
     acc = wave_sum(acc);
@@ -116,64 +216,105 @@ ssim_fwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
 }
 
 // v_pred[H,W,3] = scale * d(sum of the SSIM map)/d pred
-template <bool COMPOSITE>
-__global__ void __launch_bounds__(256)
+template <bool COMPOSITE, class T>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, const float* __restrict__ alpha,
                 const float* __restrict__ bg, const float* __restrict__ gt, const float* __restrict__ maps,
                 float scale, float* __restrict__ v_pred) {
-    __shared__ float s_m[3][kSPatch][kSPatch + 1];
-    __shared__ float s_h[3][kSPatch][kSTile + 1];
+    constexpr int TW = T::TW, PW = T::PW, PH = T::PH, SP = T::SP, SH = T::SH, CB = T::CB;
+    __shared__ __attribute__((aligned(16))) float s_m[3][PH * SP];
+    __shared__ __attribute__((aligned(16))) float s_h[3][PH * SH];
     const int Ho = H - kHalo, Wo = W - kHalo;
-    const int ox = blockIdx.x * kSTile, oy = blockIdx.y * kSTile;        // origin in the image
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int ox = blockIdx.x * TW, oy = blockIdx.y * T::TH;            // origin in the image
+    const int tid = threadIdx.x;
     const size_t n_out = (size_t)Ho * Wo;
+    float w[kWin];
+#pragma unroll
+    for (int d = 0; d < kWin; ++d) w[d] = c_win[d];
+    const int spy = tid / PW, spx = tid - spy * PW;
+    const bool stager = tid < T::RPP * PW;
+    const int tx = tid % TW, ty0 = (tid / TW) * CB;
+    const int ix = ox + tx;
+    float r0[CB], r1[CB];            // channels 0 and 1 wait for channel 2: one 12-byte store per pixel
+#pragma unroll 1
     for (int k = 0; k < 3; ++k) {
         const float* m = maps + (size_t)k * 3 * n_out;
-        __syncthreads();
-        // map patch rows oy-10 .. oy+15, cols ox-10 .. ox+15 (zero outside the map)
-        for (int i = tid; i < kSPatch * kSPatch; i += 256) {
-            const int py = i / kSPatch, px = i - py * kSPatch;
-            const int qy = oy + py - kHalo, qx = ox + px - kHalo;
-            float a = 0.f, b = 0.f, c = 0.f;
-            if (qy >= 0 && qy < Ho && qx >= 0 && qx < Wo) {
-                const size_t q = (size_t)qy * Wo + qx;
-                a = m[q]; b = m[n_out + q]; c = m[2 * n_out + q];
-            }
-            s_m[0][py][px] = a; s_m[1][py][px] = b; s_m[2][py][px] = c;
-        }
-        __syncthreads();
-        // rows: out(px) = sum_d w[d] M(px - d)  -> patch column (cx + 10 - d)
-        for (int i = tid; i < kSPatch * kSTile; i += 256) {
-            const int py = i / kSTile, cx = i - py * kSTile;
-            float sa = 0.f, sb = 0.f, sc = 0.f;
+        // map patch rows oy-10 .. oy+TH-1, cols ox-10 .. ox+TW-1 (zero outside the map):
+        // grad(p) = sum_d w[d] M(p - d) = sum_d' w[d'] M(p - 10 + d')  (symmetric window)
+        float mv[T::LOADS][3];
 #pragma unroll
-            for (int d = 0; d < kWin; ++d) {
-                const float w = c_win[d];
-                sa += w * s_m[0][py][cx + kHalo - d]; sb += w * s_m[1][py][cx + kHalo - d];
-                sc += w * s_m[2][py][cx + kHalo - d];
-            }
-            s_h[0][py][cx] = sa; s_h[1][py][cx] = sb; s_h[2][py][cx] = sc;
+        for (int j = 0; j < T::LOADS; ++j) {
+            const int qy = oy + spy + T::RPP * j - kHalo, qx = ox + spx - kHalo;
+            const size_t q = (size_t)min(max(qy, 0), Ho - 1) * Wo + min(max(qx, 0), Wo - 1);
+            const float al = m[q], bl = m[n_out + q], cl = m[2 * n_out + q];
+            const bool in = qy >= 0 && qy < Ho && qx >= 0 && qx < Wo;
+            mv[j][0] = in ? al : 0.f; mv[j][1] = in ? bl : 0.f; mv[j][2] = in ? cl : 0.f;
+        }
+        // the output pixels' own colours, requested with the maps so their latency hides behind both passes
+        float xo[CB], yo[CB];
+#pragma unroll
+        for (int o = 0; o < CB; ++o) {
+            const size_t pix = (size_t)min(oy + ty0 + o, H - 1) * W + min(ix, W - 1);
+            xo[o] = pred_at<COMPOSITE>(pred, alpha, bg, channels, pix, k);
+            yo[o] = gt[pix * 3 + k];
         }
         __syncthreads();
-        float ga = 0.f, gb = 0.f, gc = 0.f;
+        if (stager) {
 #pragma unroll
-        for (int d = 0; d < kWin; ++d) {
-            const float w = c_win[d];
-            ga += w * s_h[0][ty + kHalo - d][tx]; gb += w * s_h[1][ty + kHalo - d][tx];
-            gc += w * s_h[2][ty + kHalo - d][tx];
+            for (int j = 0; j < T::LOADS; ++j)
+                if (spy + T::RPP * j < PH) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) s_m[q][(spy + T::RPP * j) * SP + spx] = mv[j][q];
+                }
         }
-        const int ix = ox + tx, iy = oy + ty;
-        if (ix < W && iy < H) {
-            const float x = pred_at<COMPOSITE>(pred, alpha, bg, channels, W, iy, ix, k);
-            const float y = gt[((size_t)iy * W + ix) * 3 + k];
-            v_pred[((size_t)iy * W + ix) * 3 + k] = scale * (ga + 2.f * x * gb + y * gc);
+        __syncthreads();
+        for (int i = tid; i < T::ROW_ITEMS; i += 256) {
+            const int gx = i / PH, py = i - gx * PH;
+            const int o = py * SH + 4 * gx;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                float v[16];
+                read16(&s_m[q][py * SP + 4 * gx], v);
+                *reinterpret_cast<float4*>(&s_h[q][o]) = window4(v, w);
+            }
+        }
+        __syncthreads();
+        float g[3][CB];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            float v[CB + kHalo];
+#pragma unroll
+            for (int j = 0; j < CB + kHalo; ++j) v[j] = s_h[q][(ty0 + j) * SH + tx];
+#pragma unroll
+            for (int o = 0; o < CB; ++o) {
+                float a = 0.f;
+#pragma unroll
+                for (int d = 0; d < kWin; ++d) a += w[d] * v[o + d];
+                g[q][o] = a;
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < CB; ++o) {
+            const float r = scale * (g[0][o] + 2.f * xo[o] * g[1][o] + yo[o] * g[2][o]);
+            if (k == 0) r0[o] = r;
+            else if (k == 1) r1[o] = r;
+            else {
+                const int iy = oy + ty0 + o;
+                if (ix < W && iy < H) {
+                    Float3 v; v.a = r0[o]; v.b = r1[o]; v.c = r;
+                    *reinterpret_cast<Float3*>(v_pred + ((size_t)iy * W + ix) * 3) = v;
+                }
+            }
         }
     }
 }
 
+using Tile = SsimTile<32, 32>;
+
 }  // namespace qed
 
 using namespace qed;
+
 
 extern "C" int64_t qed_ssim_maps_floats(int32_t height, int32_t width) {
     if (height <= kHalo || width <= kHalo) return QED_E_INVALID_ARG;
@@ -188,13 +329,13 @@ extern "C" int qed_ssim_fwd(int32_t height, int32_t width, int32_t channels, con
     QED_REQUIRE(alpha == nullptr || (background && (channels == 3 || channels == 4)), "composite mode needs a background");
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(ssim_sum, 0, sizeof(float), st) != hipSuccess) { set_error("qed_ssim_fwd: memset failed"); return QED_E_LAUNCH; }
-    const dim3 grid((width - kHalo + kSTile - 1) / kSTile, (height - kHalo + kSTile - 1) / kSTile);
+    const dim3 grid((width - kHalo + Tile::TW - 1) / Tile::TW, (height - kHalo + Tile::TH - 1) / Tile::TH);
     if (alpha != nullptr)
-        hipLaunchKernelGGL(ssim_fwd_kernel<true>, grid, dim3(256), 0, st, height, width, channels, pred, alpha, background,
-                           gt_rgb, maps, ssim_sum);
+        hipLaunchKernelGGL((ssim_fwd_kernel<true, Tile>), grid, dim3(256), 0, st, height, width, channels, pred, alpha,
+                           background, gt_rgb, maps, ssim_sum);
     else
-        hipLaunchKernelGGL(ssim_fwd_kernel<false>, grid, dim3(256), 0, st, height, width, 3, pred, alpha, background,
-                           gt_rgb, maps, ssim_sum);
+        hipLaunchKernelGGL((ssim_fwd_kernel<false, Tile>), grid, dim3(256), 0, st, height, width, 3, pred, alpha,
+                           background, gt_rgb, maps, ssim_sum);
     return check_launch("qed_ssim_fwd");
 }
 
@@ -205,12 +346,12 @@ extern "C" int qed_ssim_bwd(int32_t height, int32_t width, int32_t channels, con
     QED_REQUIRE(pred && gt_rgb && maps && v_pred, "null buffers");
     QED_REQUIRE(alpha == nullptr || (background && (channels == 3 || channels == 4)), "composite mode needs a background");
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((width + kSTile - 1) / kSTile, (height + kSTile - 1) / kSTile);
+    const dim3 grid((width + Tile::TW - 1) / Tile::TW, (height + Tile::TH - 1) / Tile::TH);
     if (alpha != nullptr)
-        hipLaunchKernelGGL(ssim_bwd_kernel<true>, grid, dim3(256), 0, st, height, width, channels, pred, alpha, background,
-                           gt_rgb, maps, scale, v_pred);
+        hipLaunchKernelGGL((ssim_bwd_kernel<true, Tile>), grid, dim3(256), 0, st, height, width, channels, pred, alpha,
+                           background, gt_rgb, maps, scale, v_pred);
     else
-        hipLaunchKernelGGL(ssim_bwd_kernel<false>, grid, dim3(256), 0, st, height, width, 3, pred, alpha, background,
-                           gt_rgb, maps, scale, v_pred);
+        hipLaunchKernelGGL((ssim_bwd_kernel<false, Tile>), grid, dim3(256), 0, st, height, width, 3, pred, alpha,
+                           background, gt_rgb, maps, scale, v_pred);
     return check_launch("qed_ssim_bwd");
 }
