@@ -247,7 +247,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n} Gaussians, SH deg 3, {world} cam(s) @ {w}x{h}, 1 per GPU, fwd+bwd with "
-                                   f"depth-L1 + L1-RGB loss + fused Adam (SSIM term not built yet)",
+                                   f"depth-L1 + (0.8 L1 + 0.2 (1-SSIM)) RGB loss + fused Adam",
                        "gaussians": n, "visible": n_vis, "intersections": M, "width": w, "height": h,
                        "parallelism": f"dp{world} (camera-sharded, flat-gradient all-reduce)" if world > 1 else "single",
                        "async_intersection_count": not args.sync_m,

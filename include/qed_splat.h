@@ -198,6 +198,17 @@ int qed_ssim_bwd(int32_t height, int32_t width, int32_t channels, const float* p
                  const float* background, const float* gt_rgb, const float* maps, float scale,
                  float* v_pred, void* stream);
 
+/* ---- per-step evaluation metrics (model.py:120-197, metrics.py:84-156) ----------
+ * One streaming pass, results left in DEVICE memory (the reference synchronises ~12 times per step
+ * with .item()).  out[10] = {rgb_mse, rgb_psnr, depth_abs_rel, depth_sq_rel, depth_rmse,
+ * depth_rmse_log, depth_a1, depth_a2, depth_a3, n_valid_depth}; the depth entries are NaN when no
+ * pixel is valid (metrics.py:134-143) or when pred_depth/gt_depth are NULL; the rgb entries are NaN
+ * when pred_rgb/gt_rgb are NULL.  pred_rgb, gt_rgb: [n_pix,3]; depths: [n_pix]; valid depth =
+ * finite(pred) & finite(gt) & gt > tolerance (0.1 in the reference).  workspace: 12 doubles.
+ * rgb_ssim is qed_ssim_fwd's value; LPIPS (pretrained network) is not provided. */
+int qed_image_metrics(int32_t n_pix, const float* pred_rgb, const float* gt_rgb, const float* pred_depth,
+                      const float* gt_depth, float tolerance, double* workspace, float* out, void* stream);
+
 /* ---- fused multi-tensor Adam over one flat parameter buffer (config.py:44-68) --
  * n_groups contiguous segments; segment g covers elements [h_group_begin[g], h_group_begin[g+1])
  * and uses learning rate h_lr[g].  bias corrections use `step` (1-based). */

@@ -525,6 +525,32 @@ def ssim(pred: Tensor, gt: Tensor, return_map: bool = False):
     return (val, smap[0].permute(1, 2, 0)) if return_map else val
 
 
+def depth_metrics(pred: Tensor, gt: Tensor, tolerance: float = 0.1):
+    """DepthMetrics.forward (metrics.py:126-156): (abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3) over the
+    pixels with finite pred, finite gt and gt > tolerance; seven NaNs when there are none.
+    PINNED by the reference's own output on tests/golden/reference_kats.npz (dm_*)."""
+    valid = torch.isfinite(pred) & torch.isfinite(gt) & (gt > tolerance)
+    if valid.sum() == 0:
+        return tuple(torch.tensor(float("nan")) for _ in range(7))
+    p, g = pred[valid], gt[valid]
+    thresh = torch.max(g / p, p / g)
+    a1, a2, a3 = ((thresh < 1.25 ** k).to(p.dtype).mean() for k in (1, 2, 3))
+    rmse = torch.sqrt(((g - p) ** 2).mean())
+    rmse_log = torch.sqrt(((torch.log(g) - torch.log(p)) ** 2).nanmean())
+    abs_rel = (torch.abs(g - p) / g).mean()
+    sq_rel = ((g - p) ** 2 / g).mean()
+    return abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3
+
+
+def rgb_metrics(pred: Tensor, gt: Tensor):
+    """(mse, psnr, ssim) of RGBMetrics / nn.MSELoss (metrics.py:92-110, model.py:159): torchmetrics
+    PeakSignalNoiseRatio(data_range=1) = 10 log10(1 / mse) over the whole image; SSIM as in ``ssim``
+    (torchmetrics reflect-pads by 5 and crops 5 again = the unpadded valid-window map).  PARITY
+    UNPINNED (torchmetrics is not installed here)."""
+    mse = ((pred - gt) ** 2).mean()
+    return mse, 10.0 * torch.log10(1.0 / mse), ssim(pred, gt)
+
+
 def main_loss(rgb: Tensor, gt: Tensor, ssim_lambda: float = 0.2) -> Tensor:
     """SplatfactoModel main loss: (1 - l) * L1 + l * (1 - SSIM)."""
     out = (1 - ssim_lambda) * rgb_l1_loss(rgb, gt)

@@ -1,0 +1,123 @@
+// the per-step evaluation metrics of get_metrics_dict (model.py:120-197) as one
+// streaming pass with the results left in device memory (the reference pulls ~12 scalars to the host
+// with .item()/float() every iteration, model.py:160-182).
+//
+//   RGB   (metrics.py:84-112, torchmetrics PeakSignalNoiseRatio(data_range=1), nn.MSELoss):
+//         mse = mean (pred - gt)^2 over H*W*3,  psnr = 10 log10(1 / mse)
+//   depth (metrics.py:115-156): valid = finite(pred) & finite(gt) & gt > tolerance;
+//         abs_rel = mean |gt-pred|/gt, sq_rel = mean (gt-pred)^2/gt, rmse = sqrt(mean (gt-pred)^2),
+//         rmse_log = sqrt(nanmean (log gt - log pred)^2), a_k = mean [max(gt/pred, pred/gt) < 1.25^k];
+//         all NaN when no pixel is valid (metrics.py:134-143).
+//   SSIM  is qed_ssim_fwd's value (torchmetrics' reflect-pad + crop equals the unpadded "valid"
+//         window sums); LPIPS needs pretrained network weights and is out of scope.
+#include "qed_common.h"
+
+namespace qed {
+
+constexpr int kMetricSums = 12;
+// sums: 0 sum (dr^2+dg^2+db^2) | 1 n_valid | 2 sum |g-p|/g | 3 sum (g-p)^2/g | 4 sum (g-p)^2
+//       5 sum (log g - log p)^2 over non-NaN | 6 count non-NaN | 7,8,9 counts a1,a2,a3 | 10 ticket
+
+// per-wave partial of slot `slot` -> s_tmp[slot][wave]
+__device__ __forceinline__ void park_wave_sum(float v, double* s_tmp, int slot) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) s_tmp[slot * 4 + (threadIdx.x >> 6)] = (double)v;
+}
+
+__global__ void __launch_bounds__(256)
+metrics_kernel(int n_pix, const float* __restrict__ pred_rgb, const float* __restrict__ gt_rgb,
+               const float* __restrict__ pred_depth, const float* __restrict__ gt_depth, float tolerance,
+               double* __restrict__ sums, float* __restrict__ out) {
+    float acc[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) acc[i] = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n_pix; i += (size_t)gridDim.x * 256) {
+        if (pred_rgb != nullptr) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float d = pred_rgb[3 * i + k] - gt_rgb[3 * i + k];
+                acc[0] += d * d;
+            }
+        }
+        if (pred_depth != nullptr) {
+            const float p = pred_depth[i], g = gt_depth[i];
+            if (isfinite(p) && isfinite(g) && g > tolerance) {
+                const float d = g - p;
+                acc[1] += 1.f;
+                acc[2] += fabsf(d) / g;
+                acc[3] += d * d / g;
+                acc[4] += d * d;
+                const float l = logf(g) - logf(p);          // NaN for p < 0, +-inf for p == 0 (kept, like nanmean)
+                const float l2 = l * l;
+                if (!isnan(l2)) { acc[5] += l2; acc[6] += 1.f; }
+                const float t = fmaxf(g / p, p / g);
+                acc[7] += t < 1.25f ? 1.f : 0.f;
+                acc[8] += t < 1.25f * 1.25f ? 1.f : 0.f;
+                acc[9] += t < 1.25f * 1.25f * 1.25f ? 1.f : 0.f;
+            }
+        }
+    }
+    __shared__ double s_tmp[10 * 4];
+    __shared__ bool s_last;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) park_wave_sum(acc[i], s_tmp, i);
+    __syncthreads();
+    if (threadIdx.x < 10) {
+        const int i = threadIdx.x;
+        atomicAdd(&sums[i], s_tmp[4 * i] + s_tmp[4 * i + 1] + s_tmp[4 * i + 2] + s_tmp[4 * i + 3]);
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double ticket = atomicAdd(&sums[10], 1.0);
+        s_last = ticket == (double)(gridDim.x - 1);
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) {
+        double s[10];
+        for (int i = 0; i < 10; ++i) s[i] = atomicAdd(&sums[i], 0.0);
+        const float nanv = __builtin_nanf("");
+        if (pred_rgb != nullptr) {
+            const double mse = s[0] / (3.0 * (double)n_pix);
+            out[0] = (float)mse;
+            out[1] = (float)(10.0 * log10(1.0 / mse));
+        } else {
+            out[0] = nanv; out[1] = nanv;
+        }
+        const double n = s[1];
+        if (pred_depth != nullptr && n > 0.0) {
+            out[2] = (float)(s[2] / n);
+            out[3] = (float)(s[3] / n);
+            out[4] = (float)sqrt(s[4] / n);
+            out[5] = s[6] > 0.0 ? (float)sqrt(s[5] / s[6]) : nanv;
+            out[6] = (float)(s[7] / n);
+            out[7] = (float)(s[8] / n);
+            out[8] = (float)(s[9] / n);
+        } else {
+            for (int i = 2; i < 9; ++i) out[i] = nanv;
+        }
+        out[9] = (float)n;
+    }
+}
+
+}  // namespace qed
+
+using namespace qed;
+
+extern "C" int qed_image_metrics(int32_t n_pix, const float* pred_rgb, const float* gt_rgb, const float* pred_depth,
+                                 const float* gt_depth, float tolerance, double* workspace, float* out, void* stream) {
+    QED_REQUIRE(n_pix > 0 && workspace && out, "bad arguments");
+    QED_REQUIRE((pred_rgb == nullptr) == (gt_rgb == nullptr), "pred_rgb and gt_rgb go together");
+    QED_REQUIRE((pred_depth == nullptr) == (gt_depth == nullptr), "pred_depth and gt_depth go together");
+    QED_REQUIRE(pred_rgb || pred_depth, "nothing to measure");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(workspace, 0, kMetricSums * sizeof(double), st) != hipSuccess) {
+        set_error("qed_image_metrics: memset failed");
+        return QED_E_LAUNCH;
+    }
+    long long g = ((long long)n_pix + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(metrics_kernel, dim3((unsigned)g), dim3(256), 0, st, n_pix, pred_rgb, gt_rgb, pred_depth, gt_depth,
+                       tolerance, workspace, out);
+    return check_launch("qed_image_metrics");
+}

@@ -1,0 +1,116 @@
+"""Per-step evaluation metrics: the GPU side of the reference's ``metrics.py`` and
+``QEDSplatterModel.get_metrics_dict`` (model.py:120-197).
+
+The reference runs torchmetrics PSNR / SSIM / LPIPS plus its own DepthMetrics every iteration and pulls
+each scalar to the host with ``.item()`` / ``float()`` (model.py:160-182): about a dozen device
+synchronisations per step.  Here one streaming kernel (``qed_image_metrics``) produces the MSE / PSNR and
+the seven depth metrics, ``qed_ssim_fwd`` produces SSIM, and everything stays in device memory until the
+caller decides to log it.
+
+LPIPS needs the pretrained AlexNet/VGG weights torchmetrics downloads; it is not provided and the
+``lpips`` slot is NaN.  The point-cloud metrics of metrics.py:10-63 (cKDTree, CPU, offline) are out
+of scope.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib as L
+
+METRIC_NAMES = ("rgb_mse", "rgb_psnr", "depth_abs_rel", "depth_sq_rel", "depth_rmse", "depth_rmse_log",
+                "depth_a1", "depth_a2", "depth_a3", "depth_n_valid")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def image_metrics(pred_rgb: Optional[Tensor], gt_rgb: Optional[Tensor], pred_depth: Optional[Tensor] = None,
+                  gt_depth: Optional[Tensor] = None, tolerance: float = 0.1) -> Tensor:
+    """One pass over [H,W,3] colours and/or [H,W(,1)] depths -> float32[10] on the device, in the
+    order of ``METRIC_NAMES``.  No host synchronisation."""
+    lib = L.load()
+    ref = pred_rgb if pred_rgb is not None else pred_depth
+    assert ref is not None, "nothing to measure"
+    n_pix = ref.shape[0] * ref.shape[1]
+
+    def prep(t, last):
+        if t is None:
+            return None
+        t = t.to(torch.float32).contiguous()
+        assert t.numel() == n_pix * last, "shape mismatch between the images"
+        return t
+
+    pr, gr, pd, gd = prep(pred_rgb, 3), prep(gt_rgb, 3), prep(pred_depth, 1), prep(gt_depth, 1)
+    work = torch.empty(12, dtype=torch.float64, device=ref.device)
+    out = torch.empty(10, dtype=torch.float32, device=ref.device)
+    L.check(lib.qed_image_metrics(n_pix, L.ptr(pr), L.ptr(gr), L.ptr(pd), L.ptr(gd), float(tolerance), L.ptr(work),
+                                  L.ptr(out), _stream()), "qed_image_metrics")
+    return out
+
+
+def ssim_value(pred_rgb: Tensor, gt_rgb: Tensor) -> Tensor:
+    """StructuralSimilarityIndexMeasure(data_range=1, kernel_size=11) of two [H,W,3] images: torchmetrics
+    reflect-pads by 5 and crops the same 5 pixels again, i.e. the mean of the unpadded valid-window SSIM
+    map, which is what ssim.hip computes."""
+    lib = L.load()
+    H, W, _ = pred_rgb.shape
+    p, g = pred_rgb.to(torch.float32).contiguous(), gt_rgb.to(torch.float32).contiguous()
+    n_maps = lib.qed_ssim_maps_floats(H, W)
+    if n_maps < 0:
+        raise L.QedSplatError("image smaller than the 11 x 11 SSIM window")
+    maps = torch.empty(n_maps, dtype=torch.float32, device=p.device)
+    ssum = torch.empty(1, dtype=torch.float32, device=p.device)
+    L.check(lib.qed_ssim_fwd(H, W, 3, L.ptr(p), None, None, L.ptr(g), L.ptr(maps), L.ptr(ssum), _stream()), "qed_ssim_fwd")
+    return ssum.view(()) / (3.0 * (H - 10) * (W - 10))
+
+
+def _to_hwc(img: Tensor) -> Tensor:
+    """[1,3,H,W] / [3,H,W] (the layout the reference hands to torchmetrics) or [H,W,3] -> [H,W,3]."""
+    if img.dim() == 4:
+        img = img[0]
+    if img.shape[0] == 3 and img.shape[-1] != 3:
+        img = img.permute(1, 2, 0)
+    if img.dtype == torch.uint8:                                   # metrics.py:104-105
+        img = img.float() / 255.0
+    return img
+
+
+class RGBMetrics(torch.nn.Module):
+    """Mirror of metrics.py:84-112: ``forward(pred, gt) -> (psnr, ssim, lpips)`` as 0-dim device tensors."""
+
+    @torch.no_grad()
+    def forward(self, pred: Tensor, gt: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+        p, g = _to_hwc(pred), _to_hwc(gt)
+        m = image_metrics(p, g)
+        return m[1], ssim_value(p, g), torch.full((), float("nan"), device=p.device)
+
+
+class DepthMetrics(torch.nn.Module):
+    """Mirror of metrics.py:115-156: ``forward(pred, gt) -> (abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3)``."""
+
+    def __init__(self, tolerance: float = 0.1):
+        super().__init__()
+        self.tolerance = tolerance
+
+    @torch.no_grad()
+    def forward(self, pred: Tensor, gt: Tensor):
+        p = pred.reshape(pred.shape[-2], pred.shape[-1], 1) if pred.dim() == 3 and pred.shape[0] == 1 else pred
+        g = gt.reshape(p.shape).to(p.device)
+        m = image_metrics(None, None, p, g, self.tolerance)
+        return tuple(m[i] for i in range(2, 9))
+
+
+@torch.no_grad()
+def metrics_dict(pred_rgb: Tensor, gt_rgb: Tensor, pred_depth: Optional[Tensor], gt_depth: Optional[Tensor],
+                 tolerance: float = 0.1) -> Dict[str, Tensor]:
+    """The image part of get_metrics_dict (model.py:152-182) in two launches, values left on the device."""
+    m = image_metrics(pred_rgb, gt_rgb, pred_depth, gt_depth, tolerance)
+    out = {"rgb_mse": m[0], "rgb_psnr": m[1], "rgb_ssim": ssim_value(pred_rgb, gt_rgb),
+           "rgb_lpips": torch.full((), float("nan"), device=m.device)}
+    if pred_depth is not None:
+        out.update({n: m[i] for i, n in enumerate(METRIC_NAMES) if n.startswith("depth_") and n != "depth_n_valid"})
+    return out

@@ -454,6 +454,32 @@ class QEDSplatterModel(nn.Module):
         loss_dict["depth_loss"] = self.config.depth_lambda * loss             # model.py:116
         return loss_dict
 
+    # ---- get_metrics_dict (model.py:120-197) ----
+    def get_metrics_dict(self, outputs, batch) -> Dict[str, Tensor]:
+        """Same keys as the reference, but every value is a 0-dim DEVICE tensor (or an int for
+        ``gaussian_count``): the reference's ``float(...)``/``.item()`` per entry (model.py:160-182)
+        is a device synchronisation each, which caps iterations/s regardless of kernel speed; the
+        caller converts when (and if) it logs.  ``rgb_lpips`` is NaN (no pretrained weights here)."""
+        from .metrics import metrics_dict as _image_metrics
+        d = self._get_downscale_factor()
+
+        def resize(img):                                                       # model.py:131-147 (TF.resize, bilinear)
+            if d <= 1:
+                return img
+            size = (img.shape[0] // d, img.shape[1] // d)
+            return torch.nn.functional.interpolate(img.permute(2, 0, 1)[None].float(), size=size, mode="bilinear",
+                                                   align_corners=False, antialias=False)[0].permute(1, 2, 0)
+
+        gt_rgb = self.get_gt_img(resize(batch["image"]))[..., :3]
+        pred_rgb = outputs["rgb"][0] if outputs["rgb"].dim() == 4 else outputs["rgb"]
+        has_depth = "depth_image" in batch and outputs.get("depth") is not None
+        gt_depth = resize(batch["depth_image"]).to(self.device) if has_depth else None
+        with torch.no_grad():
+            out = dict(_image_metrics(pred_rgb.detach(), gt_rgb, outputs["depth"].detach() if has_depth else None, gt_depth))
+            out["gaussian_count"] = self.num_points
+            out["avg_min_scale"] = torch.nanmean(torch.exp(self.scales[..., -1]))      # model.py:192-194
+        return out
+
     # ---- fused training step: model.py:199-321 + 73-118 in as few passes as possible ----
     def fused_loss(self, camera, batch, background: Optional[Tensor] = None, sync: bool = True) -> Dict[str, Tensor]:
         """Forward + K8 fused loss.  Returns {"loss", "main_loss", "depth_loss"}: ``loss`` = main + depth is

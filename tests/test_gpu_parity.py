@@ -403,6 +403,55 @@ def test_ssim_errors_and_symmetry(cuda):
     assert float(ssim(a, b)) == pytest.approx(float(ssim(b, a)), rel=1e-6)
 
 
+def test_image_metrics_match_reference_vectors_and_oracle(cuda):
+    """qed_image_metrics against (a) the reference's own DepthMetrics output (committed KAT) and (b) the
+    oracle on a case with non-finite / below-tolerance / non-positive depths; SSIM and PSNR vs the oracle."""
+    import os
+    import numpy as np
+    from qed_splatter_amd.metrics import DepthMetrics, RGBMetrics, image_metrics
+    kats = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.npz"))
+    pred, gt = torch.from_numpy(kats["dm_pred"]), torch.from_numpy(kats["dm_gt"])
+    got = DepthMetrics()(pred.to(cuda), gt.to(cuda))
+    np.testing.assert_allclose([float(v) for v in got], kats["dm_out"], rtol=2e-5)
+    g = torch.Generator().manual_seed(5)
+    h, w = 97, 131
+    gd = torch.rand(h, w, 1, generator=g) * 5
+    pd = gd * (1 + 0.3 * torch.randn(h, w, 1, generator=g))
+    pd[0, :5] = float("nan"); gd[1, :5] = float("inf"); gd[2, :7] = 0.05; pd[3, :9] = -1.0; pd[4, :3] = 0.0
+    gr = torch.rand(h, w, 3, generator=g)
+    pr = (gr + 0.1 * torch.randn(h, w, 3, generator=g)).clamp(0, 1)
+    m = image_metrics(pr.to(cuda), gr.to(cuda), pd.to(cuda), gd.to(cuda)).cpu()
+    ref_d = O.depth_metrics(pd.double(), gd.double(), 0.1)
+    ref_mse, ref_psnr, ref_ssim = O.rgb_metrics(pr.double(), gr.double())
+    assert float(m[0]) == pytest.approx(float(ref_mse), rel=1e-5) and float(m[1]) == pytest.approx(float(ref_psnr), rel=1e-5)
+    for i, r in enumerate(ref_d):
+        if math.isinf(float(r)):
+            assert math.isinf(float(m[2 + i]))
+        else:
+            assert float(m[2 + i]) == pytest.approx(float(r), rel=2e-5), i
+    psnr, ssim_v, lpips = RGBMetrics()(pr.permute(2, 0, 1)[None].to(cuda), gr.permute(2, 0, 1)[None].to(cuda))
+    assert float(psnr) == pytest.approx(float(ref_psnr), rel=1e-5) and float(ssim_v) == pytest.approx(float(ref_ssim), rel=1e-5)
+    assert math.isnan(float(lpips))
+    none_valid = image_metrics(None, None, pd.to(cuda), torch.zeros_like(gd).to(cuda)).cpu()
+    assert all(math.isnan(float(v)) for v in none_valid[:9]) and float(none_valid[9]) == 0.0
+
+
+def test_get_metrics_dict_keys_and_values(cuda):
+    w, h, n = 160, 112, 2000
+    sc = scene(n, w, h, seed=11)
+    m, cam, batch = _model(sc, cuda)
+    m.eval()
+    with torch.no_grad():
+        out = m.get_outputs(cam)
+    md = m.get_metrics_dict(out, batch)
+    assert set(md) == {"rgb_mse", "rgb_psnr", "rgb_ssim", "rgb_lpips", "gaussian_count", "depth_abs_rel", "depth_sq_rel",
+                       "depth_rmse", "depth_rmse_log", "depth_a1", "depth_a2", "depth_a3", "avg_min_scale"}
+    assert md["gaussian_count"] == n and all(torch.is_tensor(v) and v.is_cuda for k, v in md.items() if k != "gaussian_count")
+    ref = O.depth_metrics(out["depth"].cpu().double(), sc["gt_depth"].double(), 0.1)
+    assert float(md["depth_abs_rel"]) == pytest.approx(float(ref[0]), rel=1e-4)
+    assert float(md["rgb_ssim"]) == pytest.approx(float(O.ssim(out["rgb"].cpu().double(), sc["gt_rgb"].double())), rel=1e-4)
+
+
 def test_fused_path_equals_api_path(cuda):
     """fused_loss (K8 kernel, fused activations) == get_outputs + get_loss_dict."""
     w, h, n = 200, 136, 6000

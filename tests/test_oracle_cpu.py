@@ -69,15 +69,11 @@ def test_product_get_loss_dict_matches_reference(kats):
 
 
 def test_depth_metrics_cross_check(kats):
-    """DepthMetrics (metrics.py:126-156) restated inline on the reference's vector."""
+    """oracle.depth_metrics (metrics.py:126-156) on the reference's own input/output vector."""
     pred, gt = torch.from_numpy(kats["dm_pred"]), torch.from_numpy(kats["dm_gt"])
-    valid = torch.isfinite(pred) & torch.isfinite(gt) & (gt > 0.1)
-    p, g = pred[valid], gt[valid]
-    thresh = torch.max(g / p, p / g)
-    vals = [(torch.abs(g - p) / g).mean(), ((g - p) ** 2 / g).mean(), torch.sqrt(((g - p) ** 2).mean()),
-            torch.sqrt(((torch.log(g) - torch.log(p)) ** 2).nanmean()), (thresh < 1.25).float().mean(),
-            (thresh < 1.25 ** 2).float().mean(), (thresh < 1.25 ** 3).float().mean()]
+    vals = O.depth_metrics(pred, gt, 0.1)
     np.testing.assert_allclose([float(v) for v in vals], kats["dm_out"], rtol=1e-6)
+    assert all(math.isnan(float(v)) for v in O.depth_metrics(pred, torch.zeros_like(gt)))   # metrics.py:134-143
 
 
 # ---- oracle regression against the committed golden vectors --------------------------------------
