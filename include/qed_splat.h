@@ -209,6 +209,43 @@ int qed_ssim_bwd(int32_t height, int32_t width, int32_t channels, const float* p
 int qed_image_metrics(int32_t n_pix, const float* pred_rgb, const float* gt_rgb, const float* pred_depth,
                       const float* gt_depth, float tolerance, double* workspace, float* out, void* stream);
 
+/* ---- densification / culling ---------------------------------------------------
+ * GPU side of the parent class's callbacks that consume model.py:249,289-292 (self.xys.absgrad,
+ * self.radii, self.last_size): SplatfactoModel.after_train / refinement_after / split_gaussians /
+ * dup_gaussians / cull_gaussians / dup_in_all_optim / remove_from_all_optim, restated in
+ * oracle/densify_oracle.py.  All buffers are the flat [means | scales | quats | opacities |
+ * features_dc | features_rest] layout of this package.
+ *
+ * qed_densify_accumulate (every step): for radii > 0: vis_counts += 1, xys_grad_norm +=
+ *   |absgrad| (absgrad = [N] rows of 2 floats, stride_floats apart), max_2Dsize = max(., radii *
+ *   inv_max_dim) with inv_max_dim = 1 / max(H, W).
+ * qed_densify_classify: flags[N] (bit0 split, bit1 duplicate, bit2 keep old, bit3 keep children,
+ *   bit4 keep duplicate), pos[4][N] exclusive scans {split rank, kept-old slot, kept-children slot,
+ *   kept-duplicate slot} followed by 4 * ceil(N/256) ints of scratch (qed_densify_pos_ints), totals[4] = {n_split, K_old, K_child, K_dup} (device).  densify = 0 is the
+ *   cull-only pass after stop_split_at.  Negative split_screen_size / cull_scale_thresh /
+ *   cull_screen_size switch the corresponding test off (step-dependent in the reference).
+ * qed_densify_emit: writes the N' = K_old + n_samples * K_child + K_dup rows of the new parameter and
+ *   Adam-moment buffers in the reference's order [kept old | children (sample-major) | duplicates];
+ *   children: mean + R(q/|q|) (exp(scale) * samples[s * n_split + split_rank]), scale = log(exp(s)/1.6),
+ *   zero moments.  h_totals = totals copied to the host (the caller needs N' to allocate).
+ * qed_densify_reset_opacity: opacities = min(opacities, max_logit), opacity moments = 0. */
+int qed_densify_accumulate(int32_t N, const float* absgrad, int32_t stride_floats, const int32_t* radii,
+                           float inv_max_dim, float* xys_grad_norm, float* vis_counts, float* max_2Dsize,
+                           void* stream);
+int64_t qed_densify_pos_ints(int32_t N);
+int qed_densify_classify(int32_t N, const float* scales, const float* opacities, const float* xys_grad_norm,
+                         const float* vis_counts, const float* max_2Dsize, int32_t densify,
+                         float half_max_dim, float densify_grad_thresh, float densify_size_thresh,
+                         float split_screen_size, float cull_alpha_thresh, float cull_scale_thresh,
+                         float cull_screen_size, uint8_t* flags, int32_t* pos, int32_t* totals, void* stream);
+int qed_densify_emit(int32_t N, int32_t n_samples, const uint8_t* flags, const int32_t* pos,
+                     const int32_t* h_totals, const float* samples, const float* old_params,
+                     const float* old_exp_avg, const float* old_exp_avg_sq, const int64_t* h_old_begin,
+                     float* new_params, float* new_exp_avg, float* new_exp_avg_sq,
+                     const int64_t* h_new_begin, void* stream);
+int qed_densify_reset_opacity(int32_t N, float* opacities, float* exp_avg, float* exp_avg_sq,
+                              float max_logit, void* stream);
+
 /* ---- fused multi-tensor Adam over one flat parameter buffer (config.py:44-68) --
  * n_groups contiguous segments; segment g covers elements [h_group_begin[g], h_group_begin[g+1])
  * and uses learning rate h_lr[g].  bias corrections use `step` (1-based). */

@@ -238,6 +238,25 @@ class QEDSplatterModel(nn.Module):
         self.crop_box = None
         self.camera_optimizer = None
 
+    def rebind_flat(self, flat: Tensor, n_points: int) -> None:
+        """Adopt a new flat parameter buffer (densification changes N): the six Parameters are
+        re-created as leaf views into it, in group order, with their per-Gaussian shapes kept."""
+        old_n = max(self.num_points, 1)
+        shapes = {n: (n_points,) + tuple(self.gauss_params[n].shape[1:]) for n in self.group_names}
+        widths = {n: self.gauss_params[n].numel() // old_n for n in self.group_names}
+        if self.num_points == 0:
+            widths = {n: int(torch.tensor(shapes[n][1:]).prod()) if len(shapes[n]) > 1 else 1 for n in self.group_names}
+        assert flat.numel() == n_points * sum(widths.values()) and flat.dtype == torch.float32 and flat.is_contiguous()
+        params, begin, off = {}, [0], 0
+        for name in self.group_names:
+            n = n_points * widths[name]
+            params[name] = nn.Parameter(flat[off:off + n].view(shapes[name]))
+            off += n
+            begin.append(off)
+        self._flat = flat
+        self.group_begin = begin
+        self.gauss_params = nn.ParameterDict(params)
+
     # ---- parameter groups (same names as the reference reads at model.py:227-239) ----
     means = property(lambda self: self.gauss_params["means"])
     scales = property(lambda self: self.gauss_params["scales"])
@@ -556,6 +575,15 @@ class FlatAdam:
         self.lr[i] = float(lr)
         self._lr[i] = float(lr)
         self.dev_lr[i] = float(lr)
+
+    def rebind(self, exp_avg: Tensor, exp_avg_sq: Tensor) -> None:
+        """Adopt new moment buffers after the model adopted a new flat parameter buffer (densification);
+        the step count carries on, as torch.optim.Adam's per-parameter ``step`` does in the reference."""
+        import ctypes as C
+        assert exp_avg.numel() == self.model.flat_params.numel() == exp_avg_sq.numel()
+        begins = list(self.model.group_begin)
+        self._begin = (C.c_int64 * len(begins))(*begins)
+        self.exp_avg, self.exp_avg_sq = exp_avg, exp_avg_sq
 
     @torch.no_grad()
     def step(self, device_state: bool = False) -> None:

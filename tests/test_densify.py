@@ -1,0 +1,201 @@
+"""densification / culling.  CPU tests pin the oracle restatement on hand-made
+cases; GPU tests compare csrc/densify.hip (through the C ABI and the Densifier host class) with it."""
+from __future__ import annotations
+
+import math
+
+import pytest
+import torch
+
+from oracle import densify_oracle as D
+from tests.util import PARAM_NAMES
+
+
+def _scenario(n, seed, rest=15):
+    """Parameters, Adam moments and statistics whose decision inputs sit well away from every threshold
+    (fp32 vs fp64 / expf vs torch.exp must not flip a decision, since one flip shifts every later row)."""
+    g = torch.Generator().manual_seed(seed)
+
+    def choice(vals, size):
+        v = torch.tensor(vals, dtype=torch.float32)
+        return v[torch.randint(0, len(vals), size, generator=g)]
+
+    jitter = lambda size: 1.0 + 0.01 * (2 * torch.rand(size, generator=g) - 1)                      # noqa: E731
+    smax = choice([0.002, 0.008, 0.012, 0.05, 0.6], (n,)) * jitter((n,))
+    scales = torch.log(smax[:, None] * torch.tensor([1.0, 0.7, 0.4])[None, :]).float()
+    scales = scales[torch.arange(n)[:, None], torch.stack([torch.randperm(3, generator=g) for _ in range(n)])]
+    sig = choice([0.001, 0.004, 0.2, 0.9], (n, 1)) * jitter((n, 1))
+    p = {"means": torch.randn(n, 3, generator=g), "scales": scales, "quats": torch.randn(n, 4, generator=g),
+         "opacities": torch.log(sig / (1 - sig)), "features_dc": torch.rand(n, 3, generator=g),
+         "features_rest": torch.randn(n, rest, 3, generator=g) * 0.1}
+    m = {k: torch.randn_like(v) * 0.01 for k, v in p.items()}
+    v = {k: torch.rand_like(v) * 0.01 for k, v in p.items()}
+    st = D.DensifyState()
+    st.vis_counts = torch.randint(1, 40, (n,), generator=g).float()
+    avg = choice([0.0001, 0.002], (n,)) * jitter((n,))                  # x 0.5 max(H,W) = 960 -> vs 0.0005
+    st.xys_grad_norm = avg / 960.0 * st.vis_counts
+    st.max_2Dsize = choice([0.01, 0.08, 0.2], (n,)) * jitter((n,))
+    return p, m, v, st
+
+
+# ---------------------------------------------------------------------------------------------------
+# CPU: the oracle itself
+# ---------------------------------------------------------------------------------------------------
+def test_oracle_after_train_accumulates():
+    st = D.DensifyState()
+    cfg = D.DensifyConfig()
+    absgrad = torch.tensor([[3.0, 4.0], [1.0, 0.0], [6.0, 8.0]])
+    radii = torch.tensor([5, 0, 48])
+    D.after_train(st, absgrad, radii, (1080, 1920), 10, cfg)
+    D.after_train(st, absgrad, torch.tensor([96, 0, 0]), (1080, 1920), 11, cfg)
+    assert st.vis_counts.tolist() == [3.0, 1.0, 2.0]                     # starts at ONE
+    assert st.xys_grad_norm.tolist() == [10.0, 0.0, 10.0]
+    assert st.max_2Dsize.tolist() == pytest.approx([96 / 1920, 0.0, 48 / 1920])
+    D.after_train(st, absgrad, radii, (1080, 1920), cfg.stop_split_at, cfg)   # no updates once splitting stopped
+    assert st.vis_counts.tolist() == [3.0, 1.0, 2.0]
+
+
+def test_oracle_refinement_hand_case():
+    """Five Gaussians: big+high-grad (split), small+high-grad (dup), just above the size threshold
+    (split AND, after the in-place shrink, dup), transparent (cull), quiet (kept)."""
+    cfg = D.DensifyConfig()
+    smax = torch.tensor([0.05, 0.002, 0.012, 0.05, 0.05])
+    p = {"means": torch.arange(15.0).reshape(5, 3), "scales": torch.log(smax)[:, None].repeat(1, 3),
+         "quats": torch.tensor([[1.0, 0, 0, 0]]).repeat(5, 1), "opacities": torch.tensor([[2.0], [2.0], [2.0], [-8.0], [2.0]]),
+         "features_dc": torch.rand(5, 3), "features_rest": torch.rand(5, 15, 3)}
+    m = {k: torch.ones_like(v) for k, v in p.items()}
+    v = {k: torch.ones_like(v) for k, v in p.items()}
+    st = D.DensifyState()
+    st.vis_counts = torch.full((5,), 10.0)
+    st.xys_grad_norm = torch.tensor([0.002, 0.002, 0.002, 0.002, 0.0001]) / 960 * 10
+    st.max_2Dsize = torch.zeros(5)
+    samples = torch.ones(6, 3)
+    np_, nm, nv, info = D.refinement_after(p, m, v, st, 700, cfg, (1080, 1920), 10, samples)
+    # splits {0, 2, 3}; dups {1, 2}; culled: the split originals 0, 2, 3 and the children of 3 (transparent)
+    assert (info["n_split"], info["n_dup"], info["did_densify"]) == (3, 2, True)
+    assert np_["means"].shape[0] == 2 + 2 * 2 + 2                      # kept old {1,4} + children of {0,2} + dups
+    assert torch.equal(np_["means"][:2], p["means"][[1, 4]])
+    # sample-major children: (s0: 0, 2), (s1: 0, 2); unit quaternion, samples of ones
+    child0 = p["means"][0] + 0.05
+    assert torch.allclose(np_["means"][2], child0) and torch.allclose(np_["means"][4], child0)
+    assert torch.allclose(np_["scales"][2], torch.log(torch.tensor(0.05 / 1.6)).expand(3))
+    # duplicates: 1 unchanged, 2 carries the SHRUNK scale
+    assert torch.equal(np_["scales"][6], p["scales"][1])
+    assert torch.allclose(np_["scales"][7], torch.log(torch.tensor(0.012 / 1.6)).expand(3))
+    assert torch.equal(nm["means"][:2], torch.ones(2, 3)) and float(nm["means"][2:].abs().sum()) == 0.0
+    assert st.xys_grad_norm is None and st.vis_counts is None and st.max_2Dsize is None
+
+
+def test_oracle_schedule():
+    cfg = D.DensifyConfig()
+    p, m, v, st = _scenario(64, 1)
+    out = D.refinement_after(p, m, v, st, cfg.warmup_length, cfg, (1080, 1920), 10)     # warm-up: untouched
+    assert out[0] is p and st.vis_counts is not None
+    # step 3100: reset_interval 3000 -> opacity reset, no densification (3100 % 3000 = 100 <= 10 + 100)
+    np_, nm, nv, info = D.refinement_after(p, m, v, st, 3100, cfg, (1080, 1920), 10)
+    assert info["opacity_reset"] and not info["did_densify"] and np_["means"].shape[0] == 64
+    assert float(np_["opacities"].max()) <= math.log(0.01 / 0.99) + 1e-6
+    assert float(nm["opacities"].abs().sum()) == 0.0 and torch.equal(nm["means"], m["means"])
+    # after stop_split_at: cull only
+    p, m, v, st = _scenario(64, 2)
+    np_, nm, nv, info = D.refinement_after(p, m, v, st, 15100, cfg, (1080, 1920), 10)
+    assert not info["did_densify"] and info["n_culled"] > 0 and np_["means"].shape[0] == 64 - info["n_culled"]
+
+
+# ---------------------------------------------------------------------------------------------------
+# GPU: kernels vs oracle
+# ---------------------------------------------------------------------------------------------------
+def _gpu_model(p, m, v, dev):
+    from qed_splatter_amd.model import FlatAdam, QEDSplatterModel, QEDSplatterModelConfig
+    model = QEDSplatterModel(QEDSplatterModelConfig(), **{k: p[k].to(dev) for k in PARAM_NAMES})
+    opt = FlatAdam(model)
+    off = 0
+    for name in model.group_names:
+        n = p[name].numel()
+        opt.exp_avg[off:off + n] = m[name].reshape(-1).to(dev)
+        opt.exp_avg_sq[off:off + n] = v[name].reshape(-1).to(dev)
+        off += n
+    model.last_size = (1080, 1920)
+    return model, opt
+
+
+def _moments(model, opt):
+    out_m, out_v = {}, {}
+    for name, b0, b1 in zip(model.group_names, model.group_begin[:-1], model.group_begin[1:]):
+        shape = model.gauss_params[name].shape
+        out_m[name] = opt.exp_avg[b0:b1].view(shape).cpu()
+        out_v[name] = opt.exp_avg_sq[b0:b1].view(shape).cpu()
+    return out_m, out_v
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("step,n,rest", [(700, 5000, 15), (5000, 3000, 15), (15100, 4000, 15), (3100, 1000, 15),
+                                         (700, 777, 0), (400, 100, 15)])
+def test_refinement_matches_oracle(cuda, step, n, rest):
+    from qed_splatter_amd.densify import DensifyConfig, Densifier
+    p, m, v, st = _scenario(n, seed=step + n, rest=rest)
+    cfg_o = D.DensifyConfig()
+    splits_guess = 4 * n
+    samples_all = torch.randn(splits_guess, 3, generator=torch.Generator().manual_seed(9))
+    # the oracle tells how many samples are needed; both sides then use the same ones
+    probe = D.DensifyState(); probe.__dict__.update({k: (t.clone() if t is not None else None) for k, t in st.__dict__.items()})
+    _, _, _, info0 = D.refinement_after(p, m, v, probe, step, cfg_o, (1080, 1920), 10, samples_all[:0] if False else None)
+    ns = cfg_o.n_split_samples * info0["n_split"]
+    samples = samples_all[:ns]
+    ref_p, ref_m, ref_v, info = D.refinement_after(p, m, v, st, step, cfg_o, (1080, 1920), 10, samples if info0["did_densify"] else None)
+
+    model, opt = _gpu_model(p, m, v, cuda)
+    dz = Densifier(model, opt, DensifyConfig(), num_train_data=10)
+    p2, m2, v2, st2 = _scenario(n, seed=step + n, rest=rest)
+    dz.xys_grad_norm, dz.vis_counts, dz.max_2Dsize = (t.to(cuda) for t in (st2.xys_grad_norm, st2.vis_counts, st2.max_2Dsize))
+    got = dz.refinement_after(step, samples.to(cuda) if ns else None)
+    assert got["did_densify"] == info["did_densify"] and got["opacity_reset"] == info["opacity_reset"]
+    assert (got["n_split"], got["n_dup"], got["n_culled"]) == (info["n_split"], info["n_dup"], info["n_culled"])
+    assert model.num_points == ref_p["means"].shape[0] == got["n_after"]
+    gm, gv = _moments(model, opt)
+    for name in PARAM_NAMES:
+        a, b = model.gauss_params[name].detach().cpu(), ref_p[name]
+        assert a.shape == b.shape, name
+        assert torch.allclose(a, b, rtol=2e-6, atol=2e-6), (name, float((a - b).abs().max()))
+        assert torch.equal(gm[name], ref_m[name]) and torch.equal(gv[name], ref_v[name]), name
+    if step > 500:
+        assert dz.xys_grad_norm is None and dz.vis_counts is None and dz.max_2Dsize is None
+    # the model still trains after the swap: parameters are leaf views of one flat buffer in group order
+    assert model.flat_params.numel() == sum(model.gauss_params[k].numel() for k in PARAM_NAMES)
+    assert model.gauss_params["means"].data_ptr() == model.flat_params.data_ptr()
+
+
+@pytest.mark.gpu
+def test_after_train_matches_oracle_and_training_continues(cuda):
+    """Statistics accumulated from real backward passes, then a refinement, then another training step."""
+    from qed_splatter_amd.densify import DensifyConfig, Densifier
+    from qed_splatter_amd.model import FlatAdam
+    from tests.test_gpu_parity import _model
+    from tests.util import scene
+    w, h, n = 160, 112, 3000
+    sc = scene(n, w, h, seed=21)
+    model, cam, batch = _model(sc, cuda)
+    opt = FlatAdam(model)
+    cfg = DensifyConfig(warmup_length=0, refine_every=2, densify_grad_thresh=1e-6)
+    dz = Densifier(model, opt, cfg, num_train_data=0, seed=3)
+    st = D.DensifyState()
+    for step in range(1, 4):
+        for prm in model.parameters():
+            prm.grad = None
+        out = model.fused_loss(cam, batch)
+        out["loss"].backward()
+        opt.step()
+        dz.after_train(step)
+        D.after_train(st, model.xys.absgrad[0].cpu(), model.radii.cpu(), model.last_size, step, D.DensifyConfig())
+    torch.testing.assert_close(dz.vis_counts.cpu(), st.vis_counts)
+    torch.testing.assert_close(dz.xys_grad_norm.cpu(), st.xys_grad_norm, rtol=1e-5, atol=1e-9)
+    torch.testing.assert_close(dz.max_2Dsize.cpu(), st.max_2Dsize)
+    info = dz.refinement_after(3)
+    assert info["did_densify"] and info["n_after"] == model.num_points != n
+    for prm in model.parameters():
+        prm.grad = None
+    out = model.fused_loss(cam, batch)
+    out["loss"].backward()
+    opt.step()
+    assert torch.isfinite(out["loss"]) and model.gauss_params["means"].grad.shape == (model.num_points, 3)
+    assert opt.exp_avg.numel() == model.flat_params.numel()

@@ -52,6 +52,16 @@ def _worker(rank, world, port, q):
         r = torch.full((50,), float(10 * (rank + 1)))
         allreduce_densification_stats(a, c, r)
         ok = ok and float(a[0]) == sum(range(1, world + 1)) and float(c[0]) == world and float(r[0]) == 10 * world
+        # Densifier.all_reduce_stats: vis_counts starts at ONE on every rank; exactly one "one" survives
+        from qed_splatter_amd.densify import Densifier
+        dz = Densifier.__new__(Densifier)
+        dz.xys_grad_norm = torch.full((50,), 0.5 * (rank + 1))
+        dz.vis_counts = torch.full((50,), 1.0 + 3 * (rank + 1))        # 1 + visits on this rank
+        dz.max_2Dsize = torch.full((50,), 0.01 * (rank + 1))
+        dz.all_reduce_stats()
+        visits = 3 * sum(range(1, world + 1))
+        ok = ok and float(dz.vis_counts[0]) == 1.0 + visits and abs(float(dz.max_2Dsize[0]) - 0.01 * world) < 1e-9
+        ok = ok and abs(float(dz.xys_grad_norm[0]) - 0.5 * sum(range(1, world + 1))) < 1e-6
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
