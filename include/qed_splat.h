@@ -260,6 +260,13 @@ int qed_adam_step_dev(float* params, const float* grads, float* exp_avg, float* 
                       int32_t n_groups, const int64_t* h_group_begin, const float* dev_lr, float beta1,
                       float beta2, float eps, float* dev_state, void* stream);
 
+/* ExponentialDecayScheduler of one group (the reference schedules "means": 1.6e-4 -> 1.6e-6 over
+ * 30000 steps, config.py:46-51) from the device step counter, for graph replay: dev_lr_slot[0] =
+ * exp((1-t) log lr_init + t log lr_final), t = clip(dev_state[0] / max_steps, 0, 1).  Call it before
+ * qed_adam_step_dev (dev_state[0] is then the 0-based index of the step about to be taken). */
+int qed_lr_exp_decay_dev(float* dev_lr_slot, const float* dev_state, float lr_init, float lr_final,
+                         int32_t max_steps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -229,6 +229,17 @@ __global__ void adam_tick_kernel(float* __restrict__ state, float beta1, float b
     }
 }
 
+// ExponentialDecayScheduler of the "means" group (config.py:46-51) evaluated from the device step
+// counter: lr = exp((1-t) log lr_init + t log lr_final), t = clip(step / max_steps, 0, 1), step = the
+// number of optimiser steps taken so far (the scheduler advances after optimizer.step()).
+__global__ void lr_exp_decay_kernel(float* __restrict__ lr_slot, const float* __restrict__ state, float log_init,
+                                    float log_final, float inv_max_steps) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float t = fminf(fmaxf(state[0] * inv_max_steps, 0.f), 1.f);
+        lr_slot[0] = expf(log_init * (1.f - t) + log_final * t);
+    }
+}
+
 }  // namespace qed
 
 using namespace qed;
@@ -305,6 +316,14 @@ extern "C" int qed_adam_step_dev(float* params, const float* grads, float* exp_a
     hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dev_state, beta1, beta2);
     return adam_launch(params, grads, exp_avg, exp_avg_sq, n_groups, h_group_begin, nullptr, beta1, beta2, eps, 1,
                        dev_state, dev_lr, stream);
+}
+
+extern "C" int qed_lr_exp_decay_dev(float* dev_lr_slot, const float* dev_state, float lr_init, float lr_final,
+                                    int32_t max_steps, void* stream) {
+    QED_REQUIRE(dev_lr_slot && dev_state && lr_init > 0.f && lr_final > 0.f && max_steps > 0, "bad arguments");
+    hipLaunchKernelGGL(lr_exp_decay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dev_lr_slot, dev_state,
+                       logf(lr_init), logf(lr_final), 1.f / (float)max_steps);
+    return check_launch("qed_lr_exp_decay_dev");
 }
 
 static int adam_launch(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t n_groups,

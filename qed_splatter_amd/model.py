@@ -545,18 +545,38 @@ class QEDSplatterModel(nn.Module):
         return {"loss": total, "main_loss": parts[0], "depth_loss": parts[1]}
 
 
+def exponential_decay_lr(step: int, lr_init: float, lr_final: float, max_steps: int, warmup_steps: int = 0,
+                         lr_pre_warmup: float = 0.0, ramp: str = "cosine") -> float:
+    """Nerfstudio's ExponentialDecayScheduler (the schedule config.py:46-51 / :63-67 attach to "means" and
+    "camera_opt"): log-linear from lr_init to lr_final over max_steps after an optional warm-up ramp."""
+    import math
+    if step < warmup_steps:
+        if ramp == "cosine":
+            return lr_pre_warmup + (lr_init - lr_pre_warmup) * math.sin(0.5 * math.pi * min(max(step / warmup_steps, 0), 1))
+        return lr_pre_warmup + (lr_init - lr_pre_warmup) * step / warmup_steps
+    t = min(max((step - warmup_steps) / (max_steps - warmup_steps), 0.0), 1.0)
+    return math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
+
+
 class FlatAdam:
     """Fused multi-tensor Adam over the model's flat parameter buffer, one learning rate per group
-    (the six Gaussian groups of config.py:44-68, eps=1e-15).  SURVEY 8(f) rank 2."""
+    (the six Gaussian groups of config.py:44-68, eps=1e-15) and the reference's exponential decay of
+    the "means" rate (config.py:46-51).  SURVEY 8(f) rank 2."""
+
+    MEANS_SCHEDULE = (1.6e-6, 30000)           # lr_final, max_steps (config.py:48-50)
 
     DEFAULT_LRS = {"means": 1.6e-4, "scales": 0.005, "quats": 0.001, "opacities": 0.05,
                    "features_dc": 0.0025, "features_rest": 0.0025 / 20}
 
     def __init__(self, model: QEDSplatterModel, lrs: Optional[Dict[str, float]] = None, betas=(0.9, 0.999),
-                 eps: float = 1e-15):
+                 eps: float = 1e-15, means_schedule: Optional[tuple] = None):
+        """``means_schedule=(lr_final, max_steps)`` turns on the exponential decay of the "means" rate
+        (``FlatAdam.MEANS_SCHEDULE`` is the reference's); None keeps every rate constant."""
         import ctypes as C
         self.model = model
+        self.means_schedule = means_schedule
         lrs = {**self.DEFAULT_LRS, **(lrs or {})}
+        self._means_lr_init = float(lrs["means"])
         self.lr = [float(lrs[n]) for n in model.group_names]
         begins = list(model.group_begin)
         self._begin = (C.c_int64 * len(begins))(*begins)
@@ -594,8 +614,17 @@ class FlatAdam:
         g = self.model.flat_grad()
         if g is None:
             return
-        self.t += 1
         lib = L.load()
+        if self.means_schedule is not None:                      # the rate of the step about to be taken
+            lr_final, max_steps = self.means_schedule
+            i = self.model.group_names.index("means")
+            if device_state:
+                L.check(lib.qed_lr_exp_decay_dev(L.ptr(self.dev_lr[i:i + 1]), L.ptr(self.dev_state), self._means_lr_init,
+                                                 float(lr_final), int(max_steps), _stream()), "qed_lr_exp_decay_dev")
+            else:
+                self.lr[i] = exponential_decay_lr(self.t, self._means_lr_init, lr_final, max_steps)
+                self._lr[i] = self.lr[i]
+        self.t += 1
         if device_state:
             L.check(lib.qed_adam_step_dev(L.ptr(p), L.ptr(g), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
                                           len(self.lr), C.cast(self._begin, C.c_void_p), L.ptr(self.dev_lr),

@@ -537,6 +537,57 @@ def test_fused_adam_matches_torch(cuda):
             ref_params[k].data.copy_(m.gauss_params[k].data)
 
 
+def test_training_reduces_loss(cuda):
+    """60 fused steps from perturbed parameters against a render of the unperturbed scene."""
+    from qed_splatter_amd.model import FlatAdam
+    w, h, n = 160, 112, 3000
+    sc = scene(n, w, h, seed=31)
+    gt_model, cam, _ = _model(sc, cuda)
+    gt_model.eval()
+    with torch.no_grad():
+        gt = gt_model.get_outputs(cam)
+    batch = {"image": gt["rgb"].contiguous(), "depth_image": gt["depth"].contiguous()}
+    g = torch.Generator().manual_seed(1)
+    sc2 = dict(sc)
+    sc2["means"] = sc["means"] + 0.01 * torch.randn(sc["means"].shape, generator=g)
+    sc2["features_dc"] = sc["features_dc"] + 0.3 * torch.randn(sc["features_dc"].shape, generator=g)
+    m, cam, _ = _model(sc2, cuda)
+    opt = FlatAdam(m, means_schedule=FlatAdam.MEANS_SCHEDULE)
+    hist = []
+    for _ in range(60):
+        for p in m.parameters():
+            p.grad = None
+        out = m.fused_loss(cam, batch)
+        out["loss"].backward()
+        opt.step()
+        hist.append(float(out["loss"].detach()))
+    assert all(math.isfinite(v) for v in hist) and hist[-1] < 0.5 * hist[0], (hist[0], hist[-1])
+
+
+def test_means_lr_schedule_eager_and_device(cuda):
+    """ExponentialDecayScheduler of "means" (config.py:46-51): host evaluation == device evaluation == formula."""
+    from qed_splatter_amd.model import FlatAdam, exponential_decay_lr
+    sc = scene(500, 64, 64, seed=3)
+    outs = []
+    for device_state in (False, True):
+        m, cam, batch = _model(sc, cuda)
+        opt = FlatAdam(m, means_schedule=(1.6e-6, 20))
+        for step in range(25):
+            for k in PARAM_NAMES:
+                m.gauss_params[k].grad = torch.ones_like(m.gauss_params[k])
+            opt.step(device_state=device_state)
+            want = exponential_decay_lr(step, 1.6e-4, 1.6e-6, 20)
+            got = float(opt.dev_lr[0]) if device_state else opt.lr[0]
+            assert got == pytest.approx(want, rel=2e-6), (device_state, step)
+        outs.append(m.gauss_params["means"].detach().clone())
+    assert exponential_decay_lr(0, 1.6e-4, 1.6e-6, 20) == pytest.approx(1.6e-4) and \
+        exponential_decay_lr(10, 1.6e-4, 1.6e-6, 20) == pytest.approx(1.6e-5) and \
+        exponential_decay_lr(99, 1.6e-4, 1.6e-6, 20) == pytest.approx(1.6e-6)
+    assert exponential_decay_lr(500, 1e-4, 5e-7, 30000, warmup_steps=1000, lr_pre_warmup=0.0) == \
+        pytest.approx(1e-4 * math.sin(0.25 * math.pi))                 # camera_opt's cosine warm-up (config.py:63-67)
+    assert_close(outs[0], outs[1], 1e-6, "means after scheduled steps (host vs device rate)")
+
+
 # --------------------------------------------------------------------------------------------------
 # committed golden fixtures (tests/golden/oracle_small.npz)
 # --------------------------------------------------------------------------------------------------
