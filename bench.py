@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--graph", dest="graph", action="store_true", default=None,
                     help="replay the step from a captured hipGraph (default at 1 GPU)")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="eager dispatch")
+    ap.add_argument("--graph-split", action="store_true",
+                    help="capture forward+backward and the Adam step as two graphs with the gradient all-reduce "
+                         "between them (the default for N > 1; this flag forces it at N = 1 for testing)")
     return ap.parse_args()
 
 
@@ -180,28 +183,67 @@ def main():
     # a second, un-instrumented timed region gives the headline number (event records cost host time).
     # Default at N = 1: the whole step replayed from one captured hipGraph (same kernels, same work;
     # only the host dispatch cost is removed).  --no-graph times eager dispatch instead.
-    use_graph = args.graph if args.graph is not None else (world == 1)
+    # N > 1: forward+backward and the Adam step are captured as TWO graphs and the RCCL all-reduce of the
+    # flat gradient is issued between them (a collective is not captured: it stays an ordinary call on
+    # the process group's stream).
+    use_graph = args.graph if args.graph is not None else True
+    split = use_graph and (world > 1 or args.graph_split)
     run = lambda: step(args.sync_m)
+    dispatch = "eager"
     if use_graph:
         from qed_splatter_amd.graph import GraphedTrainStep
 
-        def graph_step():
+        def fwd_bwd():
             for p in model.parameters():
                 p.grad = None
             losses = model.fused_loss(cam, batch, background=bg, sync=False)
             losses["loss"].backward()
-            if world > 1:
-                allreduce_flat_grad(model, world)
+            return losses
+
+        def adam_only():
             opt.step(device_state=True)
+            return {}
+
+        def graph_step():
+            losses = fwd_bwd()
+            adam_only()
             return losses
 
         opt.dev_state[0] = float(opt.t)               # hand the step counter over to the device-side state
-        graphed = GraphedTrainStep(graph_step, dev, warmup=3, check_every=0)
-        run = graphed.replay
-        for _ in range(3):
-            run()
-        graphed.check()
-        log("step captured into a hipGraph")
+        try:
+            if split:
+                g_fb = GraphedTrainStep(fwd_bwd, dev, warmup=3, check_every=0)
+                g_fb.replay()                          # fills the captured (static) .grad buffers before Adam's
+                g_adam = GraphedTrainStep(adam_only, dev, warmup=1, check_every=0)   # warm-up run reads them
+                graphed = g_fb
+
+                def run():
+                    g_fb.replay()
+                    if world > 1:
+                        allreduce_flat_grad(model, world)
+                    g_adam.replay()
+                dispatch = "two hipGraphs (fwd+bwd | Adam) around the gradient all-reduce"
+            else:
+                graphed = GraphedTrainStep(graph_step, dev, warmup=3, check_every=0)
+                run = graphed.replay
+                dispatch = "hipGraph replay of the whole step"
+            captured = True
+        except Exception as e:                         # capture is an optimisation of dispatch only
+            log(f"graph capture failed ({type(e).__name__}: {e})")
+            torch.cuda.synchronize()
+            captured = False
+        if dist is not None:                           # every rank must issue the same collectives from here on
+            ok = torch.tensor([1 if captured else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            captured = bool(int(ok))
+        if captured:
+            for _ in range(3):
+                run()
+            graphed.check()
+            log(f"step captured: {dispatch}")
+        else:
+            use_graph, dispatch = False, "eager (graph capture failed)"
+            run = lambda: step(args.sync_m)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -251,7 +293,7 @@ def main():
                        "gaussians": n, "visible": n_vis, "intersections": M, "width": w, "height": h,
                        "parallelism": f"dp{world} (camera-sharded, flat-gradient all-reduce)" if world > 1 else "single",
                        "async_intersection_count": not args.sync_m,
-                       "dispatch": "hipGraph replay of the whole step" if use_graph else "eager"},
+                       "dispatch": dispatch},
             "msplats_per_s": n_vis * world / (dt2 / args.steps) / 1e6,
             "ms_per_step_instrumented": dt / args.steps * 1e3,
             "kernels_ms": {k: round(v[1], 4) for k, v in sorted(kern.items())},

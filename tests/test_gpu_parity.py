@@ -664,6 +664,39 @@ def test_graphed_step_matches_eager(cuda):
     assert math.isfinite(float(out["main_loss"])) and float(o2.dev_state[0]) == 6.0
 
 
+def test_split_graphs_match_eager(cuda):
+    """Forward+backward and Adam captured as two graphs (what bench.py does around the all-reduce at N > 1)."""
+    from qed_splatter_amd.graph import GraphedTrainStep
+    from qed_splatter_amd.model import FlatAdam
+    w, h, n = 160, 112, 4000
+    sc = scene(n, w, h, seed=33)
+    stream = torch.cuda.Stream(device=cuda)
+    with torch.cuda.stream(stream):
+        m1, cam1, batch1 = _model(sc, cuda)
+        m2, cam2, batch2 = _model(sc, cuda)
+        o1, o2 = FlatAdam(m1), FlatAdam(m2)
+
+        def fwd_bwd(m, cam, batch):
+            for p in m.parameters():
+                p.grad = None
+            lf = m.fused_loss(cam, batch, sync=False)
+            lf["loss"].backward()
+            return lf
+
+        for _ in range(4):
+            fwd_bwd(m1, cam1, batch1)
+            o1.step(device_state=True)
+        g_fb = GraphedTrainStep(lambda: fwd_bwd(m2, cam2, batch2), cuda, warmup=2, check_every=1)
+        g_fb.replay()                                    # valid gradients in the static buffers
+        g_adam = GraphedTrainStep(lambda: (o2.step(device_state=True), {})[1], cuda, warmup=1, check_every=0)  # step 1
+        for _ in range(3):                               # steps 2-4
+            g_fb.replay()
+            g_adam.replay()
+        torch.cuda.synchronize()
+    assert_close(m2.flat_params, m1.flat_params, 1e-5, "parameters after 4 steps (two graphs vs eager)")
+    assert float(o2.dev_state[0]) == 4.0
+
+
 def test_one_stage_entry_points_match_two_stage(cuda, lib):
     """qed_isect_scan + qed_isect_emit + qed_sort_pairs (64-bit keys) + qed_tile_offsets -- the one-stage
     decomposition still exported by the C ABI -- give exactly the list that qed_bin_tiles produces."""
