@@ -35,6 +35,7 @@ extern "C" {
 
 #define QED_TILE 16             /* BLOCK_WIDTH = 16, model.py:243 */
 #define QED_SPLAT_FLOATS 12     /* packed per-(camera,Gaussian) record, see qed_project_fwd */
+#define QED_LOSS_SUMS_FLOATS (8 + 4 * 1024) /* sums workspace of qed_loss_reduce / qed_loss_grad */
 #define QED_VSPLAT_FLOATS 16    /* packed per-(camera,Gaussian) gradient row, see qed_composite_bwd */
 
 /* flags of qed_project_fwd / qed_project_bwd */
@@ -167,8 +168,9 @@ int qed_composite_bwd(int32_t C, int32_t N, const float* splats, const int32_t* 
 /* ---- K8: fused image-space loss + gradient ------------------------------------------------------
  * Collapses model.py:295-297 (background composite + clamp), :304-306 (depth fix-up), :87-116
  * (masked depth-L1, depth_lambda) and the L1 part of the parent's RGB loss into one pass.
- * Pass 1 (qed_loss_reduce) fills sums[8] (only {n_valid, max depth} are needed before gradients;
- * the two loss sums are accumulated by pass 2); pass 2 (qed_loss_grad) writes v_render[H,W,channels] and v_alpha[H,W] for
+ * Pass 1 (qed_loss_reduce) fills per-workgroup partials in sums[QED_LOSS_SUMS_FLOATS] (only {n_valid,
+ * max depth} are needed before gradients; the two loss sums are accumulated by pass 2, which leaves
+ * sums[0..3] = {sum|rgb-gt|, sum|d-dgt|, n_valid, max depth}); pass 2 (qed_loss_grad) writes v_render[H,W,channels] and v_alpha[H,W] for
  *   loss = rgb_weight * mean|rgb - gt| + depth_lambda * sum|d - dgt| / n_valid
  * and the scalar losses -> losses[0..2] = {rgb term, depth term, their sum}.  mask[H,W] may be
  * NULL (model.py:93-97).  An additional term on the same clamped colour (the SSIM part of the

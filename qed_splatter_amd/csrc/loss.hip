@@ -57,13 +57,19 @@ __device__ __forceinline__ PixelEval eval_pixel(const float* __restrict__ render
     return p;
 }
 
-// sums: [0] sum |rgb - gt|   [1] sum |depth - gt| over valid   [2] n_valid   [3] max depth (ordered int bits)
-//       [4] workgroups of the gradient pass that have finished (last one writes the losses)
+// sums (QED_LOSS_SUMS_FLOATS floats): from [8] on four rows of kLossMaxGrid per-workgroup partials: n_valid, max depth
+// (pass 1), sum |rgb - gt|, sum |depth - gt| (pass 2); loss_finalize_kernel folds them into sums[0..3]
+// and the scalar losses.  Per-workgroup slots instead of same-address
+// atomics: those serialise at ~12 ns each (measured: pass time grew linearly with the grid, 23-37 ns
+// per workgroup), which capped the grid at 2 workgroups per CU and the passes at ~3 TB/s.
 //
 // Pass 1 only needs what must be known BEFORE a gradient can be written: the number of valid depth
 // pixels (its reciprocal scales every depth gradient) and the largest rendered depth (the value
 // alpha == 0 pixels take, model.py:306).  It reads the depth channel, the ground-truth depth and the
 // mask -- not the colours.
+constexpr int kLossMaxGrid = (QED_LOSS_SUMS_FLOATS - 8) / 4;
+__device__ __forceinline__ float* loss_part(float* sums, int row) { return sums + 8 + row * kLossMaxGrid; }
+
 template <int CH>
 __global__ void __launch_bounds__(256)
 loss_reduce_kernel(int n_pix, const float* __restrict__ render, const float* __restrict__ alpha,
@@ -88,25 +94,37 @@ loss_reduce_kernel(int n_pix, const float* __restrict__ render, const float* __r
     if (lane == 0) { s[0][wid] = nv; s[1][wid] = dmax; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(&sums[2], s[0][0] + s[0][1] + s[0][2] + s[0][3]);
-        const float m = fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3]));
-        atomicMax(reinterpret_cast<int*>(&sums[3]), float_to_ordered(m));
+        loss_part(sums, 0)[blockIdx.x] = s[0][0] + s[0][1] + s[0][2] + s[0][3];
+        loss_part(sums, 1)[blockIdx.x] = fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3]));
     }
 }
 
-// Pass 2: gradients, the two loss sums, and -- by the last workgroup to finish -- the scalar losses.
+// Pass 2: gradients and the per-workgroup partials of the two loss sums.
 template <int CH>
 __global__ void __launch_bounds__(256)
 loss_grad_kernel(int n_pix, const float* __restrict__ render, const float* __restrict__ alpha,
                  const float* __restrict__ bg, const float* __restrict__ gt_rgb, const float* __restrict__ gt_depth,
                  const float* __restrict__ mask, float* __restrict__ sums, float rgb_weight, float depth_lambda,
-                 float* __restrict__ v_render, float* __restrict__ v_alpha, float* __restrict__ losses,
-                 const float* __restrict__ v_rgb_extra, const float* __restrict__ extra_sum, float extra_scale,
-                 float extra_offset) {
+                 float* __restrict__ v_render, float* __restrict__ v_alpha, const float* __restrict__ v_rgb_extra) {
     const float w_rgb = rgb_weight / (3.f * (float)n_pix);
-    const float nvalid = sums[2];
+    __shared__ float s[2][4];
+    // every workgroup folds pass 1's per-workgroup partials (same grid) into n_valid and the max depth
+    float nvalid = 0.f, dmax = 0.f;
+    if constexpr (CH == 4) {
+        float nv = 0.f, dm = -3.0e38f;
+        for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) {
+            nv += loss_part(sums, 0)[b];
+            dm = fmaxf(dm, loss_part(sums, 1)[b]);
+        }
+        nv = wave_sum(nv);
+        dm = wave_max(dm);
+        if ((threadIdx.x & 63) == 0) { s[0][threadIdx.x >> 6] = nv; s[1][threadIdx.x >> 6] = dm; }
+        __syncthreads();
+        nvalid = s[0][0] + s[0][1] + s[0][2] + s[0][3];
+        dmax = fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3]));
+        __syncthreads();
+    }
     const float w_d = nvalid > 0.f ? depth_lambda / nvalid : 0.f;
-    const float dmax = CH == 4 ? ordered_to_float(*reinterpret_cast<const int*>(&sums[3])) : 0.f;
     float dsum = 0.f, l1 = 0.f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n_pix; i += (size_t)gridDim.x * 256) {
         const PixelEval p = eval_pixel<CH>(render, alpha, bg, i);
@@ -143,24 +161,44 @@ loss_grad_kernel(int n_pix, const float* __restrict__ render, const float* __res
     }
     dsum = wave_sum(dsum);
     l1 = wave_sum(l1);
-    __shared__ float s[2][4];
-    __shared__ bool s_last;
     if ((threadIdx.x & 63) == 0) { s[0][threadIdx.x >> 6] = dsum; s[1][threadIdx.x >> 6] = l1; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(&sums[1], s[0][0] + s[0][1] + s[0][2] + s[0][3]);
-        atomicAdd(&sums[0], s[1][0] + s[1][1] + s[1][2] + s[1][3]);
-        // the workgroup that draws the last ticket sees every other workgroup's adds (device-scope atomics)
-        __threadfence();
-        const float ticket = atomicAdd(&sums[4], 1.f);
-        s_last = ticket == (float)(gridDim.x - 1);
-        if (s_last) {
-            const float tot_l1 = atomicAdd(&sums[0], 0.f), tot_d = atomicAdd(&sums[1], 0.f);
-            losses[0] = rgb_weight * tot_l1 / (3.f * (float)n_pix);
-            if (extra_sum != nullptr) losses[0] += extra_offset + extra_scale * extra_sum[0];
-            losses[1] = nvalid > 0.f ? depth_lambda * tot_d / nvalid : 0.f;   // empty -> 0.0 (model.py:111-114)
-            losses[2] = losses[0] + losses[1];
-        }
+        loss_part(sums, 2)[blockIdx.x] = s[1][0] + s[1][1] + s[1][2] + s[1][3];
+        loss_part(sums, 3)[blockIdx.x] = s[0][0] + s[0][1] + s[0][2] + s[0][3];
+    }
+}
+
+// One workgroup folds the per-workgroup partials of both passes into sums[0..3] and the three scalar
+// losses.  A separate (tiny) launch rather than a "last workgroup" ticket inside pass 2: the ticket
+// needs a device-scope fence behind each workgroup's stores plus a returning same-address atomic, which
+// measured ~20 ns per workgroup, serialised.
+__global__ void __launch_bounds__(256)
+loss_finalize_kernel(int n_pix, int n_blocks, int has_depth, float* __restrict__ sums, float rgb_weight,
+                     float depth_lambda, float* __restrict__ losses, const float* __restrict__ extra_sum,
+                     float extra_scale, float extra_offset) {
+    float nv = 0.f, dm = -3.0e38f, tl = 0.f, td = 0.f;
+    for (int b = threadIdx.x; b < n_blocks; b += 256) {
+        if (has_depth) { nv += loss_part(sums, 0)[b]; dm = fmaxf(dm, loss_part(sums, 1)[b]); }
+        tl += loss_part(sums, 2)[b];
+        td += loss_part(sums, 3)[b];
+    }
+    nv = wave_sum(nv); dm = wave_max(dm); tl = wave_sum(tl); td = wave_sum(td);
+    __shared__ float s[4][4];
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        s[0][w] = nv; s[1][w] = dm; s[2][w] = tl; s[3][w] = td;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float nvalid = s[0][0] + s[0][1] + s[0][2] + s[0][3];
+        const float dmax = fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3]));
+        const float tot_l1 = s[2][0] + s[2][1] + s[2][2] + s[2][3], tot_d = s[3][0] + s[3][1] + s[3][2] + s[3][3];
+        sums[0] = tot_l1; sums[1] = tot_d; sums[2] = nvalid; sums[3] = has_depth ? dmax : 0.f;
+        losses[0] = rgb_weight * tot_l1 / (3.f * (float)n_pix);
+        if (extra_sum != nullptr) losses[0] += extra_offset + extra_scale * extra_sum[0];
+        losses[1] = nvalid > 0.f ? depth_lambda * tot_d / nvalid : 0.f;       // empty -> 0.0 (model.py:111-114)
+        losses[2] = losses[0] + losses[1];
     }
 }
 
@@ -254,7 +292,13 @@ static unsigned stream_grid(long long n_items, long long cap = 2048) {
     return (unsigned)g;
 }
 // the loss kernels end with same-address atomics (one per workgroup): keep the grid at 2 per CU
-static unsigned reduce_grid(long long n_items) { return stream_grid(n_items, 512); }
+// both loss passes use the same grid: pass 2 reads pass 1's per-workgroup partials by index
+static unsigned reduce_grid(long long n_items) {
+    static long long cap = -1;
+    if (cap < 0) { const char* e = getenv("QED_LOSS_GRID"); cap = e ? atoll(e) : kLossMaxGrid; }
+    if (cap > kLossMaxGrid) cap = kLossMaxGrid;
+    return stream_grid(n_items, cap);
+}
 
 extern "C" int qed_loss_reduce(int32_t n_pix, int32_t channels, const float* render, const float* alpha,
                                const float* background, const float* gt_rgb, const float* gt_depth,
@@ -263,10 +307,6 @@ extern "C" int qed_loss_reduce(int32_t n_pix, int32_t channels, const float* ren
     QED_REQUIRE(render && alpha && background && gt_rgb && sums, "null buffers");
     QED_REQUIRE(channels == 3 || gt_depth, "gt_depth required with a depth channel");
     hipStream_t st = (hipStream_t)stream;
-    // sums = {0, 0, 0, ordered(-FLT_MAX)}: -FLT_MAX = 0xFF7FFFFF, ordered form = bits ^ 0x7FFFFFFF
-    hipError_t e = hipMemsetAsync(sums, 0, 8 * sizeof(float), st);
-    if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(sums + 3), (int)0x80800000, 1, st);
-    if (e != hipSuccess) { set_error("qed_loss_reduce: memset failed: %s", hipGetErrorString(e)); return QED_E_LAUNCH; }
     if (channels == 4)
         hipLaunchKernelGGL(loss_reduce_kernel<4>, dim3(reduce_grid(n_pix)), dim3(256), 0, st, n_pix, render, alpha,
                            background, gt_rgb, gt_depth, mask, sums);
@@ -285,15 +325,16 @@ extern "C" int qed_loss_grad(int32_t n_pix, int32_t channels, const float* rende
     QED_REQUIRE(render && alpha && background && gt_rgb && sums && v_render && v_alpha && losses, "null buffers");
     QED_REQUIRE(channels == 3 || gt_depth, "gt_depth required with a depth channel");
     hipStream_t st = (hipStream_t)stream;
-    float* sums_rw = const_cast<float*>(sums);     // slot [1] is accumulated by this pass
+    float* sums_rw = const_cast<float*>(sums);     // partial rows 2, 3 and the totals are written by this pass
+    const unsigned grid = reduce_grid(n_pix);
     if (channels == 4)
-        hipLaunchKernelGGL(loss_grad_kernel<4>, dim3(reduce_grid(n_pix)), dim3(256), 0, st, n_pix, render, alpha,
-                           background, gt_rgb, gt_depth, mask, sums_rw, rgb_weight, depth_lambda, v_render, v_alpha,
-                           losses, v_rgb_extra, extra_sum, extra_scale, extra_offset);
+        hipLaunchKernelGGL(loss_grad_kernel<4>, dim3(grid), dim3(256), 0, st, n_pix, render, alpha, background, gt_rgb,
+                           gt_depth, mask, sums_rw, rgb_weight, depth_lambda, v_render, v_alpha, v_rgb_extra);
     else
-        hipLaunchKernelGGL(loss_grad_kernel<3>, dim3(reduce_grid(n_pix)), dim3(256), 0, st, n_pix, render, alpha,
-                           background, gt_rgb, gt_depth, mask, sums_rw, rgb_weight, depth_lambda, v_render, v_alpha,
-                           losses, v_rgb_extra, extra_sum, extra_scale, extra_offset);
+        hipLaunchKernelGGL(loss_grad_kernel<3>, dim3(grid), dim3(256), 0, st, n_pix, render, alpha, background, gt_rgb,
+                           gt_depth, mask, sums_rw, rgb_weight, depth_lambda, v_render, v_alpha, v_rgb_extra);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, n_pix, (int)grid, channels == 4 ? 1 : 0, sums_rw,
+                       rgb_weight, depth_lambda, losses, extra_sum, extra_scale, extra_offset);
     return check_launch("qed_loss_grad");
 }
 

@@ -170,7 +170,7 @@ class _FusedImageLoss(torch.autograd.Function):
         assert C == 1, "one camera per training step (model.py:211)"
         dev = render.device
         n_pix = H * W
-        sums = torch.empty(8, dtype=torch.float32, device=dev)
+        sums = torch.empty(L.LOSS_SUMS_FLOATS, dtype=torch.float32, device=dev)
         losses = torch.empty(3, dtype=torch.float32, device=dev)       # rgb term, depth term, total
         v_render = torch.empty_like(render)
         v_alpha = torch.empty_like(alpha)
