@@ -35,6 +35,7 @@ extern "C" {
 
 #define QED_TILE 16             /* BLOCK_WIDTH = 16, model.py:243 */
 #define QED_SPLAT_FLOATS 12     /* packed per-(camera,Gaussian) record, see qed_project_fwd */
+#define QED_METRICS_WS_DOUBLES (10 * 1024)  /* workspace of qed_image_metrics */
 #define QED_LOSS_SUMS_FLOATS (8 + 4 * 1024) /* sums workspace of qed_loss_reduce / qed_loss_grad */
 #define QED_VSPLAT_FLOATS 16    /* packed per-(camera,Gaussian) gradient row, see qed_composite_bwd */
 
@@ -206,7 +207,8 @@ int qed_ssim_bwd(int32_t height, int32_t width, int32_t channels, const float* p
  * depth_rmse_log, depth_a1, depth_a2, depth_a3, n_valid_depth}; the depth entries are NaN when no
  * pixel is valid (metrics.py:134-143) or when pred_depth/gt_depth are NULL; the rgb entries are NaN
  * when pred_rgb/gt_rgb are NULL.  pred_rgb, gt_rgb: [n_pix,3]; depths: [n_pix]; valid depth =
- * finite(pred) & finite(gt) & gt > tolerance (0.1 in the reference).  workspace: 12 doubles.
+ * finite(pred) & finite(gt) & gt > tolerance (0.1 in the reference).  workspace: QED_METRICS_WS_DOUBLES
+ * doubles (per-workgroup partial sums; no zeroing needed).
  * rgb_ssim is qed_ssim_fwd's value; LPIPS (pretrained network) is not provided. */
 int qed_image_metrics(int32_t n_pix, const float* pred_rgb, const float* gt_rgb, const float* pred_depth,
                       const float* gt_depth, float tolerance, double* workspace, float* out, void* stream);

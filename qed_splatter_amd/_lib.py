@@ -56,6 +56,7 @@ SIGNATURES = {
 
 # flags (include/qed_splat.h)
 LOSS_SUMS_FLOATS = 8 + 4 * 1024          # QED_LOSS_SUMS_FLOATS
+METRICS_WS_DOUBLES = 10 * 1024           # QED_METRICS_WS_DOUBLES
 F_ANTIALIASED = 1
 F_LOG_SCALES = 2
 F_LOGIT_OPAC = 4

@@ -45,7 +45,7 @@ def image_metrics(pred_rgb: Optional[Tensor], gt_rgb: Optional[Tensor], pred_dep
         return t
 
     pr, gr, pd, gd = prep(pred_rgb, 3), prep(gt_rgb, 3), prep(pred_depth, 1), prep(gt_depth, 1)
-    work = torch.empty(12, dtype=torch.float64, device=ref.device)
+    work = torch.empty(L.METRICS_WS_DOUBLES, dtype=torch.float64, device=ref.device)
     out = torch.empty(10, dtype=torch.float32, device=ref.device)
     L.check(lib.qed_image_metrics(n_pix, L.ptr(pr), L.ptr(gr), L.ptr(pd), L.ptr(gd), float(tolerance), L.ptr(work),
                                   L.ptr(out), _stream()), "qed_image_metrics")
