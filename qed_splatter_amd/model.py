@@ -166,6 +166,7 @@ class _FusedImageLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, render, alpha, background, gt_rgb, gt_depth, mask, ssim_lambda, depth_lambda):
         lib = L.load()
+        ctx.set_materialize_grads(False)
         C, H, W, CH = render.shape
         assert C == 1, "one camera per training step (model.py:211)"
         dev = render.device
@@ -200,6 +201,8 @@ class _FusedImageLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, v_total, _v_parts):
+        if v_total is None:
+            return (None,) * 8
         v_render, v_alpha = ctx.saved_tensors
         # the kernel wrote d(total)/d(render, alpha); the usual upstream gradient 1.0 needs no scaling pass
         return v_render, v_alpha, None, None, None, None, None, None

@@ -97,6 +97,9 @@ class _ProjectSH(torch.autograd.Function):
     def forward(ctx, means, quats, scales, opacities, sh0, shN, viewmats, Ks, width, height, tile_w, tile_h,
                 sh_degree, flags, eps2d, near_plane, far_plane, radius_clip):
         lib = L.load()
+        # undefined output gradients arrive as None instead of freshly zero-filled tensors (autograd would
+        # otherwise fill one per output per step, the 24 MB splat record included)
+        ctx.set_materialize_grads(False)
         N, C = means.shape[0], viewmats.shape[0]
         dev = means.device
         means, quats, scales = _f32c(means, "means"), _f32c(quats, "quats"), _f32c(scales, "scales")
@@ -287,6 +290,7 @@ class _Composite(torch.autograd.Function):
     def forward(ctx, means2d, conics, rgb, opac, depths, splats, flatten_ids, offsets, backgrounds, width, height,
                 tile_w, tile_h, channels, absgrad):
         lib = L.load()
+        ctx.set_materialize_grads(False)
         C, N = opac.shape
         dev = opac.device
         render = torch.empty(C, height, width, channels, dtype=torch.float32, device=dev)
