@@ -384,7 +384,9 @@ static int adam_launch(float* params, const float* grads, float* exp_avg, float*
     if (total == 0) return QED_OK;
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(total / 4 + 1)), dim3(256), 0, (hipStream_t)stream, params, grads,
+    // 2 workgroups per CU: measured 136 us (6.1 TB/s) against 157 us with 8 per CU and 196 us with 1 --
+    // seven concurrent streams per wave favour fewer, longer-running waves (DRAM page locality)
+    hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(total / 4 + 1, 512)), dim3(256), 0, (hipStream_t)stream, params, grads,
                        exp_avg, exp_avg_sq, grp, beta1, beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)),
                        (const float*)dev_state, dev_lr);
     return check_launch("qed_adam_step");
