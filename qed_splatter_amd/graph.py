@@ -41,7 +41,9 @@ class GraphedTrainStep:
         # headroom: the captured buffers can never grow
         ws.capacity = int(ws.capacity * 1.25) + 4096
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: HIP calls made by other threads (e.g. the RCCL watchdog polling its events in a
+        # data-parallel job) must not invalidate this thread's capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.outputs = step_fn()
         self.ws = ws
 
