@@ -139,7 +139,7 @@ def main():
         for p in model.parameters():
             p.grad = None
         losses = model.fused_loss(cam, batch, background=bg, sync=sync)
-        losses["loss"].backward()
+        model.backward_fused(losses)
         if world > 1:
             allreduce_flat_grad(model, world)
         opt.step()
@@ -197,7 +197,7 @@ def main():
             for p in model.parameters():
                 p.grad = None
             losses = model.fused_loss(cam, batch, background=bg, sync=False)
-            losses["loss"].backward()
+            model.backward_fused(losses)
             return losses
 
         def adam_only():

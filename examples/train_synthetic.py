@@ -62,7 +62,7 @@ def main():
         for p in model.parameters():
             p.grad = None
         losses = model.fused_loss(cam, batch)
-        losses["loss"].backward()
+        model.backward_fused(losses)
         opt.step()
         dens.after_train(step)
         if step % dens.config.refine_every == 0:

@@ -502,6 +502,14 @@ class QEDSplatterModel(nn.Module):
             out["avg_min_scale"] = torch.nanmean(torch.exp(self.scales[..., -1]))      # model.py:192-194
         return out
 
+    def backward_fused(self, losses: Dict[str, Tensor]) -> None:
+        """``losses["loss"].backward()`` without the per-step ``ones_like`` fill autograd would launch for the
+        seed gradient (the fused loss kernel has already written d loss / d render for a seed of 1)."""
+        one = getattr(self, "_unit_grad", None)
+        if one is None or one.device != losses["loss"].device:
+            one = self._unit_grad = torch.ones((), dtype=torch.float32, device=losses["loss"].device)
+        losses["loss"].backward(gradient=one)
+
     # ---- fused training step: model.py:199-321 + 73-118 in as few passes as possible ----
     def fused_loss(self, camera, batch, background: Optional[Tensor] = None, sync: bool = True) -> Dict[str, Tensor]:
         """Forward + K8 fused loss.  Returns {"loss", "main_loss", "depth_loss"}: ``loss`` = main + depth is
