@@ -45,6 +45,9 @@ extern "C" {
 #define QED_F_LOGIT_OPAC 4u     /* `opacities` holds logits:  fuse torch.sigmoid    (model.py:271) */
 #define QED_F_DEPTH_CHANNEL 8u  /* render_mode "RGB+D": depth is colour channel 3   (model.py:256-259) */
 #define QED_F_SIGMOID_COLORS 16u /* sh_degree None path: fuse torch.sigmoid(colors) (model.py:264) */
+#define QED_F_TIGHT_TILES 32u   /* list only the tiles of the 3-sigma square that can reach alpha >= 1/255:
+                                   tiles_per_gauss / the sorted list become subsets of gsplat's, images and
+                                   gradients are unchanged (pass `splats` to qed_bin_tiles) */
 
 int qed_version(void);
 const char* qed_last_error(void);
@@ -132,12 +135,16 @@ int qed_sort_pairs(uint64_t* keys, int32_t* vals, uint64_t* keys_alt, int32_t* v
  * cam|tile and STABLY sorted on the tile bits only (2 passes at 1080p instead of 6 on 64-bit keys).
  * Outputs: flatten_ids[capacity] (first M valid), offsets[C*T+1] (offsets[C*T] = M), n_isect[1],
  * and, if isect_ids != NULL, the 64-bit keys (cam|tile) << 32 | depth_bits of the sorted list.
- * Overflow (M > capacity) sets status[0] = M and leaves M = 0.  workspace: qed_bin_workspace_bytes. */
+ * Overflow (M > capacity) sets status[0] = M and leaves M = 0.  workspace: qed_bin_workspace_bytes.
+ * splats (may be NULL): the records of qed_project_fwd; when given, each Gaussian's tile rectangle is
+ * taken from record slot 11 (the rectangle project_fwd counted) instead of being recomputed from
+ * means2d / radii -- REQUIRED when project_fwd ran with QED_F_TIGHT_TILES. */
 int64_t qed_bin_workspace_bytes(int64_t n_slots, int64_t capacity);
 int qed_bin_tiles(int32_t N, int32_t C, const float* means2d, const int32_t* radii, const float* depths,
-                  const int32_t* tiles_per_gauss, int32_t tile_w, int32_t tile_h, int64_t capacity,
-                  int32_t* flatten_ids, int32_t* offsets, int32_t* n_isect, uint64_t* isect_ids,
-                  void* workspace, int64_t workspace_bytes, int32_t* status, void* stream);
+                  const int32_t* tiles_per_gauss, const float* splats, int32_t tile_w, int32_t tile_h,
+                  int64_t capacity, int32_t* flatten_ids, int32_t* offsets, int32_t* n_isect,
+                  uint64_t* isect_ids, void* workspace, int64_t workspace_bytes, int32_t* status,
+                  void* stream);
 
 /* ---- K5: tile offsets --------------------------------------------------------------------------
  * offsets[C*T + 1]: offsets[t] = first sorted index whose (cam,tile) >= t; offsets[C*T] = M. */

@@ -35,7 +35,7 @@ SIGNATURES = {
     "qed_sort_pairs": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P, _L, _P, _P]),
     "qed_tile_offsets": (C.c_int, [_P, _P, _L, _I, _I, _I, _P, _P]),
     "qed_bin_workspace_bytes": (_L, [_L, _L]),
-    "qed_bin_tiles": (C.c_int, [_I, _I, _P, _P, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _L, _P, _P]),
+    "qed_bin_tiles": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _L, _P, _P]),
     "qed_composite_fwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "qed_composite_bwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "qed_loss_reduce": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -62,6 +62,7 @@ F_LOG_SCALES = 2
 F_LOGIT_OPAC = 4
 F_DEPTH_CHANNEL = 8
 F_SIGMOID_COLORS = 16
+F_TIGHT_TILES = 32
 SPLAT_FLOATS = 12
 VSPLAT_FLOATS = 16
 STATUS_WORDS = 4

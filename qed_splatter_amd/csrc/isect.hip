@@ -59,7 +59,7 @@ isect_emit_kernel(int N, int C, const float* __restrict__ means2d, const int* __
                   const float* __restrict__ depths, const int* __restrict__ tiles_per_gauss,
                   const int* __restrict__ block_offsets, int tile_w, int tile_h, int tile_bits,
                   const int* __restrict__ n_isect, const int* __restrict__ order, KeyT* __restrict__ keys,
-                  int* __restrict__ vals) {
+                  int* __restrict__ vals, const float* __restrict__ splats) {
     __shared__ int s_pref[4][65];   // per wave: exclusive prefix of counts (+ total)
     __shared__ int s_x0[4][64], s_y0[4][64], s_w[4][64];
     __shared__ unsigned s_depth[4][64];
@@ -76,7 +76,13 @@ isect_emit_kernel(int N, int C, const float* __restrict__ means2d, const int* __
     if (pos < total) {
         cnt = tiles_per_gauss[slot];
         if (cnt > 0) {
-            tile_rect(means2d[2 * slot], means2d[2 * slot + 1], (float)radii[slot], tile_w, tile_h, x0, y0, x1, y1);
+            if (splats != nullptr) {
+                // the rectangle project_fwd counted (QED_F_TIGHT_TILES or not), packed in record slot 11
+                const unsigned r = __float_as_uint(splats[(size_t)slot * QED_SPLAT_FLOATS + 11]);
+                x0 = (int)(r & 2047u); y0 = (int)((r >> 11) & 2047u); x1 = x0 + (int)(r >> 22);
+            } else {
+                tile_rect(means2d[2 * slot], means2d[2 * slot + 1], (float)radii[slot], tile_w, tile_h, x0, y0, x1, y1);
+            }
             dbits = __float_as_uint(depths[slot]);
         }
     }
@@ -220,10 +226,12 @@ extern "C" int64_t qed_bin_workspace_bytes(int64_t n_slots, int64_t capacity) {
 }
 
 extern "C" int qed_bin_tiles(int32_t N, int32_t C, const float* means2d, const int32_t* radii, const float* depths,
-                             const int32_t* tiles_per_gauss, int32_t tile_w, int32_t tile_h, int64_t capacity,
-                             int32_t* flatten_ids, int32_t* offsets, int32_t* n_isect, uint64_t* isect_ids,
-                             void* workspace, int64_t workspace_bytes, int32_t* status, void* stream) {
+                             const int32_t* tiles_per_gauss, const float* splats, int32_t tile_w, int32_t tile_h,
+                             int64_t capacity, int32_t* flatten_ids, int32_t* offsets, int32_t* n_isect,
+                             uint64_t* isect_ids, void* workspace, int64_t workspace_bytes, int32_t* status,
+                             void* stream) {
     QED_REQUIRE(N >= 0 && C >= 1 && tile_w > 0 && tile_h > 0, "bad extents");
+    QED_REQUIRE(splats == nullptr || (tile_w <= 1023 && tile_h <= 2047), "packed tile rectangles need tile_w <= 1023");
     QED_REQUIRE(capacity >= 0 && capacity < (1ll << 30), "capacity out of range");
     QED_REQUIRE(offsets && n_isect && status && workspace, "null buffers");
     const long long S = (long long)C * N;
@@ -273,7 +281,7 @@ extern "C" int qed_bin_tiles(int32_t N, int32_t C, const float* means2d, const i
     int* v_alt = (passes & 1) ? flatten_ids : vB;
     hipLaunchKernelGGL(isect_emit_kernel<unsigned>, dim3(gridS), dim3(256), 0, st, N, C, means2d, radii, depths,
                        tiles_per_gauss, (const int*)block_offsets, tile_w, tile_h, tile_bits, (const int*)n_isect, order,
-                       kB0, v_first);
+                       kB0, v_first, splats);
     which = sort_pairs_u32(kB0, v_first, kB1, v_alt, n_isect, capacity, end_bit, sort_ws, L.sort_ws_bytes, status, st);
     if (which < 0) return which;
     const unsigned* tile_keys = which ? kB1 : kB0;
@@ -308,7 +316,7 @@ extern "C" int qed_isect_emit(int32_t N, int32_t C, const float* means2d, const 
     const unsigned grid = (unsigned)((total + 255) / 256);
     hipLaunchKernelGGL(isect_emit_kernel<unsigned long long>, dim3(grid), dim3(256), 0, (hipStream_t)stream, N, C,
                        means2d, radii, depths, tiles_per_gauss, block_offsets, tile_w, tile_h, tile_bits, n_isect,
-                       (const int*)nullptr, (unsigned long long*)keys, vals);
+                       (const int*)nullptr, (unsigned long long*)keys, vals, (const float*)nullptr);
     return check_launch("qed_isect_emit");
 }
 

@@ -286,13 +286,16 @@ project_fwd_kernel(int N, int C, const float* __restrict__ means, const float* _
                     rgb[0] = sigmoidf_dev(rgb[0]); rgb[1] = sigmoidf_dev(rgb[1]); rgb[2] = sigmoidf_dev(rgb[2]);
                 }
             }
+            // tau = ln(255 o): alpha >= 1/255  <=>  sigma <= tau (used by the compositing kernels' quadrant culling)
+            const float tau = logf(255.f * op);
             int x0, y0, x1, y1;
-            tile_rect(mx, my, p.radius, tile_w, tile_h, x0, y0, x1, y1);
+            if (flags & QED_F_TIGHT_TILES) tight_tile_rect(mx, my, p.radius, ca, cb, cc, tau, tile_w, tile_h, x0, y0, x1, y1);
+            else tile_rect(mx, my, p.radius, tile_w, tile_h, x0, y0, x1, y1);
             ntiles = (x1 - x0) * (y1 - y0);
             r0 = make_float4(mx, my, ca, cb);
             r1 = make_float4(cc, op, rgb[0], rgb[1]);
-            // tau = ln(255 o): alpha >= 1/255  <=>  sigma <= tau (used by the compositing kernels' quadrant culling)
-            r2 = make_float4(rgb[2], (flags & QED_F_DEPTH_CHANNEL) ? z : 0.f, logf(255.f * op), 0.f);
+            r2 = make_float4(rgb[2], (flags & QED_F_DEPTH_CHANNEL) ? z : 0.f, tau,
+                             __uint_as_float(pack_tile_rect(x0, y0, x1)));
         }
         radii[slot] = rad;
         means2d[2 * slot] = mx; means2d[2 * slot + 1] = my;

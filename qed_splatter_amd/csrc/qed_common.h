@@ -53,6 +53,31 @@ __device__ __forceinline__ void tile_rect(float mx, float my, float radius, int 
     y1 = min(max(0, (int)ceilf(ty + tr)), tile_h);
 }
 
+// QED_F_TIGHT_TILES: the list only needs the tiles of gsplat's 3-sigma square in which SOME pixel can reach
+// alpha >= 1/255, i.e. sigma <= tau = ln(255 o).  The ellipse {sigma <= tau} of the conic (a, b, c) has
+// half extents sqrt(2 tau c / det) in x and sqrt(2 tau a / det) in y; tau and the extents are inflated well
+// beyond fp32 rounding of the per-pixel evaluation, and never exceed the 3-sigma radius.  Tiles dropped
+// this way are tiles every pixel would have skipped, so images and gradients do not change.
+__device__ __forceinline__ void tight_tile_rect(float mx, float my, float radius, float a, float b, float c, float tau,
+                                                int tile_w, int tile_h, int& x0, int& y0, int& x1, int& y1) {
+    const float t = tau * (1.f + 1e-4f) + 1e-2f;
+    if (!(t > 0.f)) { x0 = y0 = x1 = y1 = 0; return; }             // opacity <= 1/255: nothing can be drawn
+    const float det = fmaxf(a * c - b * b, 1e-30f);
+    const float rx = fminf(radius, sqrtf(2.f * t * c / det) * (1.f + 1e-5f) + 0.01f);
+    const float ry = fminf(radius, sqrtf(2.f * t * a / det) * (1.f + 1e-5f) + 0.01f);
+    const float ts = (float)QED_TILE;
+    x0 = min(max(0, (int)floorf((mx - rx) / ts)), tile_w);
+    y0 = min(max(0, (int)floorf((my - ry) / ts)), tile_h);
+    x1 = min(max(0, (int)ceilf((mx + rx) / ts)), tile_w);
+    y1 = min(max(0, (int)ceilf((my + ry) / ts)), tile_h);
+}
+
+// tile rectangle of a splat record (slot 11): x0 | y0 << 11 | width << 22  (tile grids up to 2047 x 2047,
+// rectangles up to 1023 tiles wide); the height follows from tiles_per_gauss
+__device__ __forceinline__ unsigned pack_tile_rect(int x0, int y0, int x1) {
+    return (unsigned)x0 | ((unsigned)y0 << 11) | ((unsigned)(x1 - x0) << 22);
+}
+
 // ---- wave64 cross-lane helpers (DPP; no LDS traffic) --------------------------------------
 // sum over the 16 lanes of each DPP row; result valid in every lane of the row
 __device__ __forceinline__ float row16_sum(float v) {

@@ -69,6 +69,9 @@ class QEDSplatterModelConfig:
     ssim_lambda: float = 0.2                 # parent's main loss: (1-l) L1 + l (1-SSIM); SSIM is 8f "next"
     num_downscales: int = 0
     resolution_schedule: int = 3000
+    # fused_loss() only (not a reference field): list each Gaussian only in the tiles of its 3-sigma square
+    # where some pixel can reach alpha >= 1/255 (QED_F_TIGHT_TILES); same images and gradients, shorter lists
+    tight_tile_lists: bool = True
 
 
 class PinholeCameras:
@@ -531,7 +534,9 @@ class QEDSplatterModel(nn.Module):
             K = camera.get_intrinsics_matrices().to(self.device, torch.float32)
         W, H = int(camera.width[0]), int(camera.height[0])
         self.last_size = (H, W)
-        flags = L.F_LOG_SCALES | L.F_LOGIT_OPAC
+        # tight tile lists: info["tiles_per_gauss"/"flatten_ids"/...] become subsets of gsplat's (nothing on the
+        # training path reads them); images, alphas and gradients are unchanged
+        flags = L.F_LOG_SCALES | L.F_LOGIT_OPAC | (L.F_TIGHT_TILES if cfg.tight_tile_lists else 0)
         if cfg.sh_degree > 0:
             deg = min(self.step // cfg.sh_degree_interval, cfg.sh_degree)
             colors, sh_rest = self.features_dc, self.features_rest

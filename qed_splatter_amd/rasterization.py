@@ -230,7 +230,7 @@ def _packed_vsplat(C, N, v_means2d, v_depths, v_conics, v_opac, v_rgb, dev) -> T
 # ==================================================================================================
 # tile binning + sort + compositing
 # ==================================================================================================
-def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, tile_w, tile_h, sync=True):
+def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, tile_w, tile_h, sync=True, splats=None):
     """Two-stage tile binning (qed_bin_tiles): depth sort of the slots, emit in depth order, stable
     sort on the tile bits, tile offsets -- one C call.
 
@@ -260,7 +260,7 @@ def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, til
         flatten_ids = torch.empty(cap, dtype=torch.int32, device=dev)
         isect_ids = torch.empty(cap, dtype=torch.int64, device=dev) if sync else None
         scratch = torch.empty(int(lib.qed_bin_workspace_bytes(C * N, cap)), dtype=torch.uint8, device=dev)
-        L.check(lib.qed_bin_tiles(N, C, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(tiles_per_gauss), tile_w,
+        L.check(lib.qed_bin_tiles(N, C, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(tiles_per_gauss), L.ptr(splats), tile_w,
                                   tile_h, cap, L.ptr(flatten_ids), L.ptr(offsets), L.ptr(n_isect), L.ptr(isect_ids),
                                   L.ptr(scratch), scratch.numel(), L.ptr(ws.status), _stream()), "qed_bin_tiles")
         if capturing:
@@ -397,8 +397,13 @@ def rasterization(
         means, quats, scales, opacities, sh0, shN, viewmats, Ks, int(width), int(height), tile_w, tile_h, deg, flags,
         float(eps2d), float(near_plane), float(far_plane), float(radius_clip))
 
+    # the packed tile rectangles of the records save the emit pass a recomputation; with F_TIGHT_TILES they
+    # are the only place the (smaller) rectangles exist
+    use_packed = tile_w <= 1023 and tile_h <= 2047
+    if (flags & L.F_TIGHT_TILES) and not use_packed:
+        raise NotImplementedError("F_TIGHT_TILES needs tile grids of at most 1023 x 2047 tiles")
     isect_ids, flatten_ids, offsets, M = _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums,
-                                                       tile_w, tile_h, sync=_sync)
+                                                       tile_w, tile_h, sync=_sync, splats=splats if use_packed else None)
     render, alpha, last_ids = _Composite.apply(means2d, conics, rgb, opac, depths if channels == 4 else None, splats,
                                                flatten_ids, offsets, backgrounds, int(width), int(height), tile_w,
                                                tile_h, channels, bool(absgrad))

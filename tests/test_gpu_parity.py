@@ -452,6 +452,45 @@ def test_get_metrics_dict_keys_and_values(cuda):
     assert float(md["rgb_ssim"]) == pytest.approx(float(O.ssim(out["rgb"].cpu().double(), sc["gt_rgb"].double())), rel=1e-4)
 
 
+def test_tight_tile_lists_change_nothing_but_the_lists(cuda):
+    """QED_F_TIGHT_TILES: the sorted list is an order-preserving subset of gsplat's, per tile; render, alpha
+    and last composited Gaussian are bit-identical, gradients equal up to atomic summation order."""
+    from qed_splatter_amd import _lib as L
+    from qed_splatter_amd.rasterization import rasterization
+    w, h, n = 320, 208, 20000
+    sc = scene(n, w, h, seed=5)
+    sc["scales"] = sc["scales"] + torch.tensor([0.9, 0.0, -0.6])        # elongated splats: where the gain is
+    sc["opacities"] = sc["opacities"] - 1.5                              # and faint ones
+    outs = []
+    for tight in (False, True):
+        ps = {k: sc[k].to(cuda).requires_grad_(True) for k in PARAM_NAMES}
+        vm = O.get_viewmat(sc["camera_to_worlds"][:1]).to(cuda)
+        flags = L.F_LOG_SCALES | L.F_LOGIT_OPAC | (L.F_TIGHT_TILES if tight else 0)
+        render, alpha, info = rasterization(
+            means=ps["means"], quats=ps["quats"], scales=ps["scales"], opacities=ps["opacities"].squeeze(-1),
+            colors=ps["features_dc"], viewmats=vm, Ks=sc["Ks"][:1].to(cuda), width=w, height=h, render_mode="RGB+D",
+            sh_degree=3, absgrad=True, _flags=flags, _sh_rest=ps["features_rest"])
+        g = torch.Generator().manual_seed(0)
+        wgt = torch.rand(render.shape, generator=g).to(cuda)
+        ((render * wgt).sum() + alpha.sum()).backward()
+        outs.append((render.detach(), alpha.detach(), info, {k: ps[k].grad for k in PARAM_NAMES}))
+    (r0, a0, i0, g0), (r1, a1, i1, g1) = outs
+    assert torch.equal(r0, r1) and torch.equal(a0, a1)
+    assert torch.equal(i0["radii"], i1["radii"])                         # the 3-sigma radius is still what is reported
+    m0, m1 = i0["flatten_ids"].numel(), i1["flatten_ids"].numel()
+    assert m1 < 0.8 * m0, (m0, m1)
+    assert bool((i1["tiles_per_gauss"] <= i0["tiles_per_gauss"]).all())
+    off0 = i0["isect_offsets"].flatten().tolist() + [m0]
+    off1 = i1["isect_offsets"].flatten().tolist() + [m1]
+    f0, f1 = i0["flatten_ids"].cpu(), i1["flatten_ids"].cpu()
+    for t in range(0, len(off0) - 1, 7):                                 # every 7th tile
+        full, sub = f0[off0[t]:off0[t + 1]].tolist(), f1[off1[t]:off1[t + 1]].tolist()
+        it = iter(full)
+        assert all(any(x == y for y in it) for x in sub), t              # order-preserving subsequence
+    for k in PARAM_NAMES:
+        assert_close(g1[k], g0[k], 1e-5, f"grad {k} (tight vs full lists)")
+
+
 def test_fused_path_equals_api_path(cuda):
     """fused_loss (K8 kernel, fused activations) == get_outputs + get_loss_dict."""
     w, h, n = 200, 136, 6000
