@@ -289,8 +289,15 @@ def main():
                 traffic = (2.0 * kk["fetch_size_kb"] + kk["write_size_kb"]) * 1024.0
         except (OSError, KeyError, ValueError):
             pass
+        valu_frac = None
+        try:
+            vp = json.load(open(os.path.join(ROOT, "profiles", "r01_valu_issue_pmc.json")))
+            if (n, w, h) == (500_000, 1920, 1080):
+                valu_frac = vp["kernels"]["qed::composite_bwd_kernel<4>"]["valu_issue_frac"]
+        except (OSError, KeyError, ValueError):
+            pass
         roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                "frac": achieved / 8000.0, "traffic": traffic,
+                "frac": achieved / 8000.0, "traffic": traffic, "valu_issue_frac_pmc": valu_frac,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": dom_ms,
                 "note": "algorithmic bytes = 92 B x M + 28 B x P (SURVEY 8d) with M = the reference's list length "
                         "(gsplat 3-sigma squares); this run lists only the tiles that can reach alpha >= 1/255 "
