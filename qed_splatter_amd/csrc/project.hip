@@ -361,8 +361,52 @@ __device__ __forceinline__ void sh_bwd(const float* __restrict__ sh0, const floa
     }
 }
 
+// Single-camera variant of sh_bwd: the coefficient gradients are final after one camera, so they go
+// straight to memory instead of through a 48-register accumulator that stays live across the whole kernel
+// (with it the degree-3 kernel needed 256 VGPRs + 82 AGPRs = one wave per SIMD).
 template <int DEG>
-__global__ void __launch_bounds__(256)
+__device__ __forceinline__ void sh_bwd_stream(const float* __restrict__ sh0, const float* __restrict__ shN,
+                                              const float* dir, const float* v_rgb_in, float* __restrict__ o0,
+                                              float* __restrict__ oN, float* v_dir /*3, +=*/) {
+    constexpr int K = (DEG + 1) * (DEG + 1);
+    const float n2 = dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2];
+    const float inorm = rsqrtf(n2);
+    const float x = dir[0] * inorm, y = dir[1] * inorm, z = dir[2] * inorm;
+    float b[K];
+    sh_basis<DEG>(x, y, z, b);
+    float c[3 * K];
+    load_sh<K>(sh0, shN, c);
+    float col[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        col[0] += b[k] * c[3 * k]; col[1] += b[k] * c[3 * k + 1]; col[2] += b[k] * c[3 * k + 2];
+    }
+    float v[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) v[ch] = (col[ch] + 0.5f >= 0.f) ? v_rgb_in[ch] : 0.f;
+    o0[0] = b[0] * v[0]; o0[1] = b[0] * v[1]; o0[2] = b[0] * v[2];
+#pragma unroll
+    for (int k = 1; k < K; ++k) {
+        oN[3 * (k - 1)] = b[k] * v[0]; oN[3 * (k - 1) + 1] = b[k] * v[1]; oN[3 * (k - 1) + 2] = b[k] * v[2];
+    }
+    if constexpr (DEG > 0) {
+        float bx[K], by[K], bz[K];
+        sh_basis_grad<DEG>(x, y, z, bx, by, bz);
+        float vx = 0.f, vy = 0.f, vz = 0.f;
+#pragma unroll
+        for (int k = 1; k < K; ++k) {
+            const float w = c[3 * k] * v[0] + c[3 * k + 1] * v[1] + c[3 * k + 2] * v[2];
+            vx += bx[k] * w; vy += by[k] * w; vz += bz[k] * w;
+        }
+        const float dot = vx * x + vy * y + vz * z;
+        v_dir[0] += (vx - dot * x) * inorm;
+        v_dir[1] += (vy - dot * y) * inorm;
+        v_dir[2] += (vz - dot * z) * inorm;
+    }
+}
+
+template <int DEG, bool ONE_CAM>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 project_bwd_kernel(int N, int C, const float* __restrict__ means, const float* __restrict__ quats,
                    const float* __restrict__ scales, const float* __restrict__ opacities,
                    const float* __restrict__ sh0, int sh0_stride, const float* __restrict__ shN, int shN_stride,
@@ -377,9 +421,12 @@ project_bwd_kernel(int N, int C, const float* __restrict__ means, const float* _
     const bool active = n < N;
 
     float vm[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f}, vo = 0.f;
-    float vcoef[3 * K];
+    // ONE_CAM with SH: coefficient gradients are streamed to memory by sh_bwd_stream (no accumulator)
+    constexpr bool kStreamSH = ONE_CAM && DEG >= 0;
+    float vcoef[kStreamSH ? 1 : 3 * K];
 #pragma unroll
-    for (int i = 0; i < 3 * K; ++i) vcoef[i] = 0.f;
+    for (int i = 0; i < (kStreamSH ? 1 : 3 * K); ++i) vcoef[i] = 0.f;
+    bool sh_written = false;
 
     float mean[3] = {0.f, 0.f, 0.f}, qraw[4] = {1.f, 0.f, 0.f, 0.f}, q[4], sraw[3] = {0.f, 0.f, 0.f}, s[3];
     float qin = 1.f, oraw = 0.f, oact = 0.f;
@@ -492,8 +539,15 @@ project_bwd_kernel(int N, int C, const float* __restrict__ means, const float* _
             float vdir[3] = {0.f, 0.f, 0.f};
             if constexpr (DEG >= 0) {
                 const float dir[3] = {mean[0] - cam.campos[0], mean[1] - cam.campos[1], mean[2] - cam.campos[2]};
-                sh_bwd<(DEG < 0 ? 0 : DEG)>(sh0 + (size_t)n * sh0_stride, shN + (size_t)n * shN_stride, dir, v_rgb,
-                                            vcoef, vdir);
+                if constexpr (kStreamSH) {
+                    sh_bwd_stream<(DEG < 0 ? 0 : DEG)>(sh0 + (size_t)n * sh0_stride, shN + (size_t)n * shN_stride, dir,
+                                                       v_rgb, v_sh0 + (size_t)n * v_sh0_stride,
+                                                       v_shN + (size_t)n * v_shN_stride, vdir);
+                    sh_written = true;
+                } else {
+                    sh_bwd<(DEG < 0 ? 0 : DEG)>(sh0 + (size_t)n * sh0_stride, shN + (size_t)n * shN_stride, dir, v_rgb,
+                                                vcoef, vdir);
+                }
             } else {
                 if (flags & QED_F_SIGMOID_COLORS) {
                     const float* cptr = sh0 + (size_t)n * sh0_stride;
@@ -577,11 +631,22 @@ project_bwd_kernel(int N, int C, const float* __restrict__ means, const float* _
     }
     v_opacities[n] = (flags & QED_F_LOGIT_OPAC) ? vo * oact * (1.f - oact) : vo;
     float* o0 = v_sh0 + (size_t)n * v_sh0_stride;
-    o0[0] = vcoef[0]; o0[1] = vcoef[1]; o0[2] = vcoef[2];
-    if constexpr (K > 1) {
-        float* oN = v_shN + (size_t)n * v_shN_stride;
+    if constexpr (kStreamSH) {
+        if (!sh_written) {                              // not visible: zero gradient
+            o0[0] = 0.f; o0[1] = 0.f; o0[2] = 0.f;
+            if constexpr (K > 1) {
+                float* oN = v_shN + (size_t)n * v_shN_stride;
 #pragma unroll
-        for (int i = 0; i < 3 * (K - 1); ++i) oN[i] = vcoef[3 + i];
+                for (int i = 0; i < 3 * (K - 1); ++i) oN[i] = 0.f;
+            }
+        }
+    } else {
+        o0[0] = vcoef[0]; o0[1] = vcoef[1]; o0[2] = vcoef[2];
+        if constexpr (K > 1) {
+            float* oN = v_shN + (size_t)n * v_shN_stride;
+#pragma unroll
+            for (int i = 0; i < 3 * (K - 1); ++i) oN[i] = vcoef[3 + i];
+        }
     }
 }
 
@@ -667,11 +732,16 @@ extern "C" int qed_project_bwd(int32_t N, int32_t C, const float* means, const f
     QED_REQUIRE(sh_degree <= 0 || (shN && v_shN), "shN / v_shN required for sh_degree > 0");
     const unsigned grid = (unsigned)((N + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
-#define QED_LAUNCH_BWD(D)                                                                                          \
-    hipLaunchKernelGGL(project_bwd_kernel<D>, dim3(grid), dim3(256), 0, st, N, C, means, quats, scales, opacities, \
-                       sh0, sh0_stride, shN, shN_stride, viewmats, Ks, width, height, eps2d, flags, radii,         \
-                       (const float4*)vsplat, v_means, v_quats, v_scales, v_opacities, v_sh0, v_sh0_stride, v_shN, \
-                       v_shN_stride, v_viewmats)
+#define QED_LAUNCH_BWD_(D, ONE)                                                                                    \
+    hipLaunchKernelGGL((project_bwd_kernel<D, ONE>), dim3(grid), dim3(256), 0, st, N, C, means, quats, scales,     \
+                       opacities, sh0, sh0_stride, shN, shN_stride, viewmats, Ks, width, height, eps2d, flags,     \
+                       radii, (const float4*)vsplat, v_means, v_quats, v_scales, v_opacities, v_sh0, v_sh0_stride, \
+                       v_shN, v_shN_stride, v_viewmats)
+#define QED_LAUNCH_BWD(D)                \
+    do {                                 \
+        if (C == 1) QED_LAUNCH_BWD_(D, true); \
+        else QED_LAUNCH_BWD_(D, false);  \
+    } while (0)
     switch (sh_degree) {
         case 0: QED_LAUNCH_BWD(0); break;
         case 1: QED_LAUNCH_BWD(1); break;
@@ -680,5 +750,6 @@ extern "C" int qed_project_bwd(int32_t N, int32_t C, const float* means, const f
         default: QED_LAUNCH_BWD(-1); break;
     }
 #undef QED_LAUNCH_BWD
+#undef QED_LAUNCH_BWD_
     return check_launch("qed_project_bwd");
 }
