@@ -104,13 +104,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    # rehearsal aid for a one-GPU box: QED_BENCH_REHEARSE=1 puts every rank on cuda:0 and uses gloo, which
+    # exercises the multi-rank control flow (split graphs, rank agreement, barriers) without RCCL
+    rehearse = os.environ.get("QED_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     # Work on an explicit (non-legacy) stream from the start: autograd pins each leaf's gradient
@@ -227,7 +235,9 @@ def main():
             if split:
                 g_fb = GraphedTrainStep(fwd_bwd, dev, warmup=3, check_every=0)
                 g_fb.replay()                          # fills the captured (static) .grad buffers before Adam's
-                g_adam = GraphedTrainStep(adam_only, dev, warmup=1, check_every=0)   # warm-up run reads them
+                if world > 1:                          # warm-up run reads them; keep the replicas identical
+                    allreduce_flat_grad(model, world)
+                g_adam = GraphedTrainStep(adam_only, dev, warmup=1, check_every=0)
                 graphed = g_fb
 
                 def run():
