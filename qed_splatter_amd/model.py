@@ -621,6 +621,35 @@ class FlatAdam:
         self._begin = (C.c_int64 * len(begins))(*begins)
         self.exp_avg, self.exp_avg_sq = exp_avg, exp_avg_sq
 
+    # ---- one step in pieces: lets a data-parallel job update a range of the flat buffer as soon as that
+    # range of the gradient has been all-reduced, while later ranges are still on the wire ----
+    @torch.no_grad()
+    def begin_step(self) -> None:
+        """Advance the (host-side) step counter and the scheduled rates; follow with step_range() calls that
+        together cover [0, numel)."""
+        if self.means_schedule is not None:
+            lr_final, max_steps = self.means_schedule
+            i = self.model.group_names.index("means")
+            self.lr[i] = exponential_decay_lr(self.t, self._means_lr_init, lr_final, max_steps)
+            self._lr[i] = self.lr[i]
+        self.t += 1
+
+    @torch.no_grad()
+    def step_range(self, lo: int, hi: int) -> None:
+        """Adam update of flat elements [lo, hi) (lo a multiple of 4) with the current step count."""
+        import ctypes as C
+        assert 0 <= lo <= hi <= self.model.flat_params.numel() and lo % 4 == 0
+        if hi == lo:
+            return
+        g = self.model.flat_grad()
+        begins = [min(max(b - lo, 0), hi - lo) for b in self.model.group_begin]
+        h_begin = (C.c_int64 * len(begins))(*begins)
+        p = self.model.flat_params
+        L.check(L.load().qed_adam_step(L.ptr(p[lo:hi]), L.ptr(g[lo:hi]), L.ptr(self.exp_avg[lo:hi]),
+                                       L.ptr(self.exp_avg_sq[lo:hi]), len(self.lr), C.cast(h_begin, C.c_void_p),
+                                       C.cast(self._lr, C.c_void_p), self.betas[0], self.betas[1], self.eps, self.t,
+                                       _stream()), "qed_adam_step")
+
     @torch.no_grad()
     def step(self, device_state: bool = False) -> None:
         """One Adam step.  ``device_state=True`` keeps the step counter / bias corrections in device

@@ -29,6 +29,38 @@ def allreduce_flat_grad(model, world_size: int, group=None) -> torch.Tensor:
     return g
 
 
+def allreduce_and_step(model, optimizer, world_size: int, n_chunks: int = 4, group=None) -> None:
+    """Gradient all-reduce and Adam step, pipelined: the flat gradient is reduced in ``n_chunks`` contiguous
+    pieces issued back to back on the process group's stream, and each piece's range of the flat parameter
+    buffer is updated (``FlatAdam.step_range``) as soon as its reduction has finished -- the HBM-bound
+    optimiser pass hides behind the link-bound collectives of the later pieces.  Same result as
+    ``allreduce_flat_grad`` + ``optimizer.step()``.
+
+    Whether it pays depends on how RCCL's bus bandwidth falls off with message size on the node at hand:
+    hiding the ~0.13 ms Adam pass of config B is worth it only if four 30 MB all-reduces cost less than
+    0.13 ms more than one 118 MB all-reduce.  bench.py keeps the single collective (not measurable on the
+    one-GPU development box); ``scripts/dp_rehearsal.py`` checks the equivalence on two ranks."""
+    g = model.flat_grad()
+    if g is None:
+        raise RuntimeError("no gradients to reduce: call backward() first")
+    total = g.numel()
+    if world_size <= 1:
+        optimizer.begin_step()
+        optimizer.step_range(0, total)
+        return
+    n_chunks = max(1, min(int(n_chunks), total // 4 or 1))
+    bounds = [min(total, (total * k // n_chunks) // 4 * 4) for k in range(n_chunks)] + [total]
+    avg = dist.get_backend(group) == "nccl"
+    works = [dist.all_reduce(g[a:b], op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=group, async_op=True)
+             for a, b in zip(bounds[:-1], bounds[1:])]
+    optimizer.begin_step()
+    for w, a, b in zip(works, bounds[:-1], bounds[1:]):
+        w.wait()                                   # the current stream waits for this piece only
+        if not avg:
+            g[a:b].mul_(1.0 / world_size)
+        optimizer.step_range(a, b)
+
+
 def allreduce_densification_stats(xys_absgrad_norm: torch.Tensor, vis_counts: torch.Tensor,
                                   max_radii: torch.Tensor, group=None) -> None:
     """Reduce what Nerfstudio's densifier accumulates from model.py:289-292 side effects:

@@ -603,6 +603,38 @@ def test_training_reduces_loss(cuda):
     assert all(math.isfinite(v) for v in hist) and hist[-1] < 0.5 * hist[0], (hist[0], hist[-1])
 
 
+def test_adam_step_in_ranges_equals_one_step(cuda):
+    """FlatAdam.begin_step + step_range pieces (what parallel.allreduce_and_step interleaves with the chunked
+    all-reduce) == FlatAdam.step, schedule included."""
+    from qed_splatter_amd.model import FlatAdam
+    from qed_splatter_amd.parallel import allreduce_and_step
+    sc = scene(1001, 64, 64, seed=8)                      # odd N: group boundaries not multiples of 4
+    ms, opts = [], []
+    for _ in range(3):
+        m, _, _ = _model(sc, cuda)
+        ms.append(m)
+        opts.append(FlatAdam(m, means_schedule=(1.6e-6, 50)))
+    g = torch.Generator().manual_seed(2)
+    for step in range(3):
+        grads = {k: torch.randn(ms[0].gauss_params[k].shape, generator=g).to(cuda) for k in PARAM_NAMES}
+        for m in ms:
+            flat = torch.cat([grads[k].reshape(-1) for k in m.group_names])
+            off = 0
+            for k in m.group_names:
+                p = m.gauss_params[k]
+                p.grad = flat[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+        opts[0].step()
+        total = ms[1].flat_params.numel()
+        opts[1].begin_step()
+        cuts = [0, 1000, 1004, total // 2 // 4 * 4, total]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            opts[1].step_range(a, b)
+        allreduce_and_step(ms[2], opts[2], 1, n_chunks=5)
+    assert torch.equal(ms[1].flat_params, ms[0].flat_params) and torch.equal(ms[2].flat_params, ms[0].flat_params)
+    assert torch.equal(opts[1].exp_avg_sq, opts[0].exp_avg_sq) and opts[1].t == opts[0].t == 3
+
+
 def test_means_lr_schedule_eager_and_device(cuda):
     """ExponentialDecayScheduler of "means" (config.py:46-51): host evaluation == device evaluation == formula."""
     from qed_splatter_amd.model import FlatAdam, exponential_decay_lr
