@@ -45,6 +45,9 @@ extern "C" {
 #define QED_F_LOGIT_OPAC 4u     /* `opacities` holds logits:  fuse torch.sigmoid    (model.py:271) */
 #define QED_F_DEPTH_CHANNEL 8u  /* render_mode "RGB+D": depth is colour channel 3   (model.py:256-259) */
 #define QED_F_SIGMOID_COLORS 16u /* sh_degree None path: fuse torch.sigmoid(colors) (model.py:264) */
+#define QED_F_SH_GRAD_COMPACT 64u /* qed_project_bwd (one camera): v_sh0 receives the clamp-masked colour gradient
+                                    (3 floats) instead of b_0 v, v_shN is not written; qed_sh_grad_from_views
+                                    rebuilds all coefficient gradients from the views' colour gradients */
 #define QED_F_TIGHT_TILES 32u   /* list only the tiles of the 3-sigma square that can reach alpha >= 1/255:
                                    tiles_per_gauss / the sorted list become subsets of gsplat's, images and
                                    gradients are unchanged (pass `splats` to qed_bin_tiles) */
@@ -104,6 +107,18 @@ int qed_project_bwd(int32_t N, int32_t C, const float* means, const float* quats
                     const float* vsplat, float* v_means, float* v_quats, float* v_scales,
                     float* v_opacities, float* v_sh0, int32_t v_sh0_stride, float* v_shN,
                     int32_t v_shN_stride, float* v_viewmats, void* stream);
+
+/* ---- data-parallel exchange of the SH gradients -----------------------------------------
+ * d L / d sh_k = sum over views of b_k(dir_view) * v_view (b_k the real SH basis, dir = mean - camera
+ * position, v_view the clamp-masked colour gradient written by qed_project_bwd with
+ * QED_F_SH_GRAD_COMPACT).  View c's colour gradients are v_views + c * view_stride ([N,3]; a view that
+ * does not see a Gaussian holds zeros) and its 4x4 view matrix viewmats + c * viewmat_stride (strides in
+ * floats, so that one all-gathered buffer can carry both); v_sh0 / v_shN receive scale * the sums
+ * (scale = 1/n_views averages). */
+int qed_sh_grad_from_views(int32_t N, int32_t n_views, const float* means, const float* viewmats,
+                           int64_t viewmat_stride, const float* v_views, int64_t view_stride,
+                           int32_t sh_degree, float scale, float* v_sh0, int32_t v_sh0_stride,
+                           float* v_shN, int32_t v_shN_stride, void* stream);
 
 /* ---- K3: tile intersection ------------------------------------------------------------------
  * qed_isect_scan: exclusive scan of block_sums -> block_offsets[n_blocks] and the total

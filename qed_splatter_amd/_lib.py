@@ -40,6 +40,7 @@ SIGNATURES = {
     "qed_composite_bwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "qed_loss_reduce": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qed_loss_grad": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _F, _F, _P]),
+    "qed_sh_grad_from_views": (C.c_int, [_I, _I, _P, _P, _L, _P, _L, _I, _F, _P, _I, _P, _I, _P]),
     "qed_lr_exp_decay_dev": (C.c_int, [_P, _P, _F, _F, _I, _P]),
     "qed_densify_accumulate": (C.c_int, [_I, _P, _I, _P, _F, _P, _P, _P, _P]),
     "qed_densify_pos_ints": (C.c_int64, [_I]),
@@ -63,6 +64,7 @@ F_LOGIT_OPAC = 4
 F_DEPTH_CHANNEL = 8
 F_SIGMOID_COLORS = 16
 F_TIGHT_TILES = 32
+F_SH_GRAD_COMPACT = 64
 SPLAT_FLOATS = 12
 VSPLAT_FLOATS = 16
 STATUS_WORDS = 4

@@ -514,7 +514,8 @@ class QEDSplatterModel(nn.Module):
         losses["loss"].backward(gradient=one)
 
     # ---- fused training step: model.py:199-321 + 73-118 in as few passes as possible ----
-    def fused_loss(self, camera, batch, background: Optional[Tensor] = None, sync: bool = True) -> Dict[str, Tensor]:
+    def fused_loss(self, camera, batch, background: Optional[Tensor] = None, sync: bool = True,
+                   compact_sh_grad: bool = False) -> Dict[str, Tensor]:
         """Forward + K8 fused loss.  Returns {"loss", "main_loss", "depth_loss"}: ``loss`` = main + depth is
         the differentiable total (call ``.backward()`` on it as is: the kernel already wrote its gradient
         for an upstream gradient of 1); the two parts are detached views for logging.  Numerically the
@@ -537,6 +538,11 @@ class QEDSplatterModel(nn.Module):
         # tight tile lists: info["tiles_per_gauss"/"flatten_ids"/...] become subsets of gsplat's (nothing on the
         # training path reads them); images, alphas and gradients are unchanged
         flags = L.F_LOG_SCALES | L.F_LOGIT_OPAC | (L.F_TIGHT_TILES if cfg.tight_tile_lists else 0)
+        if compact_sh_grad and cfg.sh_degree > 0:
+            # data parallel: features_dc.grad then holds the clamp-masked colour gradient and features_rest.grad
+            # is not written; parallel.exchange_grads_compact() rebuilds both from all ranks' views
+            flags |= L.F_SH_GRAD_COMPACT
+        self.last_viewmat = None
         if cfg.sh_degree > 0:
             deg = min(self.step // cfg.sh_degree_interval, cfg.sh_degree)
             colors, sh_rest = self.features_dc, self.features_rest
@@ -550,6 +556,7 @@ class QEDSplatterModel(nn.Module):
             rasterize_mode=cfg.rasterize_mode, _flags=flags, _sh_rest=sh_rest, _sync=sync)
         self.xys = self.info["means2d"]
         self.radii = self.info["radii"][0]
+        self.last_viewmat, self.last_sh_degree = viewmat, deg
         bg = background if background is not None else self._get_background_color()
         gt_rgb = batch["image"]
         gt_depth = batch["depth_image"]

@@ -171,6 +171,8 @@ class _ProjectSH(torch.autograd.Function):
             v_shN_ptr, v_shN_stride = v_sh0.data_ptr() + 12, shN_stride
             shN_ptr = sh0.data_ptr() + 12
         else:
+            # (with F_SH_GRAD_COMPACT the kernel leaves v_shN untouched: qed_sh_grad_from_views fills the active
+            # coefficients later, the inactive ones still need their zeros)
             if shN is not None and k_active - 1 < shN.shape[1]:
                 v_shN.zero_()
             v_sh0_ptr, v_sh0_stride = v_sh0.data_ptr(), sh0_stride

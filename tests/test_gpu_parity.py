@@ -603,6 +603,34 @@ def test_training_reduces_loss(cuda):
     assert all(math.isfinite(v) for v in hist) and hist[-1] < 0.5 * hist[0], (hist[0], hist[-1])
 
 
+def test_compact_sh_gradient_exchange_equals_averaged_full_gradients(cuda):
+    """Data-parallel exchange: features_dc / features_rest gradients rebuilt from the per-view
+    colour gradients (3 floats per Gaussian and view) == the average of the per-view full gradients."""
+    from qed_splatter_amd.model import PinholeCameras
+    from qed_splatter_amd.parallel import exchange_grads_compact
+    w, h, n, n_views = 200, 136, 6000, 3
+    sc = scene(n, w, h, seed=12, n_cameras=n_views)
+    K = sc["Ks"][0]
+    full, views = [], []
+    for c in range(n_views):
+        for compact in (False, True):
+            m, _, batch = _model(sc, cuda)
+            cam = PinholeCameras(sc["camera_to_worlds"][c:c + 1].to(cuda), K[0, 0], K[1, 1], K[0, 2], K[1, 2], w, h)
+            m.backward_fused(m.fused_loss(cam, batch, compact_sh_grad=compact))
+            if compact:
+                views.append((m.gauss_params["features_dc"].grad.clone(), m.last_viewmat.clone()))
+                last = m
+            else:
+                full.append(m.flat_grad().clone())
+    want = torch.stack(full).mean(0)
+    got = exchange_grads_compact(last, 1, views=views)
+    b = last.group_begin
+    assert_close(got[b[4]:b[5]], want[b[4]:b[5]], 1e-5, "features_dc.grad rebuilt from the views")
+    assert_close(got[b[5]:], want[b[5]:], 1e-5, "features_rest.grad rebuilt from the views")
+    # the geometry part of a compact run is the ordinary per-view gradient (here: the last view's)
+    assert_close(got[:b[4]], full[-1][:b[4]], 1e-5, "geometry gradients unaffected by the compact flag")
+
+
 def test_adam_step_in_ranges_equals_one_step(cuda):
     """FlatAdam.begin_step + step_range pieces (what parallel.allreduce_and_step interleaves with the chunked
     all-reduce) == FlatAdam.step, schedule included."""
