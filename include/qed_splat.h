@@ -272,6 +272,20 @@ int qed_densify_emit(int32_t N, int32_t n_samples, const uint8_t* flags, const i
 int qed_densify_reset_opacity(int32_t N, float* opacities, float* exp_avg, float* exp_avg_sq,
                               float max_logit, void* stream);
 
+/* ---- depth back-projection for the initial point cloud --------------------------
+ * Geometry of qed-init-pc's backproject_frame (create_init_pointcloud.py:148-196): every stride-th pixel
+ * (u, v) with a finite depth 0 < d < depth_max becomes the world point c2w * ((u-cx) d/fx, (v-cy) d/fy, d)
+ * (Open3D create_from_depth_image with depth_scale 1).  h_c2w_opengl: HOST pointer to the OpenGL
+ * camera-to-world pose, row-major with row stride 4 (a 3x4 or 4x4 matrix); the OpenCV flip of
+ * _opengl_c2w_to_opencv_w2c (:61-70) is applied inside.  points[capacity,3] receives the points in
+ * row-major pixel order, n_points[1] their number; more than `capacity` sets status[0] to the number
+ * needed and n_points to 0.  workspace: qed_backproject_workspace_ints ints. */
+int64_t qed_backproject_workspace_ints(int32_t height, int32_t width, int32_t stride);
+int qed_backproject_depth(int32_t height, int32_t width, const float* depth, float fx, float fy, float cx,
+                          float cy, const float* h_c2w_opengl, float depth_max, int32_t stride,
+                          int64_t capacity, float* points, int32_t* n_points, int32_t* workspace,
+                          int32_t* status, void* stream);
+
 /* ---- fused multi-tensor Adam over one flat parameter buffer (config.py:44-68) --
  * n_groups contiguous segments; segment g covers elements [h_group_begin[g], h_group_begin[g+1])
  * and uses learning rate h_lr[g].  bias corrections use `step` (1-based). */

@@ -47,6 +47,8 @@ SIGNATURES = {
     "qed_densify_classify": (C.c_int, [_I, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P]),
     "qed_densify_emit": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qed_densify_reset_opacity": (C.c_int, [_I, _P, _P, _P, _F, _P]),
+    "qed_backproject_workspace_ints": (C.c_int64, [_I, _I, _I]),
+    "qed_backproject_depth": (C.c_int, [_I, _I, _P, _F, _F, _F, _F, _P, _F, _I, _L, _P, _P, _P, _P, _P]),
     "qed_image_metrics": (C.c_int, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
     "qed_ssim_maps_floats": (C.c_int64, [_I, _I]),
     "qed_ssim_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),

@@ -15,7 +15,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB_DIR = PKG / "lib"
 LIB_PATH = LIB_DIR / "libqed_splat.so"
-SOURCES = ["project.hip", "isect.hip", "radix_sort.hip", "composite.hip", "loss.hip", "ssim.hip", "metrics.hip", "densify.hip"]
+SOURCES = ["project.hip", "isect.hip", "radix_sort.hip", "composite.hip", "loss.hip", "ssim.hip", "metrics.hip", "densify.hip", "backproject.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
