@@ -34,13 +34,6 @@ typedef unsigned long long u64;
 constexpr int kBatch = 64;
 constexpr float kLog2e = 1.4426950408889634f;
 
-// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
-// contiguous range of tiles (whole image rows): neighbouring tiles share splat records in one L2.
-__device__ __forceinline__ int xcd_remap(int b, int n) {
-    const int q = n >> 3, r = n & 7, x = b & 7;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-}
-
 // per-lane select by a wave-uniform 64-bit mask held in an SGPR pair: bit set -> a, else b
 __device__ __forceinline__ float sel(u64 m, float a, float b) {
     float d;

@@ -78,6 +78,13 @@ __device__ __forceinline__ unsigned pack_tile_rect(int x0, int y0, int x1) {
     return (unsigned)x0 | ((unsigned)y0 << 11) | ((unsigned)(x1 - x0) << 22);
 }
 
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
+// contiguous range of tiles (whole image rows): neighbouring tiles share splat records in one L2.
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+    const int q = n >> 3, r = n & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
 // ---- wave64 cross-lane helpers (DPP; no LDS traffic) --------------------------------------
 // sum over the 16 lanes of each DPP row; result valid in every lane of the row
 __device__ __forceinline__ float row16_sum(float v) {

@@ -114,7 +114,12 @@ ssim_fwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
     __shared__ __attribute__((aligned(16))) float s_h[4][PH * SH];
     __shared__ float s_red[4];
     const int Ho = H - kHalo, Wo = W - kHalo;
-    const int ox = blockIdx.x * TW, oy = blockIdx.y * T::TH;            // origin in the SSIM map
+    // neighbouring blocks share 10-pixel halos: keep them on one XCD's L2 (workgroups are dealt round-robin
+    // over the 8 XCDs, so a linear grid is remapped to give each XCD a contiguous run of blocks)
+    const int nbx = (Wo + TW - 1) / TW;
+    const int blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int by = blk / nbx, bx = blk - by * nbx;
+    const int ox = bx * TW, oy = by * T::TH;                            // origin in the SSIM map
     const int tid = threadIdx.x;
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
     const size_t n_out = (size_t)Ho * Wo;
@@ -225,7 +230,10 @@ ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
     __shared__ __attribute__((aligned(16))) float s_m[3][PH * SP];
     __shared__ __attribute__((aligned(16))) float s_h[3][PH * SH];
     const int Ho = H - kHalo, Wo = W - kHalo;
-    const int ox = blockIdx.x * TW, oy = blockIdx.y * T::TH;            // origin in the image
+    const int nbx = (W + TW - 1) / TW;
+    const int blk = xcd_remap(blockIdx.x, gridDim.x);                   // halo sharing: see ssim_fwd_kernel
+    const int by = blk / nbx, bx = blk - by * nbx;
+    const int ox = bx * TW, oy = by * T::TH;                            // origin in the image
     const int tid = threadIdx.x;
     const size_t n_out = (size_t)Ho * Wo;
     float w[kWin];
@@ -329,7 +337,7 @@ extern "C" int qed_ssim_fwd(int32_t height, int32_t width, int32_t channels, con
     QED_REQUIRE(alpha == nullptr || (background && (channels == 3 || channels == 4)), "composite mode needs a background");
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(ssim_sum, 0, sizeof(float), st) != hipSuccess) { set_error("qed_ssim_fwd: memset failed"); return QED_E_LAUNCH; }
-    const dim3 grid((width - kHalo + Tile::TW - 1) / Tile::TW, (height - kHalo + Tile::TH - 1) / Tile::TH);
+    const dim3 grid(((width - kHalo + Tile::TW - 1) / Tile::TW) * ((height - kHalo + Tile::TH - 1) / Tile::TH));
     if (alpha != nullptr)
         hipLaunchKernelGGL((ssim_fwd_kernel<true, Tile>), grid, dim3(256), 0, st, height, width, channels, pred, alpha,
                            background, gt_rgb, maps, ssim_sum);
@@ -346,7 +354,7 @@ extern "C" int qed_ssim_bwd(int32_t height, int32_t width, int32_t channels, con
     QED_REQUIRE(pred && gt_rgb && maps && v_pred, "null buffers");
     QED_REQUIRE(alpha == nullptr || (background && (channels == 3 || channels == 4)), "composite mode needs a background");
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((width + Tile::TW - 1) / Tile::TW, (height + Tile::TH - 1) / Tile::TH);
+    const dim3 grid(((width + Tile::TW - 1) / Tile::TW) * ((height + Tile::TH - 1) / Tile::TH));
     if (alpha != nullptr)
         hipLaunchKernelGGL((ssim_bwd_kernel<true, Tile>), grid, dim3(256), 0, st, height, width, channels, pred, alpha,
                            background, gt_rgb, maps, scale, v_pred);
