@@ -343,6 +343,18 @@ def main():
                        "async_intersection_count": not args.sync_m,
                        "dispatch": dispatch},
             "msplats_per_s": n_vis * world / (dt2 / args.steps) / 1e6,
+            # Msplats rasterized / s = N_visible / t_fwd (t_fwd = projection + binning + compositing
+            # forward, HIP-event sums of the instrumented region), the list rate M / t_fwd, and the step rate
+            # with the optimiser launch left out
+            "forward_ms": round(sum(kern.get(k, (0, 0.0))[1] for k in
+                                    ("qed_camera_setup", "qed_project_fwd", "qed_bin_tiles", "qed_composite_fwd")), 4),
+            "msplats_per_s_forward": n_vis / max(sum(kern.get(k, (0, 0.0))[1] for k in
+                                                     ("qed_camera_setup", "qed_project_fwd", "qed_bin_tiles",
+                                                      "qed_composite_fwd")), 1e-9) / 1e3,
+            "mintersections_per_s_forward": M_ref / max(sum(kern.get(k, (0, 0.0))[1] for k in
+                                                            ("qed_camera_setup", "qed_project_fwd", "qed_bin_tiles",
+                                                             "qed_composite_fwd")), 1e-9) / 1e3,
+            "iters_per_s_without_optimizer": world * 1e3 / max(ms_step - kern.get("qed_adam_step", (0, 0.0))[1], 1e-9),
             "ms_per_step_instrumented": dt / args.steps * 1e3,
             "kernels_ms": {k: round(v[1], 4) for k, v in sorted(kern.items())},
             "roofline": roof,
