@@ -293,12 +293,7 @@ static unsigned stream_grid(long long n_items, long long cap = 2048) {
 }
 // the loss kernels end with same-address atomics (one per workgroup): keep the grid at 2 per CU
 // both loss passes use the same grid: pass 2 reads pass 1's per-workgroup partials by index
-static unsigned reduce_grid(long long n_items) {
-    static long long cap = -1;
-    if (cap < 0) { const char* e = getenv("QED_LOSS_GRID"); cap = e ? atoll(e) : kLossMaxGrid; }
-    if (cap > kLossMaxGrid) cap = kLossMaxGrid;
-    return stream_grid(n_items, cap);
-}
+static unsigned reduce_grid(long long n_items) { return stream_grid(n_items, kLossMaxGrid); }
 
 extern "C" int qed_loss_reduce(int32_t n_pix, int32_t channels, const float* render, const float* alpha,
                                const float* background, const float* gt_rgb, const float* gt_depth,
