@@ -28,13 +28,23 @@ class GraphedTrainStep:
         self.device = torch.device(device)
         self.step_fn = step_fn
         self.check_every = check_every
+        self.warmup = warmup
         self.n_replays = 0
+        self._capture()
+
+    def recapture(self) -> None:
+        """Capture again after anything the captured launches were specialised on has changed: the number
+        of Gaussians (densification swaps the flat parameter / moment buffers), the image size, the SH degree."""
+        self.graph = None
+        self._capture()
+
+    def _capture(self) -> None:
         ws = _workspace(self.device)
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
-            for _ in range(max(warmup, 1)):
-                step_fn()                       # also calibrates the intersection capacity (first call syncs)
+            for _ in range(max(self.warmup, 1)):
+                self.step_fn()                  # also calibrates the intersection capacity (first call syncs)
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         ws.poll_pending()
@@ -44,7 +54,7 @@ class GraphedTrainStep:
         # thread_local: HIP calls made by other threads (e.g. the RCCL watchdog polling its events in a
         # data-parallel job) must not invalidate this thread's capture
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.outputs = step_fn()
+            self.outputs = self.step_fn()
         self.ws = ws
 
     def replay(self) -> Dict[str, torch.Tensor]:

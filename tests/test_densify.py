@@ -199,3 +199,40 @@ def test_after_train_matches_oracle_and_training_continues(cuda):
     opt.step()
     assert torch.isfinite(out["loss"]) and model.gauss_params["means"].grad.shape == (model.num_points, 3)
     assert opt.exp_avg.numel() == model.flat_params.numel()
+
+
+@pytest.mark.gpu
+def test_graphed_step_recaptured_after_refinement(cuda):
+    """Densification changes N and swaps the flat buffers: the captured step is re-captured and keeps training."""
+    from qed_splatter_amd.densify import DensifyConfig, Densifier
+    from qed_splatter_amd.graph import GraphedTrainStep
+    from qed_splatter_amd.model import FlatAdam
+    from tests.test_gpu_parity import _model
+    from tests.util import scene
+    w, h, n = 160, 112, 3000
+    sc = scene(n, w, h, seed=22)
+    stream = torch.cuda.Stream(device=cuda)
+    with torch.cuda.stream(stream):
+        model, cam, batch = _model(sc, cuda)
+        opt = FlatAdam(model)
+        dz = Densifier(model, opt, DensifyConfig(warmup_length=0, refine_every=2, densify_grad_thresh=1e-6), num_train_data=0)
+
+        def step():
+            for prm in model.parameters():
+                prm.grad = None
+            losses = model.fused_loss(cam, batch, sync=False)
+            model.backward_fused(losses)
+            opt.step(device_state=True)
+            return losses
+
+        g = GraphedTrainStep(step, cuda, warmup=2, check_every=1)
+        for s_i in range(1, 4):
+            g.replay()
+            dz.after_train(s_i)
+        info = dz.refinement_after(3)
+        assert info["did_densify"] and model.num_points != n
+        g.recapture()
+        out = g.replay()
+        torch.cuda.synchronize()
+    assert torch.isfinite(out["loss"]) and model.gauss_params["means"].grad.shape == (model.num_points, 3)
+    assert opt.exp_avg.numel() == model.flat_params.numel()
