@@ -37,7 +37,12 @@ for case in (range(n_cases) if only is None else [only]):
     deg = int(torch.randint(0, 4, (1,), generator=g))
     mode = "antialiased" if case % 3 == 1 else "classic"
     use_mask = case % 4 == 2
-    sc = O.synthetic_scene(n, w, h, seed=1000 + case)
+    # QED_SWEEP_CAM=k: view the scene from the k-th camera of a 5-degree fan (k = 11 is 55 degrees off axis: many
+    # Gaussians beyond the frustum rim, where the projection Jacobian is clamped)
+    cam_k = int(os.environ.get("QED_SWEEP_CAM", "0"))
+    sc = O.synthetic_scene(n, w, h, seed=1000 + case, n_cameras=cam_k + 1)
+    sc["camera_to_worlds"] = sc["camera_to_worlds"][cam_k:cam_k + 1]
+    sc["Ks"] = sc["Ks"][:1]
     sc["scales"] = sc["scales"] + float(torch.rand(1, generator=g)) * 2.5            # up to ~12x larger splats
     sc["opacities"] = sc["opacities"] + (float(torch.rand(1, generator=g)) - 0.7) * 4
     cfg = QEDSplatterModelConfig(sh_degree=3, sh_degree_interval=1, rasterize_mode=mode,

@@ -663,6 +663,45 @@ def test_adam_step_in_ranges_equals_one_step(cuda):
     assert torch.equal(opts[1].exp_avg_sq, opts[0].exp_avg_sq) and opts[1].t == opts[0].t == 3
 
 
+def test_fused_training_loop_tracks_torch_training_loop(cuda):
+    """40 steps over 3 cameras: fused_loss + FlatAdam (the product's training step) against an independent loop
+    built from the reference's own call sequence (get_outputs + get_loss_dict, torch autograd for the losses)
+    and six torch.optim.Adam optimisers with the reference's rates and "means" schedule."""
+    from qed_splatter_amd.model import FlatAdam, PinholeCameras, exponential_decay_lr
+    w, h, n, n_cams = 160, 112, 3000, 3
+    sc = scene(n, w, h, seed=41, n_cameras=n_cams)
+    K = sc["Ks"][0]
+    m1, _, batch = _model(sc, cuda)
+    m2, _, _ = _model(sc, cuda)
+    cams = [PinholeCameras(sc["camera_to_worlds"][c:c + 1].to(cuda), K[0, 0], K[1, 1], K[0, 2], K[1, 2], w, h) for c in range(n_cams)]
+    o1 = FlatAdam(m1, means_schedule=FlatAdam.MEANS_SCHEDULE)
+    o2 = {k: torch.optim.Adam([m2.gauss_params[k]], lr=FlatAdam.DEFAULT_LRS[k], eps=1e-15) for k in PARAM_NAMES}
+    l1 = l2 = None
+    for step in range(40):
+        c = (step * 7) % n_cams
+        for p in m1.parameters():
+            p.grad = None
+        lf = m1.fused_loss(cams[c], batch)
+        m1.backward_fused(lf)
+        o1.step()
+        for o in o2.values():
+            o.zero_grad(set_to_none=True)
+        ld = m2.get_loss_dict(m2.get_outputs(cams[c]), batch)
+        (ld["main_loss"] + ld["depth_loss"]).backward()
+        o2["means"].param_groups[0]["lr"] = exponential_decay_lr(step, 1.6e-4, 1.6e-6, 30000)
+        for o in o2.values():
+            o.step()
+        l1, l2 = float(lf["loss"].detach()), float((ld["main_loss"] + ld["depth_loss"]).detach())
+    assert l1 == pytest.approx(l2, rel=2e-4)
+    for k in PARAM_NAMES:
+        # Adam turns last-bit gradient differences (atomic summation order) into +-lr steps where a gradient is
+        # ~0, so compare with an absolute slack of a few learning-rate steps
+        a, b = m1.gauss_params[k].detach(), m2.gauss_params[k].detach()
+        slack = 4 * FlatAdam.DEFAULT_LRS[k]
+        frac = float(((a - b).abs() <= slack + 1e-4 * b.abs()).float().mean())
+        assert frac > 0.999, (k, frac)
+
+
 def test_means_lr_schedule_eager_and_device(cuda):
     """ExponentialDecayScheduler of "means" (config.py:46-51): host evaluation == device evaluation == formula."""
     from qed_splatter_amd.model import FlatAdam, exponential_decay_lr
