@@ -43,7 +43,8 @@ for case in (range(n_cases) if only is None else [only]):
     sc = O.synthetic_scene(n, w, h, seed=1000 + case, n_cameras=cam_k + 1)
     sc["camera_to_worlds"] = sc["camera_to_worlds"][cam_k:cam_k + 1]
     sc["Ks"] = sc["Ks"][:1]
-    sc["scales"] = sc["scales"] + float(torch.rand(1, generator=g)) * 2.5            # up to ~12x larger splats
+    boost = float(os.environ.get("QED_SWEEP_SCALE_BOOST", "2.5"))
+    sc["scales"] = sc["scales"] + float(torch.rand(1, generator=g)) * boost          # up to e^boost x larger splats
     sc["opacities"] = sc["opacities"] + (float(torch.rand(1, generator=g)) - 0.7) * 4
     cfg = QEDSplatterModelConfig(sh_degree=3, sh_degree_interval=1, rasterize_mode=mode,
                                  tight_tile_lists=os.environ.get("QED_SWEEP_TIGHT", "1") == "1")
