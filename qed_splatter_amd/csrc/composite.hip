@@ -96,17 +96,21 @@ __device__ __forceinline__ bool quadrant_may_touch(const float4& r0, const float
     const float smin = rect_min_sigma(r0.z, r0.w, r1.x, x0, x1, y0, y1, scale);
     return !(smin > tau + 1e-3f + 8e-6f * scale);
 }
-// four per-quadrant survivor masks of the 64 staged Gaussians (one per lane)
+// per-quadrant survivor masks of the 64 staged Gaussians (one per lane).  NQ = 4: the whole tile;
+// NQ = 1: only quadrant q0 (a wave that owns one 8x8 quadrant of a tile, see composite_fwd_kernel)
+template <int NQ>
 __device__ __forceinline__ void quadrant_masks(bool present, const float4& r0, const float4& r1, float tau, float ox,
-                                               float oy, u64* mq) {
-    const bool tile_keep = present && tile_may_touch(r0, r1, tau, ox, oy);
-    bool k[4] = {false, false, false, false};
-    if (tile_keep) {
+                                               float oy, int q0, u64* mq) {
+    bool k[NQ];
+    if constexpr (NQ == 4) {
+        const bool tile_keep = present && tile_may_touch(r0, r1, tau, ox, oy);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) k[q] = quadrant_may_touch(r0, r1, tau, ox, oy, q);
+        for (int q = 0; q < 4; ++q) k[q] = tile_keep && quadrant_may_touch(r0, r1, tau, ox, oy, q);
+    } else {
+        k[0] = present && quadrant_may_touch(r0, r1, tau, ox, oy, q0);
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) mq[q] = __ballot(k[q]);
+    for (int q = 0; q < NQ; ++q) mq[q] = __ballot(k[q]);
 }
 
 // ================================================================================================
@@ -161,14 +165,15 @@ __device__ __forceinline__ void fwd_quadrant(f2 pq, f2 XY, f2 AC, float B, float
 // ================================================================================================
 // forward
 // ================================================================================================
-template <int CH>
-__global__ void __launch_bounds__(64)
-composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __restrict__ flatten_ids,
-                     const int* __restrict__ offsets, int width, int height, int tile_w, int tile_h,
-                     const float* __restrict__ backgrounds, float* __restrict__ render, float* __restrict__ alpha_out,
-                     int* __restrict__ last_ids) {
+// One wave composites either a whole 16x16 tile (NQ = 4: four pixels per lane, one per 8x8 quadrant) or a
+// single quadrant q0 of it (NQ = 1: one pixel per lane).
+template <int CH, int NQ>
+__device__ __forceinline__ void fwd_tile(int tile, int q0, int C, const float4* __restrict__ splats,
+                                         const int* __restrict__ flatten_ids, const int* __restrict__ offsets, int width,
+                                         int height, int tile_w, int tile_h, const float* __restrict__ backgrounds,
+                                         float* __restrict__ render, float* __restrict__ alpha_out,
+                                         int* __restrict__ last_ids) {
     const int n_tiles = tile_w * tile_h;
-    const int tile = xcd_remap(blockIdx.x, C * n_tiles);   // cam * T + ty * tile_w + tx
     const int cam = tile / n_tiles;
     const int t_in = tile - cam * n_tiles;
     const int ty = t_in / tile_w, tx = t_in - ty * tile_w;
@@ -182,13 +187,14 @@ composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
 #endif
 
-    f2 pq[4];                                           // pixel centres of this lane's four pixels
-    FwdPixel px[4];
-    u64 done[4];                                        // wave-uniform masks
-    bool inside[4];
+    f2 pq[NQ];                                          // pixel centres of this lane's NQ pixels
+    FwdPixel px[NQ];
+    u64 done[NQ];                                       // wave-uniform masks
+    bool inside[NQ];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int ix = tx * QED_TILE + ((q & 1) << 3) + lx, iy = ty * QED_TILE + ((q >> 1) << 3) + ly;
+    for (int q = 0; q < NQ; ++q) {
+        const int qq = NQ == 4 ? q : q0;
+        const int ix = tx * QED_TILE + ((qq & 1) << 3) + lx, iy = ty * QED_TILE + ((qq >> 1) << 3) + ly;
         pq[q] = (f2){(float)ix + 0.5f, (float)iy + 0.5f};
         inside[q] = ix < width && iy < height;
         done[q] = __ballot(!inside[q]);
@@ -205,14 +211,22 @@ composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
         const size_t g = (size_t)flatten_ids[start + lane];
         r0 = splats[3 * g]; r1 = splats[3 * g + 1]; r2 = splats[3 * g + 2];
     }
-    bool all_done = (done[0] & done[1] & done[2] & done[3]) == ~0ull;
+    auto and_done = [&]() { u64 m = ~0ull;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) m &= done[q];
+        return m; };
+    auto or_masks = [&](const u64* mq) { u64 m = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) m |= mq[q];
+        return m; };
+    bool all_done = and_done() == ~0ull;
     for (int b = 0; b < nb && !all_done; ++b) {
         // ---- stage this lane's Gaussian: cull per quadrant, pre-scale the conic by -log2(e) ----
-        u64 mq[4];
-        quadrant_masks(present, r0, r1, r2.z, ox, oy, mq);
+        u64 mq[NQ];
+        quadrant_masks<NQ>(present, r0, r1, r2.z, ox, oy, q0, mq);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) mq[q] = done[q] == ~0ull ? 0ull : uniform_u64(mq[q]);
-        u64 km = mq[0] | mq[1] | mq[2] | mq[3];
+        for (int q = 0; q < NQ; ++q) mq[q] = done[q] == ~0ull ? 0ull : uniform_u64(mq[q]);
+        u64 km = or_masks(mq);
         const float gx = r0.x, gy = r0.y;
         const float gA = -0.5f * kLog2e * r0.z, gB = -kLog2e * r0.w, gC = -0.5f * kLog2e * r1.x;
         const float gop = r1.y, gr = r1.z, gg = r1.w, gb = r2.x, gd = r2.y;
@@ -239,24 +253,25 @@ composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
             int idx_v;                                  // one VGPR copy per Gaussian, not per quadrant
             asm volatile("v_mov_b32 %0, %1" : "=v"(idx_v) : "s"(batch_start + t));
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 if (!(mq[q] & bit)) continue;           // wave-uniform: this quadrant cannot see Gaussian t
                 fwd_quadrant<CH>(pq[q], XY, AC, B, op, col01, col23, idx_v, done[q], px[q]);
                 if (done[q] == ~0ull) {                 // quadrant finished: drop it from the masks
                     mq[q] = 0;
-                    km &= mq[0] | mq[1] | mq[2] | mq[3];
+                    km &= or_masks(mq);
                 }
             }
-            if ((done[0] & done[1] & done[2] & done[3]) == ~0ull) {
+            if (and_done() == ~0ull) {
                 all_done = true;
                 break;
             }
         }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         if (inside[q]) {
-            const int ix = tx * QED_TILE + ((q & 1) << 3) + lx, iy = ty * QED_TILE + ((q >> 1) << 3) + ly;
+            const int qq = NQ == 4 ? q : q0;
+            const int ix = tx * QED_TILE + ((qq & 1) << 3) + lx, iy = ty * QED_TILE + ((qq >> 1) << 3) + ly;
             const size_t pix = ((size_t)cam * height + iy) * width + ix;
             float out[4] = {px[q].out01.x, px[q].out01.y, px[q].out23.x, px[q].out23.y};
             if (backgrounds != nullptr) {
@@ -274,7 +289,7 @@ composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
     }
 #ifdef QED_TILE_TIMING
     // diagnostic build only: duration, start, HW_ID, XCC_ID of this tile's wave in its first four alphas
-    if (lane == 0) {
+    if (lane == 0 && NQ == 4) {
         const size_t pix = ((size_t)cam * height + ty * QED_TILE) * width + tx * QED_TILE;
         alpha_out[pix] = (float)(__builtin_amdgcn_s_memtime() - t_start);
         alpha_out[pix + 1] = (float)(t_start & 0xFFFFFFFull);
@@ -282,6 +297,28 @@ composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
         alpha_out[pix + 3] = (float)(__builtin_amdgcn_s_getreg(63508) & 0xF);
     }
 #endif
+}
+
+// Launch shape: the first n_big positions of the (XCD-remapped) tile order are composited by one wave each;
+// every later tile by FOUR waves, one per quadrant.  Workgroups are dispatched in index order, so the
+// quarter-size work items arrive last and fill the end of the launch, where whole-tile waves would leave most
+// wave slots idle (measured: 2.7 of 5 resident waves per SIMD on average with whole tiles only).
+template <int CH>
+__global__ void __launch_bounds__(64)
+composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __restrict__ flatten_ids,
+                     const int* __restrict__ offsets, int width, int height, int tile_w, int tile_h,
+                     const float* __restrict__ backgrounds, float* __restrict__ render, float* __restrict__ alpha_out,
+                     int* __restrict__ last_ids, int n_big) {
+    const int n_total = C * tile_w * tile_h;
+    const int b = blockIdx.x;
+    if (b < n_big) {
+        fwd_tile<CH, 4>(xcd_remap(b, n_total), 0, C, splats, flatten_ids, offsets, width, height, tile_w, tile_h,
+                        backgrounds, render, alpha_out, last_ids);
+    } else {
+        const int r = b - n_big;
+        fwd_tile<CH, 1>(xcd_remap(n_big + (r >> 2), n_total), r & 3, C, splats, flatten_ids, offsets, width, height,
+                        tile_w, tile_h, backgrounds, render, alpha_out, last_ids);
+    }
 }
 
 // ================================================================================================
@@ -372,17 +409,14 @@ __device__ __forceinline__ void bwd_quadrant(f2 pq, f2 XY, f2 AC, float B, float
 //  0 v_x  1 v_y  2 |v_x|  3 |v_y|  4 v_conic_a  5 v_conic_b  6 v_conic_c  7 v_opacity  8 v_r  9 v_g  10 v_b  11 v_depth
 // Values 4, 6 and 7 are accumulated un-scaled (sum v_sigma dx^2, sum v_sigma dy^2, sum v_sigma) and
 // scaled by 0.5, 0.5 and -1/opacity once per (tile, Gaussian) at flush time.
-template <int CH>
-__global__ void __launch_bounds__(64)
-composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __restrict__ flatten_ids,
-                     const int* __restrict__ offsets, int width, int height, int tile_w, int tile_h,
-                     const float* __restrict__ backgrounds, const float* __restrict__ render_alpha,
-                     const int* __restrict__ last_ids, const float* __restrict__ v_render,
-                     const float* __restrict__ v_alpha, float* __restrict__ vsplat) {
-    __shared__ float s_acc[kBatch][12];
-
+template <int CH, int NQ>
+__device__ __forceinline__ void bwd_tile(int tile, int q0, float (*s_acc)[12], int C, const float4* __restrict__ splats,
+                                         const int* __restrict__ flatten_ids, const int* __restrict__ offsets, int width,
+                                         int height, int tile_w, int tile_h, const float* __restrict__ backgrounds,
+                                         const float* __restrict__ render_alpha, const int* __restrict__ last_ids,
+                                         const float* __restrict__ v_render, const float* __restrict__ v_alpha,
+                                         float* __restrict__ vsplat) {
     const int n_tiles = tile_w * tile_h;
-    const int tile = xcd_remap(blockIdx.x, C * n_tiles);
     const int cam = tile / n_tiles;
     const int t_in = tile - cam * n_tiles;
     const int ty = t_in / tile_w, tx = t_in - ty * tile_w;
@@ -393,13 +427,14 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
     const int start = offsets[tile], end = offsets[tile + 1];
     if (end <= start) return;
 
-    f2 pq[4];
-    BwdPixel px[4];
-    int quad_last[4];
+    f2 pq[NQ];
+    BwdPixel px[NQ];
+    int quad_last[NQ];
     int tile_last = -1;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int ix = tx * QED_TILE + ((q & 1) << 3) + lx, iy = ty * QED_TILE + ((q >> 1) << 3) + ly;
+    for (int q = 0; q < NQ; ++q) {
+        const int qq = NQ == 4 ? q : q0;
+        const int ix = tx * QED_TILE + ((qq & 1) << 3) + lx, iy = ty * QED_TILE + ((qq >> 1) << 3) + ly;
         pq[q] = (f2){(float)ix + 0.5f, (float)iy + 0.5f};
         const bool inside = ix < width && iy < height;
         float T_final = 1.f, vra = 0.f;
@@ -450,17 +485,19 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
     }
     for (int b = 0; b < nb; ++b) {
         const int batch_hi = eff_end - 1 - b * kBatch;            // sorted index gathered by lane 0
-        u64 mq[4];
-        quadrant_masks(rid >= 0, r0, r1, r2.z, ox, oy, mq);
+        u64 mq[NQ];
+        quadrant_masks<NQ>(rid >= 0, r0, r1, r2.z, ox, oy, q0, mq);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             mq[q] = uniform_u64(mq[q]);
             // lane t holds sorted index batch_hi - t: beyond every pixel of the quadrant -> cannot be valid
             const int t0 = batch_hi - quad_last[q];
             if (t0 >= kBatch) mq[q] = 0;
             else if (t0 > 0) mq[q] &= ~0ull << t0;
         }
-        u64 km = mq[0] | mq[1] | mq[2] | mq[3];
+        u64 km = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) km |= mq[q];
         const float gx = r0.x, gy = r0.y, gca = r0.z, gcb = r0.w, gcc = r1.x;
         const float gop = r1.y, gr = r1.z, gg = r1.w, gb = r2.x, gd = r2.y;
         const int gid = rid;
@@ -490,7 +527,7 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
             g.ax = g.ay = g.c2 = g.s0 = 0.f;
             u64 any_valid = 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 if (!(mq[q] & bit)) continue;           // wave-uniform: this quadrant cannot see Gaussian t
                 bwd_quadrant<CH>(pq[q], XY, AC, B, op, cab, cbc, col01, col23, idx, px[q], any_valid, g);
             }
@@ -534,9 +571,48 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
     }
 }
 
+// same launch shape as composite_fwd_kernel: whole-tile waves first, quadrant waves for the last tiles
+template <int CH>
+__global__ void __launch_bounds__(64)
+composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __restrict__ flatten_ids,
+                     const int* __restrict__ offsets, int width, int height, int tile_w, int tile_h,
+                     const float* __restrict__ backgrounds, const float* __restrict__ render_alpha,
+                     const int* __restrict__ last_ids, const float* __restrict__ v_render,
+                     const float* __restrict__ v_alpha, float* __restrict__ vsplat, int n_big) {
+    __shared__ float s_acc[kBatch][12];
+    const int n_total = C * tile_w * tile_h;
+    const int b = blockIdx.x;
+    if (b < n_big) {
+        bwd_tile<CH, 4>(xcd_remap(b, n_total), 0, s_acc, C, splats, flatten_ids, offsets, width, height, tile_w, tile_h,
+                        backgrounds, render_alpha, last_ids, v_render, v_alpha, vsplat);
+    } else {
+        const int r = b - n_big;
+        bwd_tile<CH, 1>(xcd_remap(n_big + (r >> 2), n_total), r & 3, s_acc, C, splats, flatten_ids, offsets, width, height,
+                        tile_w, tile_h, backgrounds, render_alpha, last_ids, v_render, v_alpha, vsplat);
+    }
+}
+
 }  // namespace qed
 
 using namespace qed;
+
+// Number of leading tiles (in dispatch order) composited by whole-tile waves; the rest get one wave per
+// quadrant.  The quadrant waves are there to fill the end of the launch: their number is a multiple of the
+// device's wave slots for the kernel (measured optimum at 1080p on MI355X: 1.9 x 5120 slots for the forward,
+// 1.2 x 4096 for the backward kernel), independent of the image size; an image with fewer tiles than that is
+// composited by quadrant waves only (it could not fill the device with whole-tile waves anyway).
+static long long big_tiles(long long n_tiles, double small_waves_per_slot, int waves_per_simd) {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                   ? prop.multiProcessorCount : 256;
+    }
+    const long long slots = (long long)n_cu * 4 * waves_per_simd;
+    const long long n_small = (long long)(small_waves_per_slot * (double)slots / 4.0);
+    return n_tiles > n_small ? n_tiles - n_small : 0;
+}
 
 extern "C" int qed_composite_fwd(int32_t C, int32_t N, const float* splats, const int32_t* flatten_ids,
                                  const int32_t* offsets, int32_t width, int32_t height, int32_t tile_w,
@@ -552,12 +628,16 @@ extern "C" int qed_composite_fwd(int32_t C, int32_t N, const float* splats, cons
     const long long grid = (long long)C * tile_w * tile_h;
     QED_REQUIRE(grid < (1ll << 31), "too many tiles");
     hipStream_t st = (hipStream_t)stream;
+    const long long n_big = big_tiles(grid, 1.9, 5);
+    const unsigned blocks = (unsigned)(n_big + 4 * (grid - n_big));
     if (channels == 4)
-        hipLaunchKernelGGL(composite_fwd_kernel<4>, dim3((unsigned)grid), dim3(64), 0, st, C, (const float4*)splats,
-                           flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render, alpha, last_ids);
+        hipLaunchKernelGGL(composite_fwd_kernel<4>, dim3(blocks), dim3(64), 0, st, C, (const float4*)splats,
+                           flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render, alpha, last_ids,
+                           (int)n_big);
     else
-        hipLaunchKernelGGL(composite_fwd_kernel<3>, dim3((unsigned)grid), dim3(64), 0, st, C, (const float4*)splats,
-                           flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render, alpha, last_ids);
+        hipLaunchKernelGGL(composite_fwd_kernel<3>, dim3(blocks), dim3(64), 0, st, C, (const float4*)splats,
+                           flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render, alpha, last_ids,
+                           (int)n_big);
     return check_launch("qed_composite_fwd");
 }
 
@@ -576,13 +656,15 @@ extern "C" int qed_composite_bwd(int32_t C, int32_t N, const float* splats, cons
     const long long grid = (long long)C * tile_w * tile_h;
     QED_REQUIRE(grid < (1ll << 31), "too many tiles");
     hipStream_t st = (hipStream_t)stream;
+    const long long n_big = big_tiles(grid, 1.2, 4);
+    const unsigned blocks = (unsigned)(n_big + 4 * (grid - n_big));
     if (channels == 4)
-        hipLaunchKernelGGL(composite_bwd_kernel<4>, dim3((unsigned)grid), dim3(64), 0, st, C, (const float4*)splats,
+        hipLaunchKernelGGL(composite_bwd_kernel<4>, dim3(blocks), dim3(64), 0, st, C, (const float4*)splats,
                            flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render_alpha, last_ids,
-                           v_render, v_alpha, vsplat);
+                           v_render, v_alpha, vsplat, (int)n_big);
     else
-        hipLaunchKernelGGL(composite_bwd_kernel<3>, dim3((unsigned)grid), dim3(64), 0, st, C, (const float4*)splats,
+        hipLaunchKernelGGL(composite_bwd_kernel<3>, dim3(blocks), dim3(64), 0, st, C, (const float4*)splats,
                            flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render_alpha, last_ids,
-                           v_render, v_alpha, vsplat);
+                           v_render, v_alpha, vsplat, (int)n_big);
     return check_launch("qed_composite_bwd");
 }
