@@ -325,7 +325,7 @@ def main():
                         "(config.intersections) and renders the same image.  The kernel is VALU-issue bound, not "
                         "HBM bound: ~45 VALU instructions per pixel-Gaussian pair against 44 B per 256 pairs; "
                         "measured traffic is BELOW the algorithmic bytes because culled / early-terminated list "
-                        "entries are never gathered.  See DESIGN.md section 7 for the VALU-side roofline."}
+                        "entries are never gathered.  See DESIGN.md section 4 ('Roofline honesty') for the VALU-side roofline."}
         out = {
             "metric": "train iters/sec @ 1080p, 500k Gaussians (fwd + loss + bwd + Adam; camera-steps/s over all GPUs)",
             "value": world * args.steps / dt2, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
