@@ -300,6 +300,26 @@ int qed_adam_step_dev(float* params, const float* grads, float* exp_avg, float* 
                       int32_t n_groups, const int64_t* h_group_begin, const float* dev_lr, float beta1,
                       float beta2, float eps, float* dev_state, void* stream);
 
+/* Adam step that never materialises the SH-coefficient gradients.  Every group is [N, width]; the LAST
+ * two must be features_dc [N,3] and features_rest [N,KR,3].  Their gradient is the rank-1 product
+ *   g[n][k][c] = scale * sum_{view} b_k(direction of Gaussian n from that view's camera) * v_views[view][n][c]
+ * (what qed_sh_grad_from_views would write), evaluated on the fly from the 3 N clamp-masked colour
+ * gradients qed_project_bwd leaves with QED_F_SH_GRAD_COMPACT; `grads` is read for the other groups only
+ * (v_views may point into it).  `means` are the positions the views were rendered with (normally the
+ * means group of `params`: the SH launch, which reads them, precedes the launch that updates them).
+ * State: either device (dev_state + dev_lr as qed_adam_step_dev; h_lr and step ignored; with
+ * sched_group >= 0 the same tick launch first sets dev_lr[sched_group] to the exponential decay of
+ * qed_lr_exp_decay_dev for the step about to be taken) or host (h_lr + 1-based step; dev_* NULL,
+ * sched_group < 0).  Saves, for one camera per step at 500 k Gaussians, 96 MB written + 96 MB read; for
+ * data-parallel steps also the rebuild pass. */
+int qed_adam_step_sh(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                     int32_t n_groups, const int64_t* h_group_begin, const float* h_lr, float* dev_lr,
+                     float beta1, float beta2, float eps, int32_t step, float* dev_state,
+                     int32_t sched_group, float sched_lr_init, float sched_lr_final,
+                     int32_t sched_max_steps, int32_t N, int32_t sh_degree, const float* means,
+                     int32_t n_views, const float* viewmats, int64_t viewmat_stride,
+                     const float* v_views, int64_t view_stride, float scale, void* stream);
+
 /* ExponentialDecayScheduler of one group (the reference schedules "means": 1.6e-4 -> 1.6e-6 over
  * 30000 steps, config.py:46-51) from the device step counter, for graph replay: dev_lr_slot[0] =
  * exp((1-t) log lr_init + t log lr_final), t = clip(dev_state[0] / max_steps, 0, 1).  Call it before

@@ -8,6 +8,7 @@
 // into two streaming passes (a global max / count must be known before gradients can be written).
 // Pure HBM streaming: 20 B/pixel render+alpha, 16-20 B/pixel ground truth in, 20 B/pixel out.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "qed_common.h"
 
@@ -209,31 +210,37 @@ struct AdamGroups {
     int n;
 };
 
+struct AdamCoef {
+    float beta1, beta2, eps, inv_bc1, inv_bc2_sqrt;
+};
+
+__device__ __forceinline__ float adam_update(const AdamCoef& a, float pp, float gg, float& mm, float& vv, float lr) {
+    mm = a.beta1 * mm + (1.f - a.beta1) * gg;
+    vv = a.beta2 * vv + (1.f - a.beta2) * gg * gg;
+    const float denom = sqrtf(vv) * a.inv_bc2_sqrt + a.eps;
+    return pp - lr * a.inv_bc1 * mm / denom;
+}
+
 __global__ void __launch_bounds__(256)
 adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
             AdamGroups grp, float beta1, float beta2, float eps, float inv_bc1, float inv_bc2_sqrt,
             const float* __restrict__ dev_state, const float* __restrict__ dev_lr) {
     // device-resident step state / learning rates (hipGraph replays cannot change kernel arguments)
     if (dev_state != nullptr) { inv_bc1 = dev_state[1]; inv_bc2_sqrt = dev_state[2]; }
-    if (dev_lr != nullptr) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) grp.lr[k] = dev_lr[k];
-    }
+    float lrs[8];                                        // (not written back into grp: a modified by-value
+#pragma unroll                                           //  kernel argument is copied to scratch)
+    for (int k = 0; k < 8; ++k) lrs[k] = dev_lr != nullptr ? dev_lr[k] : grp.lr[k];
     const long long total = grp.begin[grp.n];
     const long long nvec = total >> 2;
     auto lr_of = [&](long long i) {
-        float lr = grp.lr[0];
+        float lr = lrs[0];
 #pragma unroll
         for (int k = 1; k < 8; ++k)
-            if (k < grp.n && i >= grp.begin[k]) lr = grp.lr[k];
+            if (k < grp.n && i >= grp.begin[k]) lr = lrs[k];
         return lr;
     };
-    auto upd = [&](float pp, float gg, float& mm, float& vv, float lr) {
-        mm = beta1 * mm + (1.f - beta1) * gg;
-        vv = beta2 * vv + (1.f - beta2) * gg * gg;
-        const float denom = sqrtf(vv) * inv_bc2_sqrt + eps;
-        return pp - lr * inv_bc1 * mm / denom;
-    };
+    const AdamCoef co{beta1, beta2, eps, inv_bc1, inv_bc2_sqrt};
+    auto upd = [&](float pp, float gg, float& mm, float& vv, float lr) { return adam_update(co, pp, gg, mm, vv, lr); };
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
         float4 pp = reinterpret_cast<float4*>(p)[i];
         const float4 gg = reinterpret_cast<const float4*>(g)[i];
@@ -257,9 +264,152 @@ adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restric
     }
 }
 
+// ---- Adam over the two SH groups with the coefficient gradients rebuilt on the fly ---------------------
+// The gradient of SH coefficient k, channel c of Gaussian n is a rank-1 product per view:
+//   g[n][k][c] = scale * sum_views b_k(dir_view(n)) * v_view[n][c]        (v = clamp-masked colour gradient)
+// so the 48 N coefficient gradients never need to exist in memory: project_bwd (QED_F_SH_GRAD_COMPACT)
+// leaves 3 N floats, and this kernel evaluates the products while it streams p / m / v of the features_dc
+// [N,3] and features_rest [N,KR,3] segments.  One workgroup pass = 256 Gaussians: one thread per Gaussian
+// writes its row of KR*3 gradients to LDS, then all 256 threads stream the (contiguous) rows as float4.
+// Element ranges need no alignment: a pass vectorises the 16-byte aligned interior of its rows and updates
+// the <= 3 + 3 elements at the ends one by one; neighbouring passes own disjoint elements.
+constexpr int kShChunk = 256;
+
+__device__ __forceinline__ void adam_one(const AdamCoef& a, float* __restrict__ p, float* __restrict__ m,
+                                         float* __restrict__ v, long long e, float g, float lr) {
+    float mm = m[e], vv = v[e];
+    p[e] = adam_update(a, p[e], g, mm, vv, lr);
+    m[e] = mm; v[e] = vv;
+}
+
+__device__ __forceinline__ void adam_vec(const AdamCoef& a, float* __restrict__ p, float* __restrict__ m,
+                                         float* __restrict__ v, long long e, const float4& gg, float lr) {
+    float4 pp = *reinterpret_cast<float4*>(p + e);
+    float4 mm = *reinterpret_cast<float4*>(m + e);
+    float4 vv = *reinterpret_cast<float4*>(v + e);
+    pp.x = adam_update(a, pp.x, gg.x, mm.x, vv.x, lr);
+    pp.y = adam_update(a, pp.y, gg.y, mm.y, vv.y, lr);
+    pp.z = adam_update(a, pp.z, gg.z, mm.z, vv.z, lr);
+    pp.w = adam_update(a, pp.w, gg.w, mm.w, vv.w, lr);
+    *reinterpret_cast<float4*>(p + e) = pp;
+    *reinterpret_cast<float4*>(m + e) = mm;
+    *reinterpret_cast<float4*>(v + e) = vv;
+}
+
+// Adam over elements [lo, hi) by one workgroup: float4 over the 16-byte aligned interior, the <= 3 + 3 elements
+// at the ends one by one.  g1(e) / g4(e) give the gradient of element e / of the aligned vector at e.
+template <class G1, class G4>
+__device__ __forceinline__ void adam_span(const AdamCoef& a, float* __restrict__ p, float* __restrict__ m,
+                                          float* __restrict__ v, long long lo, long long hi, float lr, int tid, G1 g1,
+                                          G4 g4) {
+    const long long e_lo = (lo + 3) & ~3LL, e_hi = hi & ~3LL;
+    for (long long e = e_lo + 4 * tid; e < e_hi; e += 4 * 256) adam_vec(a, p, m, v, e, g4(e), lr);
+    const long long head_end = e_lo < hi ? e_lo : hi;
+    if (lo + tid < head_end) adam_one(a, p, m, v, lo + tid, g1(lo + tid), lr);
+    const long long tail = e_hi > e_lo ? e_hi : e_lo;
+    if (tail + tid < hi) adam_one(a, p, m, v, tail + tid, g1(tail + tid), lr);
+}
+
+// Every group is [N, width[k]] rows; the last two are features_dc (width 3) and features_rest (width 3 KR).
+struct AdamRows {
+    long long begin[9];
+    float lr[8];
+    int width[8];
+    int n;
+};
+
+template <int DEG>
+__global__ void __launch_bounds__(256)
+adam_sh_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, long long b_dc, long long b_rest,
+               int RW, int N, const float* __restrict__ means, int n_views, const float* __restrict__ viewmats,
+               long long viewmat_stride, const float* __restrict__ v_views, long long view_stride, float scale,
+               AdamCoef a, const float* __restrict__ dev_state, const float* __restrict__ dev_lr, int dc_group,
+               float lr_dc, float lr_rest) {
+    extern __shared__ float s_g[];                       // kShChunk * RW + 4 floats
+    constexpr int K = (DEG + 1) * (DEG + 1);             // coefficient rows with a non-zero gradient
+    if (dev_state != nullptr) { a.inv_bc1 = dev_state[1]; a.inv_bc2_sqrt = dev_state[2]; }
+    if (dev_lr != nullptr) { lr_dc = dev_lr[dc_group]; lr_rest = dev_lr[dc_group + 1]; }
+    const int tid = threadIdx.x;
+    const int n_chunks = (N + kShChunk - 1) / kShChunk;
+    auto g_dc = [&](long long e) {       // features_dc: b_0 is a constant, elementwise in the views' colour gradients
+        const long long i = e - b_dc;
+        float acc = 0.f;
+        for (int c = 0; c < n_views; ++c) acc += SH_C0 * v_views[view_stride * c + i];
+        return acc * scale;
+    };
+    // ---- features_dc: one grid-wide streaming pass ----
+    {
+        const long long gt = (long long)blockIdx.x * 256 + tid, gs = (long long)gridDim.x * 256;
+        const float lr = lr_dc;
+        const long long e_lo = (b_dc + 3) & ~3LL, e_hi = b_rest & ~3LL;
+        for (long long e = e_lo + 4 * gt; e < e_hi; e += 4 * gs)
+            adam_vec(a, p, m, v, e, make_float4(g_dc(e), g_dc(e + 1), g_dc(e + 2), g_dc(e + 3)), lr);
+        if (blockIdx.x == 0) {
+            const long long head_end = e_lo < b_rest ? e_lo : b_rest;
+            if (b_dc + tid < head_end) adam_one(a, p, m, v, b_dc + tid, g_dc(b_dc + tid), lr);
+            const long long tail = e_hi > e_lo ? e_hi : e_lo;
+            if (tail + tid < b_rest) adam_one(a, p, m, v, tail + tid, g_dc(tail + tid), lr);
+        }
+    }
+    // ---- features_rest: passes of 256 Gaussians, gradients through LDS ----
+    for (int ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+        const int n0 = ch * kShChunk;
+        const int cnt = N - n0 < kShChunk ? N - n0 : kShChunk;
+        const long long lo = b_rest + (long long)n0 * RW, hi = lo + (long long)cnt * RW;
+        const int sh = (int)(lo & 3);                    // LDS index of element e is e - (lo - sh): 16-byte
+        if (tid < cnt && RW > 0) {                       // aligned exactly where the global address is
+            float* row = s_g + sh + tid * RW;
+            int filled = 0;
+            if constexpr (K > 1) {
+                const int n = n0 + tid;
+                const float mean[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
+                float acc[3 * (K - 1)];
+#pragma unroll
+                for (int i = 0; i < 3 * (K - 1); ++i) acc[i] = 0.f;
+                for (int c = 0; c < n_views; ++c) {
+                    const float* vm = viewmats + viewmat_stride * c;
+                    const float* vv = v_views + view_stride * c + (size_t)n * 3;
+                    const float cv[3] = {vv[0], vv[1], vv[2]};
+                    if (cv[0] == 0.f && cv[1] == 0.f && cv[2] == 0.f) continue;      // not visible in this view
+                    float dir[3];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)                                      // campos = -R^T t
+                        dir[j] = mean[j] + (vm[0 + j] * vm[3] + vm[4 + j] * vm[7] + vm[8 + j] * vm[11]);
+                    const float inorm = rsqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+                    float b[K];
+                    sh_basis<DEG>(dir[0] * inorm, dir[1] * inorm, dir[2] * inorm, b);
+#pragma unroll
+                    for (int k = 1; k < K; ++k) {
+                        acc[3 * (k - 1)] += b[k] * cv[0]; acc[3 * (k - 1) + 1] += b[k] * cv[1];
+                        acc[3 * (k - 1) + 2] += b[k] * cv[2];
+                    }
+                }
+                filled = 3 * (K - 1) < RW ? 3 * (K - 1) : RW;
+#pragma unroll
+                for (int i = 0; i < 3 * (K - 1); ++i)
+                    if (i < RW) row[i] = acc[i] * scale;
+            }
+            for (int i = filled; i < RW; ++i) row[i] = 0.f;                          // degrees not active yet
+        }
+        __syncthreads();
+        // features_rest rows of this pass, gradients from LDS
+        {
+            const long long base = lo - sh;
+            adam_span(a, p, m, v, lo, hi, lr_rest, tid, [&](long long e) { return s_g[e - base]; },
+                      [&](long long e) { return *reinterpret_cast<const float4*>(s_g + (e - base)); });
+        }
+        __syncthreads();
+    }
+}
+
 // state = {step (as float), 1 / (1 - beta1^step), 1 / sqrt(1 - beta2^step)}; advances the step by one
-__global__ void adam_tick_kernel(float* __restrict__ state, float beta1, float beta2) {
+__global__ void adam_tick_kernel(float* __restrict__ state, float beta1, float beta2, float* __restrict__ lr_slot,
+                                 float log_init, float log_final, float inv_max_steps) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (lr_slot != nullptr) {       // scheduled rate of the step about to be taken (lr_exp_decay_kernel's formula)
+            const float u = fminf(fmaxf(state[0] * inv_max_steps, 0.f), 1.f);
+            lr_slot[0] = expf(log_init * (1.f - u) + log_final * u);
+        }
         const float t = state[0] + 1.f;
         state[0] = t;
         state[1] = 1.f / (1.f - powf(beta1, t));
@@ -349,9 +499,85 @@ extern "C" int qed_adam_step_dev(float* params, const float* grads, float* exp_a
                                  int32_t n_groups, const int64_t* h_group_begin, const float* dev_lr, float beta1,
                                  float beta2, float eps, float* dev_state, void* stream) {
     QED_REQUIRE(dev_lr && dev_state, "device lr / state required");
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dev_state, beta1, beta2);
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dev_state, beta1, beta2,
+                       (float*)nullptr, 0.f, 0.f, 0.f);
     return adam_launch(params, grads, exp_avg, exp_avg_sq, n_groups, h_group_begin, nullptr, beta1, beta2, eps, 1,
                        dev_state, dev_lr, stream);
+}
+
+extern "C" int qed_adam_step_sh(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t n_groups,
+                                const int64_t* h_group_begin, const float* h_lr, float* dev_lr, float beta1,
+                                float beta2, float eps, int32_t step, float* dev_state, int32_t sched_group,
+                                float sched_lr_init, float sched_lr_final, int32_t sched_max_steps, int32_t N,
+                                int32_t sh_degree, const float* means, int32_t n_views, const float* viewmats,
+                                int64_t viewmat_stride, const float* v_views, int64_t view_stride, float scale,
+                                void* stream) {
+    QED_REQUIRE(n_groups >= 2 && n_groups <= 8 && h_group_begin, "2..8 groups, the last two features_dc, features_rest");
+    QED_REQUIRE((dev_state != nullptr) == (dev_lr != nullptr), "device state and device rates go together");
+    QED_REQUIRE(dev_state || (h_lr && step >= 1), "host rates and a 1-based step, or device state");
+    QED_REQUIRE(params && exp_avg && exp_avg_sq && N > 0 && means && n_views >= 1 && viewmats && v_views,
+                "bad arguments");
+    QED_REQUIRE(grads || n_groups == 2, "gradients of the leading groups required");
+    QED_REQUIRE((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
+                "buffers must be 16-byte aligned");
+    QED_REQUIRE(sched_group < n_groups && (sched_group < 0 || (dev_state && sched_lr_init > 0.f && sched_lr_final > 0.f &&
+                                                                sched_max_steps > 0)),
+                "a scheduled group needs device state, positive rates and max_steps (host state: schedule h_lr)");
+    AdamRows grp;
+    QED_REQUIRE(h_group_begin[0] == 0, "group 0 must start at element 0");
+    for (int i = 0; i < 9; ++i) grp.begin[i] = h_group_begin[i < n_groups ? i : n_groups];
+    for (int i = 0; i < 8; ++i) {
+        grp.lr[i] = (h_lr != nullptr && i < n_groups) ? h_lr[i] : 0.f;
+        const long long len = grp.begin[i + 1] - grp.begin[i];
+        QED_REQUIRE(len >= 0 && len % N == 0, "every group must be [N, width]");
+        grp.width[i] = (int)(len / N);
+    }
+    grp.n = n_groups;
+    QED_REQUIRE(grp.width[n_groups - 2] == 3, "features_dc must be [N,3]");
+    const int RW = grp.width[n_groups - 1];
+    QED_REQUIRE(RW % 3 == 0 && RW <= 45, "features_rest must be [N,KR,3] with KR <= 15");
+    QED_REQUIRE(sh_degree >= 0 && sh_degree <= 3 && 3 * ((sh_degree + 1) * (sh_degree + 1) - 1) <= RW,
+                "sh_degree 0..3 within the stored coefficient rows");
+    hipStream_t st = (hipStream_t)stream;
+    AdamCoef co{beta1, beta2, eps, 1.f, 1.f};
+    if (dev_state != nullptr) {
+        const bool sched = sched_group >= 0;
+        hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, st, dev_state, beta1, beta2,
+                           sched ? dev_lr + sched_group : (float*)nullptr, sched ? logf(sched_lr_init) : 0.f,
+                           sched ? logf(sched_lr_final) : 0.f, sched ? 1.f / (float)sched_max_steps : 0.f);
+    } else {
+        co.inv_bc1 = (float)(1.0 / (1.0 - pow((double)beta1, (double)step)));
+        co.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
+    }
+    // 3 workgroups per CU (46 KB of LDS each; measured at 500 k, both launches: 256 -> 150 us, 512 -> 125 us,
+    // 768 -> 121 us, 1024 -> 132 us).  Folding the leading groups into the same launch was slower in two
+    // forms (their rows per pass: 139 us; grid-wide per-group passes + means rows per pass: 154 us): short spans
+    // expose one memory latency each.
+    static const int grid_cap = [] {
+        const char* e = getenv("QED_ADAM_SH_GRID");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? v : 768;
+    }();
+    const int n_chunks = (N + kShChunk - 1) / kShChunk;
+    const unsigned grid = (unsigned)(n_chunks < grid_cap ? n_chunks : grid_cap);
+    const size_t lds = ((size_t)kShChunk * RW + 4) * sizeof(float);
+    // the SH pass reads `means`, which the pass over the leading groups updates: SH first
+#define QED_LAUNCH_ASH(D)                                                                                            \
+    hipLaunchKernelGGL(adam_sh_kernel<D>, dim3(grid), dim3(256), lds, st, params, exp_avg, exp_avg_sq,                \
+                       grp.begin[n_groups - 2], grp.begin[n_groups - 1], RW, N, means, n_views, viewmats,            \
+                       (long long)viewmat_stride, v_views, (long long)view_stride, scale, co,                        \
+                       (const float*)dev_state, (const float*)dev_lr, n_groups - 2, grp.lr[n_groups - 2],            \
+                       grp.lr[n_groups - 1])
+    switch (sh_degree) {
+        case 0: QED_LAUNCH_ASH(0); break;
+        case 1: QED_LAUNCH_ASH(1); break;
+        case 2: QED_LAUNCH_ASH(2); break;
+        default: QED_LAUNCH_ASH(3); break;
+    }
+#undef QED_LAUNCH_ASH
+    if (n_groups == 2) return check_launch("qed_adam_step_sh");
+    return adam_launch(params, grads, exp_avg, exp_avg_sq, n_groups - 2, h_group_begin, h_lr, beta1, beta2, eps,
+                       dev_state ? 1 : step, dev_state, dev_lr, stream);
 }
 
 extern "C" int qed_lr_exp_decay_dev(float* dev_lr_slot, const float* dev_state, float lr_init, float lr_final,

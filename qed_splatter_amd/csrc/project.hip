@@ -135,39 +135,11 @@ __device__ __forceinline__ void project_one(const Cam& cam, const float* mean, c
 }
 
 // ---- spherical harmonics (standard real SH basis, 3DGS constants) ------------------------------
-constexpr float SH_C0 = 0.28209479177387814f;
-constexpr float SH_C1 = 0.4886025119029199f;
 __device__ __constant__ float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
                                           -1.0925484305920792f, 0.5462742152960396f};
 __device__ __constant__ float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
                                           0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
                                           -0.5900435899266435f};
-
-// basis values b[0..K) for unit direction (x,y,z)
-template <int DEG>
-__device__ __forceinline__ void sh_basis(float x, float y, float z, float* b) {
-    b[0] = SH_C0;
-    if constexpr (DEG > 0) {
-        b[1] = -SH_C1 * y; b[2] = SH_C1 * z; b[3] = -SH_C1 * x;
-    }
-    if constexpr (DEG > 1) {
-        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-        b[4] = 1.0925484305920792f * xy;
-        b[5] = -1.0925484305920792f * yz;
-        b[6] = 0.31539156525252005f * (2.f * zz - xx - yy);
-        b[7] = -1.0925484305920792f * xz;
-        b[8] = 0.5462742152960396f * (xx - yy);
-        if constexpr (DEG > 2) {
-            b[9] = -0.5900435899266435f * y * (3.f * xx - yy);
-            b[10] = 2.890611442640554f * xy * z;
-            b[11] = -0.4570457994644658f * y * (4.f * zz - xx - yy);
-            b[12] = 0.3731763325901154f * z * (2.f * zz - 3.f * xx - 3.f * yy);
-            b[13] = -0.4570457994644658f * x * (4.f * zz - xx - yy);
-            b[14] = 1.445305721320277f * z * (xx - yy);
-            b[15] = -0.5900435899266435f * x * (xx - 3.f * yy);
-        }
-    }
-}
 
 // d(basis)/dx, /dy, /dz
 template <int DEG>

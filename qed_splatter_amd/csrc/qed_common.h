@@ -87,6 +87,37 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 
 // ---- wave64 cross-lane helpers (DPP; no LDS traffic) --------------------------------------
 // sum over the 16 lanes of each DPP row; result valid in every lane of the row
+// ---- spherical harmonics (standard real SH basis, 3DGS constants) ------------------------------
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+
+// basis values b[0..K) for unit direction (x,y,z)
+template <int DEG>
+__device__ __forceinline__ void sh_basis(float x, float y, float z, float* b) {
+    b[0] = SH_C0;
+    if constexpr (DEG > 0) {
+        b[1] = -SH_C1 * y; b[2] = SH_C1 * z; b[3] = -SH_C1 * x;
+    }
+    if constexpr (DEG > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        b[4] = 1.0925484305920792f * xy;
+        b[5] = -1.0925484305920792f * yz;
+        b[6] = 0.31539156525252005f * (2.f * zz - xx - yy);
+        b[7] = -1.0925484305920792f * xz;
+        b[8] = 0.5462742152960396f * (xx - yy);
+        if constexpr (DEG > 2) {
+            b[9] = -0.5900435899266435f * y * (3.f * xx - yy);
+            b[10] = 2.890611442640554f * xy * z;
+            b[11] = -0.4570457994644658f * y * (4.f * zz - xx - yy);
+            b[12] = 0.3731763325901154f * z * (2.f * zz - 3.f * xx - 3.f * yy);
+            b[13] = -0.4570457994644658f * x * (4.f * zz - xx - yy);
+            b[14] = 1.445305721320277f * z * (xx - yy);
+            b[15] = -0.5900435899266435f * x * (xx - 3.f * yy);
+        }
+    }
+}
+
+
 __device__ __forceinline__ float row16_sum(float v) {
     // quad_perm / row_ror rotate within a row of 16 lanes
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1

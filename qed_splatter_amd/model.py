@@ -543,6 +543,8 @@ class QEDSplatterModel(nn.Module):
             # is not written; parallel.exchange_grads_compact() rebuilds both from all ranks' views
             flags |= L.F_SH_GRAD_COMPACT
         self.last_viewmat = None
+        self.last_compact = bool(flags & L.F_SH_GRAD_COMPACT)
+        self.sh_views = None                  # set by parallel.exchange_grads_compact(rebuild=False)
         if cfg.sh_degree > 0:
             deg = min(self.step // cfg.sh_degree_interval, cfg.sh_degree)
             colors, sh_rest = self.features_dc, self.features_rest
@@ -658,25 +660,51 @@ class FlatAdam:
                                        _stream()), "qed_adam_step")
 
     @torch.no_grad()
-    def step(self, device_state: bool = False) -> None:
+    def step(self, device_state: bool = False, fused_sh: bool = False) -> None:
         """One Adam step.  ``device_state=True`` keeps the step counter / bias corrections in device
-        memory (qed_adam_step_dev), which is what makes the step replayable from a hipGraph."""
+        memory (qed_adam_step_dev), which is what makes the step replayable from a hipGraph.
+
+        ``fused_sh=True`` (after ``fused_loss(..., compact_sh_grad=True)`` + backward): the 48 N SH-coefficient
+        gradients are never written or read -- qed_adam_step_sh evaluates b_k(dir) x colour gradient while it
+        updates features_dc / features_rest (one view: this rank's; data parallel: the views gathered by
+        ``parallel.exchange_grads_compact(..., rebuild=False)``).  Same update as the plain step."""
         import ctypes as C
         p = self.model.flat_params
         g = self.model.flat_grad()
         if g is None:
             return
         lib = L.load()
+        sched = (-1, 0.0, 0.0, 0)
         if self.means_schedule is not None:                      # the rate of the step about to be taken
             lr_final, max_steps = self.means_schedule
             i = self.model.group_names.index("means")
-            if device_state:
+            if device_state and fused_sh:                        # evaluated by qed_adam_step_sh's own tick launch
+                sched = (i, self._means_lr_init, float(lr_final), int(max_steps))
+            elif device_state:
                 L.check(lib.qed_lr_exp_decay_dev(L.ptr(self.dev_lr[i:i + 1]), L.ptr(self.dev_state), self._means_lr_init,
                                                  float(lr_final), int(max_steps), _stream()), "qed_lr_exp_decay_dev")
             else:
                 self.lr[i] = exponential_decay_lr(self.t, self._means_lr_init, lr_final, max_steps)
                 self._lr[i] = self.lr[i]
         self.t += 1
+        if fused_sh:
+            m = self.model
+            if not getattr(m, "last_compact", False):
+                raise RuntimeError("fused_sh needs gradients from fused_loss(..., compact_sh_grad=True)")
+            assert m.group_names[-2:] == ["features_dc", "features_rest"]
+            views = m.sh_views
+            if views is None:                                    # this rank's view only
+                b = m.group_begin
+                views = (1, m.last_viewmat, 16, g[b[-3]:b[-2]], 0, 1.0)
+            n_views, viewmats, vm_stride, v_views, view_stride, scale = views
+            L.check(lib.qed_adam_step_sh(
+                L.ptr(p), L.ptr(g), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), len(self.lr),
+                C.cast(self._begin, C.c_void_p), None if device_state else C.cast(self._lr, C.c_void_p),
+                L.ptr(self.dev_lr) if device_state else None, self.betas[0], self.betas[1], self.eps, self.t,
+                L.ptr(self.dev_state) if device_state else None, *sched, m.num_points, int(m.last_sh_degree or 0),
+                L.ptr(m.means), n_views, L.ptr(viewmats), vm_stride, L.ptr(v_views), view_stride, float(scale),
+                _stream()), "qed_adam_step_sh")
+            return
         if device_state:
             L.check(lib.qed_adam_step_dev(L.ptr(p), L.ptr(g), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
                                           len(self.lr), C.cast(self._begin, C.c_void_p), L.ptr(self.dev_lr),

@@ -29,7 +29,7 @@ def allreduce_flat_grad(model, world_size: int, group=None) -> torch.Tensor:
     return g
 
 
-def exchange_grads_compact(model, world_size: int, group=None, views=None) -> torch.Tensor:
+def exchange_grads_compact(model, world_size: int, group=None, views=None, rebuild: bool = True) -> torch.Tensor:
     """Data-parallel gradient exchange that moves ~2.6x fewer bytes than all-reducing the flat gradient.
 
     The 48 SH-coefficient gradients of a Gaussian are b_k(direction to the camera) x (3 colour gradients): a
@@ -40,7 +40,11 @@ def exchange_grads_compact(model, world_size: int, group=None, views=None) -> to
     leaving ``model.flat_grad()`` exactly as ``allreduce_flat_grad`` would (up to fp32 summation order).
     At 8 ranks / 500 k Gaussians a rank receives 42 + 19 MB instead of moving 206 MB.
 
-    ``views`` (tests): a list of (colour-gradient [N,3], viewmat [1,4,4]) pairs standing in for the gather."""
+    ``views`` (tests): a list of (colour-gradient [N,3], viewmat [1,4,4]) pairs standing in for the gather.
+
+    ``rebuild=False`` skips step 3 and leaves the gathered views in ``model.sh_views`` for
+    ``FlatAdam.step(fused_sh=True)``, which evaluates the coefficient gradients inside the optimiser pass
+    (the message buffers are persistent, so a captured Adam graph keeps reading the right memory)."""
     from . import _lib as L
     g = model.flat_grad()
     if g is None:
@@ -51,12 +55,17 @@ def exchange_grads_compact(model, world_size: int, group=None, views=None) -> to
     geo, v_local = g[:begin[i_dc]], g[begin[i_dc]:begin[i_dc + 1]]
     nv = v_local.numel()                                          # 3 N
     row = nv + 16                                                 # one message per rank: colour gradients + view matrix
-    send = torch.empty(row, dtype=torch.float32, device=g.device)
+    n_rows = len(views) if views is not None else max(world_size, 1)
+    bufs = getattr(model, "_dp_buffers", None)
+    if bufs is None or bufs[0].numel() != row or bufs[1].shape != (n_rows, row) or bufs[0].device != g.device:
+        bufs = model._dp_buffers = (torch.empty(row, dtype=torch.float32, device=g.device),
+                                    torch.empty(n_rows, row, dtype=torch.float32, device=g.device))
+    send = bufs[0]
     send[:nv] = v_local
     send[nv:] = model.last_viewmat.reshape(-1).to(torch.float32)
     if views is not None:
         n_views = len(views)
-        recv = torch.empty(n_views, row, dtype=torch.float32, device=g.device)
+        recv = bufs[1]
         for c, (v, m) in enumerate(views):
             recv[c, :nv] = v.reshape(-1)
             recv[c, nv:] = m.reshape(-1)
@@ -67,13 +76,16 @@ def exchange_grads_compact(model, world_size: int, group=None, views=None) -> to
         else:
             dist.all_reduce(geo, op=dist.ReduceOp.SUM, group=group)
             geo.mul_(1.0 / world_size)
-        recv = torch.empty(world_size, row, dtype=torch.float32, device=g.device)
+        recv = bufs[1]
         if dist.get_backend(group) == "nccl":
             dist.all_gather_into_tensor(recv.view(-1), send, group=group)
         else:                                                     # gloo (rehearsal / CPU tests)
             dist.all_gather(list(recv.unbind(0)), send, group=group)
     else:
         n_views, recv = 1, send.view(1, row)
+    if not rebuild:
+        model.sh_views = (n_views, recv[:, nv:], row, recv, row, 1.0 / n_views)
+        return g
     rest_w = (begin[i_rest + 1] - begin[i_rest]) // max(N, 1)
     deg = int(model.last_sh_degree)
     assert 3 * ((deg + 1) ** 2 - 1) <= rest_w

@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--seed", type=int, default=1235)
     ap.add_argument("--async-m", action="store_true")
+    ap.add_argument("--compact", action="store_true", help="QED_F_SH_GRAD_COMPACT in project_bwd")
+    ap.add_argument("--fused-sh", action="store_true", help="compact + qed_adam_step_sh")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     L.load()
@@ -47,13 +49,13 @@ def main():
             p.grad = None
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        losses = model.fused_loss(cam, batch, sync=not (a.async_m and it > 0))
+        losses = model.fused_loss(cam, batch, sync=not (a.async_m and it > 0), compact_sh_grad=a.compact or a.fused_sh)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         losses["loss"].backward()
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        opt.step()
+        opt.step(fused_sh=a.fused_sh)
         torch.cuda.synchronize()
         t3 = time.perf_counter()
         ks = L.TIMER.summary()

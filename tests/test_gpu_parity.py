@@ -631,6 +631,71 @@ def test_compact_sh_gradient_exchange_equals_averaged_full_gradients(cuda):
     assert_close(got[:b[4]], full[-1][:b[4]], 1e-5, "geometry gradients unaffected by the compact flag")
 
 
+@pytest.mark.parametrize("n,model_step,device_state", [(1237, 30000, False), (1000, 30000, True), (1001, 1, True),
+                                                         (258, 0, False), (3, 30000, False)])
+def test_adam_with_sh_gradients_rebuilt_in_the_optimiser_equals_plain_step(cuda, n, model_step, device_state):
+    """qed_adam_step_sh (coefficient gradients b_k(dir) x v evaluated inside the optimiser pass, never in
+    memory) == qed_project_bwd writing them + the plain fused Adam step.  N values whose group boundaries are
+    not multiples of 4 floats, active SH degree 3 / 1 / 0, host- and device-resident step state."""
+    from qed_splatter_amd.model import FlatAdam, PinholeCameras
+    w, h = 96, 64
+    sc = scene(n, w, h, seed=21)
+    K = sc["Ks"][0]
+    cam = PinholeCameras(sc["camera_to_worlds"][:1].to(cuda), K[0, 0], K[1, 1], K[0, 2], K[1, 2], w, h)
+    runs = []
+    for fused in (False, True):
+        m, _, batch = _model(sc, cuda)
+        m.step = model_step
+        opt = FlatAdam(m, means_schedule=(1.6e-6, 50))
+        for _ in range(3):
+            for p in m.parameters():
+                p.grad = None
+            m.backward_fused(m.fused_loss(cam, batch, compact_sh_grad=fused))
+            opt.step(device_state=device_state, fused_sh=fused)
+        torch.cuda.synchronize()
+        runs.append((m, opt))
+    (m0, o0), (m1, o1) = runs
+    b = m0.group_begin
+    # geometry groups: same kernel, same inputs (up to the atomic summation order of their gradients)
+    assert_close(m1.flat_params[:b[4]], m0.flat_params[:b[4]], 1e-5, "geometry parameters")
+    for name, x1, x0 in (("params", m1.flat_params, m0.flat_params), ("exp_avg", o1.exp_avg, o0.exp_avg),
+                         ("exp_avg_sq", o1.exp_avg_sq, o0.exp_avg_sq)):
+        assert_close(x1[b[4]:b[5]], x0[b[4]:b[5]], 1e-5, f"features_dc {name}")
+        assert_close(x1[b[5]:], x0[b[5]:], 1e-5, f"features_rest {name}")
+    assert bool((o0.exp_avg[b[5]:] != 0).any()) == (min(model_step, 3) > 0)
+
+
+def test_adam_with_sh_gradients_from_several_views_equals_rebuild_then_step(cuda):
+    """Data-parallel form: the views gathered by exchange_grads_compact(rebuild=False) feed qed_adam_step_sh
+    directly == rebuilding the averaged coefficient gradients (qed_sh_grad_from_views) and the plain step."""
+    from qed_splatter_amd.model import FlatAdam, PinholeCameras
+    from qed_splatter_amd.parallel import exchange_grads_compact
+    w, h, n, n_views = 160, 96, 3001, 3
+    sc = scene(n, w, h, seed=13, n_cameras=n_views)
+    K = sc["Ks"][0]
+    views = []
+    for c in range(n_views):
+        m, _, batch = _model(sc, cuda)
+        cam = PinholeCameras(sc["camera_to_worlds"][c:c + 1].to(cuda), K[0, 0], K[1, 1], K[0, 2], K[1, 2], w, h)
+        m.backward_fused(m.fused_loss(cam, batch, compact_sh_grad=True))
+        views.append((m.gauss_params["features_dc"].grad.clone(), m.last_viewmat.clone()))
+    runs = []
+    for rebuild in (True, False):
+        m, _, batch = _model(sc, cuda)
+        opt = FlatAdam(m)
+        m.backward_fused(m.fused_loss(cam, batch, compact_sh_grad=True))
+        exchange_grads_compact(m, 1, views=views, rebuild=rebuild)
+        opt.step(fused_sh=not rebuild)
+        torch.cuda.synchronize()
+        runs.append((m, opt))
+    (m0, o0), (m1, o1) = runs
+    b = m0.group_begin
+    for name, x1, x0 in (("params", m1.flat_params, m0.flat_params), ("exp_avg", o1.exp_avg, o0.exp_avg),
+                         ("exp_avg_sq", o1.exp_avg_sq, o0.exp_avg_sq)):
+        assert_close(x1[b[4]:], x0[b[4]:], 1e-6, f"SH groups: {name}")
+        assert_close(x1[:b[4]], x0[:b[4]], 1e-5, f"geometry groups: {name}")
+
+
 def test_adam_step_in_ranges_equals_one_step(cuda):
     """FlatAdam.begin_step + step_range pieces (what parallel.allreduce_and_step interleaves with the chunked
     all-reduce) == FlatAdam.step, schedule included."""
