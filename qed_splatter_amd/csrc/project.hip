@@ -346,19 +346,31 @@ __device__ __forceinline__ void sh_bwd_stream(const float* __restrict__ sh0, con
     const float x = dir[0] * inorm, y = dir[1] * inorm, z = dir[2] * inorm;
     float b[K];
     sh_basis<DEG>(x, y, z, b);
-    float c[3 * K];
-    load_sh<K>(sh0, shN, c);
+    // ONE pass over the 3 K coefficients, each consumed as it arrives (holding all 48 beside the basis and its
+    // three derivative tables spilled 25 VGPRs at the 256-register limit): the colour needs sum_k b_k c_k, the
+    // direction gradient sum_k db_k (c_k . v) = sum_ch v_ch (sum_k db_k c_k,ch) -- nine sums that do not need v
     float col[3] = {0.f, 0.f, 0.f};
+    float S[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};      // [axis][channel]
+    {
+        float bx[K], by[K], bz[K];
+        sh_basis_grad<DEG>(x, y, z, bx, by, bz);
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        col[0] += b[k] * c[3 * k]; col[1] += b[k] * c[3 * k + 1]; col[2] += b[k] * c[3 * k + 2];
+        for (int k = 0; k < K; ++k) {
+            const float* ck = k == 0 ? sh0 : shN + 3 * (k - 1);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float c = ck[ch];
+                col[ch] += b[k] * c;
+                if (k > 0) { S[0][ch] += bx[k] * c; S[1][ch] += by[k] * c; S[2][ch] += bz[k] * c; }
+            }
+        }
     }
     float v[3];
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) v[ch] = (col[ch] + 0.5f >= 0.f) ? v_rgb_in[ch] : 0.f;
     if (compact) {
         // QED_F_SH_GRAD_COMPACT: only the clamp-masked colour gradient (3 floats) leaves the kernel; the 48
-        // coefficient gradients b_k(dir) v are rebuilt from it by qed_sh_grad_from_views
+        // coefficient gradients b_k(dir) v are rebuilt from it by qed_sh_grad_from_views / qed_adam_step_sh
         o0[0] = v[0]; o0[1] = v[1]; o0[2] = v[2];
     } else {
         o0[0] = b[0] * v[0]; o0[1] = b[0] * v[1]; o0[2] = b[0] * v[2];
@@ -368,14 +380,9 @@ __device__ __forceinline__ void sh_bwd_stream(const float* __restrict__ sh0, con
         }
     }
     if constexpr (DEG > 0) {
-        float bx[K], by[K], bz[K];
-        sh_basis_grad<DEG>(x, y, z, bx, by, bz);
-        float vx = 0.f, vy = 0.f, vz = 0.f;
-#pragma unroll
-        for (int k = 1; k < K; ++k) {
-            const float w = c[3 * k] * v[0] + c[3 * k + 1] * v[1] + c[3 * k + 2] * v[2];
-            vx += bx[k] * w; vy += by[k] * w; vz += bz[k] * w;
-        }
+        const float vx = S[0][0] * v[0] + S[0][1] * v[1] + S[0][2] * v[2];
+        const float vy = S[1][0] * v[0] + S[1][1] * v[1] + S[1][2] * v[2];
+        const float vz = S[2][0] * v[0] + S[2][1] * v[1] + S[2][2] * v[2];
         const float dot = vx * x + vy * y + vz * z;
         v_dir[0] += (vx - dot * x) * inorm;
         v_dir[1] += (vy - dot * y) * inorm;
@@ -384,7 +391,10 @@ __device__ __forceinline__ void sh_bwd_stream(const float* __restrict__ sh0, con
 }
 
 template <int DEG, bool ONE_CAM>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+#ifndef QED_PBWD_WAVES
+#define QED_PBWD_WAVES 2
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QED_PBWD_WAVES, QED_PBWD_WAVES)))
 project_bwd_kernel(int N, int C, const float* __restrict__ means, const float* __restrict__ quats,
                    const float* __restrict__ scales, const float* __restrict__ opacities,
                    const float* __restrict__ sh0, int sh0_stride, const float* __restrict__ shN, int shN_stride,
