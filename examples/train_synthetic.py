@@ -61,9 +61,9 @@ def main():
         model.step = 10_000 + step
         for p in model.parameters():
             p.grad = None
-        losses = model.fused_loss(cam, batch)
+        losses = model.fused_loss(cam, batch, compact_sh_grad=True)
         model.backward_fused(losses)
-        opt.step()
+        opt.step(fused_sh=True)       # SH-coefficient gradients expanded inside the Adam pass
         dens.after_train(step)
         if step % dens.config.refine_every == 0:
             info = dens.refinement_after(step)

@@ -50,12 +50,12 @@ for step in range(steps):
     for p in model.parameters():
         p.grad = None
     try:
-        losses = model.fused_loss(cams[c], batches[c], sync=(step % 100 == 0))     # async between refinements
+        losses = model.fused_loss(cams[c], batches[c], sync=(step % 100 == 0), compact_sh_grad=True)     # async between refinements
     except L.QedSplatError as e:                                                       # async overflow protocol
         print(f"step {step}: {e}")
-        losses = model.fused_loss(cams[c], batches[c], sync=True)
+        losses = model.fused_loss(cams[c], batches[c], sync=True, compact_sh_grad=True)
     model.backward_fused(losses)
-    opt.step()
+    opt.step(fused_sh=True)
     dens.after_train(step)
     if step % dens.config.refine_every == 0:
         info = dens.refinement_after(step)
