@@ -299,6 +299,22 @@ __device__ __forceinline__ void fwd_tile(int tile, int q0, int C, const float4* 
 #endif
 }
 
+// Quadrant waves: block r of the tail -> (tile, quadrant).  Workgroups are dealt round-robin over the 8 XCDs, so
+// the four waves of a tile get block indices that are congruent mod 8 (r = 32 j + 8 q + x  ->  tile 8 j + x):
+// they run on the same XCD at about the same time and share its L2 copy of the tile's records (r -> (r >> 2,
+// r & 3) put them on four XCDs and tripled the kernel's HBM fetch).
+__device__ __forceinline__ void small_wave(int r, int n_small, int& t, int& q) {
+    const int full = n_small & ~7;                       // tiles in whole groups of 8
+    if (r < 4 * full) {
+        t = ((r >> 5) << 3) | (r & 7);
+        q = (r >> 3) & 3;
+    } else {
+        const int rr = r - 4 * full, rem = n_small - full;
+        q = rr / rem;
+        t = full + rr - q * rem;
+    }
+}
+
 // Launch shape: the first n_big positions of the (XCD-remapped) tile order are composited by one wave each;
 // every later tile by FOUR waves, one per quadrant.  Workgroups are dispatched in index order, so the
 // quarter-size work items arrive last and fill the end of the launch, where whole-tile waves would leave most
@@ -315,8 +331,9 @@ composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
         fwd_tile<CH, 4>(xcd_remap(b, n_total), 0, C, splats, flatten_ids, offsets, width, height, tile_w, tile_h,
                         backgrounds, render, alpha_out, last_ids);
     } else {
-        const int r = b - n_big;
-        fwd_tile<CH, 1>(xcd_remap(n_big + (r >> 2), n_total), r & 3, C, splats, flatten_ids, offsets, width, height,
+        int t, q;
+        small_wave(b - n_big, n_total - n_big, t, q);
+        fwd_tile<CH, 1>(xcd_remap(n_big + t, n_total), q, C, splats, flatten_ids, offsets, width, height,
                         tile_w, tile_h, backgrounds, render, alpha_out, last_ids);
     }
 }
@@ -586,8 +603,9 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
         bwd_tile<CH, 4>(xcd_remap(b, n_total), 0, s_acc, C, splats, flatten_ids, offsets, width, height, tile_w, tile_h,
                         backgrounds, render_alpha, last_ids, v_render, v_alpha, vsplat);
     } else {
-        const int r = b - n_big;
-        bwd_tile<CH, 1>(xcd_remap(n_big + (r >> 2), n_total), r & 3, s_acc, C, splats, flatten_ids, offsets, width, height,
+        int t, q;
+        small_wave(b - n_big, n_total - n_big, t, q);
+        bwd_tile<CH, 1>(xcd_remap(n_big + t, n_total), q, s_acc, C, splats, flatten_ids, offsets, width, height,
                         tile_w, tile_h, backgrounds, render_alpha, last_ids, v_render, v_alpha, vsplat);
     }
 }

@@ -85,8 +85,6 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
-// ---- wave64 cross-lane helpers (DPP; no LDS traffic) --------------------------------------
-// sum over the 16 lanes of each DPP row; result valid in every lane of the row
 // ---- spherical harmonics (standard real SH basis, 3DGS constants) ------------------------------
 constexpr float SH_C0 = 0.28209479177387814f;
 constexpr float SH_C1 = 0.4886025119029199f;
@@ -118,6 +116,8 @@ __device__ __forceinline__ void sh_basis(float x, float y, float z, float* b) {
 }
 
 
+// ---- wave64 cross-lane helpers (DPP; no LDS traffic) --------------------------------------
+// sum over the 16 lanes of each DPP row; result valid in every lane of the row
 __device__ __forceinline__ float row16_sum(float v) {
     // quad_perm / row_ror rotate within a row of 16 lanes
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1

@@ -105,7 +105,10 @@ __device__ __forceinline__ void read16(const float* __restrict__ p, float (&v)[1
 }
 
 template <bool COMPOSITE, class T>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+#ifndef QED_SSIM_FWD_WAVES
+#define QED_SSIM_FWD_WAVES 4
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QED_SSIM_FWD_WAVES, QED_SSIM_FWD_WAVES)))
 ssim_fwd_kernel(int H, int W, int channels, const float* __restrict__ pred, const float* __restrict__ alpha,
                 const float* __restrict__ bg, const float* __restrict__ gt, float* __restrict__ maps,
                 float* __restrict__ ssim_sum) {
