@@ -319,8 +319,14 @@ __device__ __forceinline__ void small_wave(int r, int n_small, int& t, int& q) {
 // every later tile by FOUR waves, one per quadrant.  Workgroups are dispatched in index order, so the
 // quarter-size work items arrive last and fill the end of the launch, where whole-tile waves would leave most
 // wave slots idle (measured: 2.7 of 5 resident waves per SIMD on average with whole tiles only).
+#ifndef QED_K6_WAVES
+#define QED_K6_WAVES 5
+#endif
+#ifndef QED_K7_WAVES
+#define QED_K7_WAVES 4
+#endif
 template <int CH>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QED_K6_WAVES, QED_K6_WAVES)))
 composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __restrict__ flatten_ids,
                      const int* __restrict__ offsets, int width, int height, int tile_w, int tile_h,
                      const float* __restrict__ backgrounds, float* __restrict__ render, float* __restrict__ alpha_out,
@@ -590,7 +596,7 @@ __device__ __forceinline__ void bwd_tile(int tile, int q0, float (*s_acc)[12], i
 
 // same launch shape as composite_fwd_kernel: whole-tile waves first, quadrant waves for the last tiles
 template <int CH>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QED_K7_WAVES, QED_K7_WAVES)))
 composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __restrict__ flatten_ids,
                      const int* __restrict__ offsets, int width, int height, int tile_w, int tile_h,
                      const float* __restrict__ backgrounds, const float* __restrict__ render_alpha,
@@ -646,7 +652,7 @@ extern "C" int qed_composite_fwd(int32_t C, int32_t N, const float* splats, cons
     const long long grid = (long long)C * tile_w * tile_h;
     QED_REQUIRE(grid < (1ll << 31), "too many tiles");
     hipStream_t st = (hipStream_t)stream;
-    const long long n_big = big_tiles(grid, 1.9, 5);
+    const long long n_big = big_tiles(grid, 1.9, QED_K6_WAVES);
     const unsigned blocks = (unsigned)(n_big + 4 * (grid - n_big));
     if (channels == 4)
         hipLaunchKernelGGL(composite_fwd_kernel<4>, dim3(blocks), dim3(64), 0, st, C, (const float4*)splats,
@@ -674,7 +680,7 @@ extern "C" int qed_composite_bwd(int32_t C, int32_t N, const float* splats, cons
     const long long grid = (long long)C * tile_w * tile_h;
     QED_REQUIRE(grid < (1ll << 31), "too many tiles");
     hipStream_t st = (hipStream_t)stream;
-    const long long n_big = big_tiles(grid, 1.2, 4);
+    const long long n_big = big_tiles(grid, 1.2, QED_K7_WAVES);
     const unsigned blocks = (unsigned)(n_big + 4 * (grid - n_big));
     if (channels == 4)
         hipLaunchKernelGGL(composite_bwd_kernel<4>, dim3(blocks), dim3(64), 0, st, C, (const float4*)splats,
