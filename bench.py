@@ -151,6 +151,20 @@ def main():
 
     # SH-coefficient gradients as (3 colour gradients + view) per Gaussian, expanded inside the optimiser pass
     # (qed_adam_step_sh): the default; --dp-plain / --plain-adam materialise the 48 N gradients instead
+    # Training changes the scene (and with it the list length M and the step time: random ground truth drives
+    # opacities down), so every timed region measures the SAME steps of the same run: parameters and optimiser
+    # state are put back to the initial scene, W warm-up steps are taken, then K steps are timed.
+    init_params = model.flat_params.detach().clone()
+
+    def restore():
+        with torch.no_grad():
+            model.flat_params.copy_(init_params)
+            opt.exp_avg.zero_()
+            opt.exp_avg_sq.zero_()
+            opt.dev_state.zero_()
+        opt.t = 0
+        opt.set_lr("means", opt._means_lr_init)
+
     dp_compact = not args.dp_plain and not args.plain_adam
     fused_sh = dp_compact
 
@@ -192,7 +206,8 @@ def main():
     M_ref = M if M_ref is None else M_ref
     n_vis = int((model.info["radii"] > 0).sum())
     log(f"scene ready: N={n} visible={n_vis} M={M}")
-    for _ in range(max(args.warmup - 1, 0)):
+    restore()
+    for _ in range(args.warmup):
         step(args.sync_m)
     torch.cuda.synchronize()
 
@@ -277,25 +292,58 @@ def main():
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             captured = bool(int(ok))
         if captured:
-            for _ in range(3):
-                run()
-            graphed.check()
             log(f"step captured: {dispatch}")
         else:
             use_graph, dispatch = False, "eager (graph capture failed)"
             run = lambda: step(args.sync_m)
+
+    def rewind():
+        """Back to the initial scene + W warm-up steps: what precedes every timed region."""
+        restore()
+        for _ in range(args.warmup):
+            run()
+        if use_graph:
+            graphed.check()
+
+    rewind()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run()
+    t_issue = time.perf_counter() - t0               # host time to enqueue the steps (logged, not reported)
     barrier()
     dt2 = time.perf_counter() - t0
+    log(f"host enqueue time {t_issue / args.steps * 1e3:.3f} ms/step")
     if use_graph:
         graphed.check()                                # no intersection overflow during the timed replays
     if dist is not None:
         t = torch.tensor([dt2], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt2 = float(t)
+
+    # per-step spread (SURVEY 8d: median and p10/p90): a third, short region with a HIP event between
+    # consecutive steps -- kept out of the headline region, which contains nothing but the steps
+    pct = None
+    if world == 1:
+        n_ev = min(max(args.steps, 20), 100)
+        rewind()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev + 1)]
+        evs[0].record()
+        for i in range(n_ev):
+            run()
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        per = sorted(a.elapsed_time(b) for a, b in zip(evs[:-1], evs[1:]))
+        pct = {"p10": round(per[int(0.1 * (n_ev - 1))], 4), "p50": round(per[(n_ev - 1) // 2], 4),
+               "p90": round(per[int(0.9 * (n_ev - 1))], 4), "steps": n_ev}
+
+    # list length after W + K steps of training (the scene drifts; config.intersections is the first step's)
+    rewind()
+    for _ in range(args.steps):
+        run()
+    with torch.no_grad():
+        model.fused_loss(cam, batch, background=bg, sync=True)
+    M_end = int(model.info["n_isects"])
 
     if rank == 0:
         ms_step = dt2 / args.steps * 1e3
@@ -339,7 +387,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n} Gaussians, SH deg 3, {world} cam(s) @ {w}x{h}, 1 per GPU, fwd+bwd with "
                                    f"depth-L1 + (0.8 L1 + 0.2 (1-SSIM)) RGB loss + fused Adam",
-                       "gaussians": n, "visible": n_vis, "intersections": M, "intersections_reference_list": M_ref,
+                       "gaussians": n, "visible": n_vis, "intersections": M, "intersections_after_timed_steps": M_end,
+                       "intersections_reference_list": M_ref,
                        "tile_lists": "tight (tiles of the 3-sigma square that can reach alpha >= 1/255; images and "
                                      "gradients identical)" if cfg.tight_tile_lists else "gsplat 3-sigma squares",
                        "width": w, "height": h,
@@ -363,6 +412,7 @@ def main():
             "iters_per_s_without_optimizer": world * 1e3 / max(ms_step - max(kern.get("qed_adam_step", (0, 0.0))[1],
                                                                                       kern.get("qed_adam_step_sh", (0, 0.0))[1]), 1e-9),
             "ms_per_step_instrumented": dt / args.steps * 1e3,
+            "ms_per_step_percentiles": pct,
             "kernels_ms": {k: round(v[1], 4) for k, v in sorted(kern.items())},
             "roofline": roof,
         }
