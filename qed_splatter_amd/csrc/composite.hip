@@ -204,13 +204,19 @@ __device__ __forceinline__ void fwd_tile(int tile, int q0, int C, const float4* 
         px[q].out23 = (f2){0.f, 0.f};
     }
 
-    // prefetch batch 0
-    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
-    bool present = start + lane < end;
-    if (present) {
-        const size_t g = (size_t)flatten_ids[start + lane];
+    // Two-deep software pipeline over the batches: while batch b is composited the records of b+1 and the ids of b+2
+    // are in flight (fetched back to back, the id -> record dependency cost one exposed memory latency per batch).
+    // Every load is UNCONDITIONAL from a clamped index (lanes past the end re-read the tile's last entry: one cache
+    // line) into registers of its own that are rotated in at the end of the batch: a load under a per-lane
+    // condition is merged with the old value right behind it, which makes the wave wait for it on the spot.
+    auto id_at = [&](int idx) { return flatten_ids[idx < end ? idx : end - 1]; };
+    int rid_n = id_at(start + kBatch + lane);
+    float4 r0, r1, r2;
+    {
+        const size_t g = (size_t)id_at(start + lane);
         r0 = splats[3 * g]; r1 = splats[3 * g + 1]; r2 = splats[3 * g + 2];
     }
+    bool present = start + lane < end;
     auto and_done = [&]() { u64 m = ~0ull;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) m &= done[q];
@@ -230,15 +236,10 @@ __device__ __forceinline__ void fwd_tile(int tile, int q0, int C, const float4* 
         const float gx = r0.x, gy = r0.y;
         const float gA = -0.5f * kLog2e * r0.z, gB = -kLog2e * r0.w, gC = -0.5f * kLog2e * r1.x;
         const float gop = r1.y, gr = r1.z, gg = r1.w, gb = r2.x, gd = r2.y;
-        // issue the gather of the next batch; it lands while this batch is composited
-        if (b + 1 < nb) {
-            const int idx = start + (b + 1) * kBatch + lane;
-            present = idx < end;
-            if (present) {
-                const size_t g = (size_t)flatten_ids[idx];
-                r0 = splats[3 * g]; r1 = splats[3 * g + 1]; r2 = splats[3 * g + 2];
-            }
-        }
+        // issue the gather of the next batch (its ids arrived a batch ago) and the id load of the one after
+        const size_t g_n = (size_t)rid_n;
+        const float4 n0 = splats[3 * g_n], n1 = splats[3 * g_n + 1], n2 = splats[3 * g_n + 2];
+        const int rid_nn = id_at(start + (b + 2) * kBatch + lane);
         const int batch_start = start + b * kBatch;
         while (km) {
             const int t = __builtin_ctzll(km);
@@ -266,6 +267,9 @@ __device__ __forceinline__ void fwd_tile(int tile, int q0, int C, const float4* 
                 break;
             }
         }
+        r0 = n0; r1 = n1; r2 = n2;                      // rotate the pipeline (the wave waits HERE, not above)
+        rid_n = rid_nn;
+        present = start + (b + 1) * kBatch + lane < end;
     }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -497,19 +501,21 @@ __device__ __forceinline__ void bwd_tile(int tile, int q0, float (*s_acc)[12], i
     const int nb = (eff_end - start + kBatch - 1) / kBatch;
 
     // batches run back to front; lane l of batch b gathers sorted index (eff_end - 1 - 64 b - l)
-    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
-    int rid = -1;
-    {
-        const int idx = eff_end - 1 - lane;
-        if (idx >= start) {
-            rid = flatten_ids[idx];
-            r0 = splats[3 * (size_t)rid]; r1 = splats[3 * (size_t)rid + 1]; r2 = splats[3 * (size_t)rid + 2];
-        }
-    }
+    // two-deep pipeline as in the forward pass (unconditional loads from clamped indices, rotated at the end of the
+    // batch); lane l of batch b holds sorted index eff_end - 1 - 64 b - l, valid while >= start
+    auto id_at = [&](int idx) { return flatten_ids[idx > start ? idx : start]; };
+    int rid = id_at(eff_end - 1 - lane);
+    int rid_n = id_at(eff_end - 1 - kBatch - lane);
+    float4 r0 = splats[3 * (size_t)rid], r1 = splats[3 * (size_t)rid + 1], r2 = splats[3 * (size_t)rid + 2];
+    bool present = eff_end - 1 - lane >= start;
+    // everything fetched so far (pixel state, first records, second ids) has landed before the loop: inside it the
+    // only loads in flight are the prefetches, and the per-Gaussian body never waits on memory (without this the
+    // compiler's conservative loop-carried count put s_waitcnt vmcnt(0) in front of every quadrant body)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     for (int b = 0; b < nb; ++b) {
         const int batch_hi = eff_end - 1 - b * kBatch;            // sorted index gathered by lane 0
         u64 mq[NQ];
-        quadrant_masks<NQ>(rid >= 0, r0, r1, r2.z, ox, oy, q0, mq);
+        quadrant_masks<NQ>(present, r0, r1, r2.z, ox, oy, q0, mq);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             mq[q] = uniform_u64(mq[q]);
@@ -524,14 +530,9 @@ __device__ __forceinline__ void bwd_tile(int tile, int q0, float (*s_acc)[12], i
         const float gx = r0.x, gy = r0.y, gca = r0.z, gcb = r0.w, gcc = r1.x;
         const float gop = r1.y, gr = r1.z, gg = r1.w, gb = r2.x, gd = r2.y;
         const int gid = rid;
-        if (b + 1 < nb) {
-            const int idx = batch_hi - kBatch - lane;
-            rid = -1;
-            if (idx >= start) {
-                rid = flatten_ids[idx];
-                r0 = splats[3 * (size_t)rid]; r1 = splats[3 * (size_t)rid + 1]; r2 = splats[3 * (size_t)rid + 2];
-            }
-        }
+        const float4 n0 = splats[3 * (size_t)rid_n], n1 = splats[3 * (size_t)rid_n + 1],
+                     n2 = splats[3 * (size_t)rid_n + 2];
+        const int rid_nn = id_at(batch_hi - 2 * kBatch - lane);
         u64 touched = 0;
         while (km) {
             const int t = __builtin_ctzll(km);
@@ -591,6 +592,9 @@ __device__ __forceinline__ void bwd_tile(int tile, int q0, float (*s_acc)[12], i
             }
         }
         __syncthreads();
+        r0 = n0; r1 = n1; r2 = n2;                      // rotate the pipeline
+        rid = rid_n; rid_n = rid_nn;
+        present = batch_hi - kBatch - lane >= start;
     }
 }
 
