@@ -418,15 +418,16 @@ __device__ __forceinline__ void bwd_quadrant(f2 pq, f2 XY, f2 AC, float B, float
     g.rg += s.vr01 * ff;
     if constexpr (CH == 4) g.bd += s.vr23 * ff;
     else g.bd.x += s.vr23.x * fac;
-    const float v_a = Tn * cv - ra * s.bufv;
+    const float v_a = __builtin_fmaf(Tn, cv, -(ra * s.bufv));      // mul + fma (the packed form needs a register copy)
     s.bufv = __builtin_fmaf(fac, cv, s.bufv);
     const u64 m_vs = m_valid & __ballot(opv <= kAlphaMax);
     const float vs = sel(m_vs, -opv * v_a, 0.f);
     const f2 sv = d * (f2){vs, vs};                     // (v_sigma dx, v_sigma dy)
     const f2 v = cab * (f2){sv.x, sv.x} + cbc * (f2){sv.y, sv.y};   // (ca sx + cb sy, cb sx + cc sy)
     g.vxy += v;
-    g.ax += fabsf(v.x);
-    g.ay += fabsf(v.y);
+    // |.| as a source modifier of a plain add (the compiler's and + and + packed add is one instruction more)
+    asm("v_add_f32_e64 %0, %0, |%1|" : "+v"(g.ax) : "v"(v.x));
+    asm("v_add_f32_e64 %0, %0, |%1|" : "+v"(g.ay) : "v"(v.y));
     g.c01 += d * (f2){sv.x, sv.x};                      // (sx dx, sx dy)
     g.c2 = __builtin_fmaf(sv.y, d.y, g.c2);
     g.s0 += vs;
