@@ -74,16 +74,20 @@ isect_emit_kernel(int N, int C, const float* __restrict__ means2d, const int* __
     int cnt = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0;
     unsigned dbits = 0;
     if (pos < total) {
-        cnt = tiles_per_gauss[slot];
-        if (cnt > 0) {
-            if (splats != nullptr) {
-                // the rectangle project_fwd counted (QED_F_TIGHT_TILES or not), packed in record slot 11
-                const unsigned r = __float_as_uint(splats[(size_t)slot * QED_SPLAT_FLOATS + 11]);
-                x0 = (int)(r & 2047u); y0 = (int)((r >> 11) & 2047u); x1 = x0 + (int)(r >> 22);
-            } else {
+        if (splats != nullptr) {
+            // the rectangle project_fwd counted (QED_F_TIGHT_TILES or not), packed in record slot 11.  Fetched
+            // beside the count, not behind it: both gathers depend on `slot` only (a rectangle read under
+            // `cnt > 0` is a third serialised random access per Gaussian)
+            const unsigned r = __float_as_uint(splats[(size_t)slot * QED_SPLAT_FLOATS + 11]);
+            cnt = tiles_per_gauss[slot];
+            x0 = (int)(r & 2047u); y0 = (int)((r >> 11) & 2047u); x1 = x0 + (int)(r >> 22);
+            if constexpr (sizeof(KeyT) == 8) dbits = __float_as_uint(depths[slot]);
+        } else {
+            cnt = tiles_per_gauss[slot];
+            if (cnt > 0) {
                 tile_rect(means2d[2 * slot], means2d[2 * slot + 1], (float)radii[slot], tile_w, tile_h, x0, y0, x1, y1);
+                dbits = __float_as_uint(depths[slot]);
             }
-            dbits = __float_as_uint(depths[slot]);
         }
     }
     // wave-inclusive scan of the counts
