@@ -123,7 +123,11 @@ __device__ __forceinline__ float row16_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));  // row_ror:2
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+    // row_ror:8 as ONE instruction.  Written with the builtin, the compiler sinks this last add into a following
+    // `if (lane % 16 == 0)` and leaves v_mov 0 + v_mov_dpp outside it: three instructions instead of one, per value.
+    // (s_nop 1: a DPP read needs two wait states after the VALU write of its source; the compiler cannot see
+    // that hazard through inline asm.)
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(v));
     return v;
 }
 

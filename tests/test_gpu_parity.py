@@ -400,7 +400,9 @@ def test_ssim_errors_and_symmetry(cuda):
         ssim(torch.rand(10, 40, 3, device=cuda), torch.rand(10, 40, 3, device=cuda))
     a, b = torch.rand(33, 33, 3, device=cuda), torch.rand(33, 33, 3, device=cuda)
     assert float(ssim(a, a)) == pytest.approx(1.0, abs=1e-6)
-    assert float(ssim(a, b)) == pytest.approx(float(ssim(b, a)), rel=1e-6)
+    # SSIM of two random images is a mean of ~1600 values of either sign that nearly cancel (~1e-4): symmetric to
+    # fp32 rounding on the scale of SSIM itself, not relative to that remainder (fma(x,x,y*y) != fma(y,y,x*x))
+    assert float(ssim(a, b)) == pytest.approx(float(ssim(b, a)), abs=1e-6)
 
 
 def test_image_metrics_match_reference_vectors_and_oracle(cuda):
