@@ -51,12 +51,15 @@ __device__ __forceinline__ float bcast(float v, int t) {
 }
 
 // ---- exact-conservative tile culling ---------------------------------------------------------------
-__device__ __forceinline__ float rect_min_sigma(float a, float b, float c, float x0, float x1, float y0, float y1,
-                                                float& scale) {
+// ia, ic = 1/a, 1/c to within an ulp (v_rcp_f32, once per Gaussian for the tile and its four quadrants -- as IEEE
+// divisions inside this function they were a third of the staging instructions): they only place the point on an
+// edge at which the quadratic is evaluated, and a point that is off the minimiser by one part in 1e7 raises the
+// result by one part in 1e14 -- the margin the callers add is eleven orders of magnitude wider.
+__device__ __forceinline__ float rect_min_sigma(float a, float b, float c, float ia, float ic, float x0, float x1,
+                                                float y0, float y1, float& scale) {
     const float ax = fmaxf(fabsf(x0), fabsf(x1)), ay = fmaxf(fabsf(y0), fabsf(y1));
     scale = a * ax * ax + c * ay * ay + fabsf(b) * ax * ay;
     if (x0 <= 0.f && x1 >= 0.f && y0 <= 0.f && y1 >= 0.f) return 0.f;
-    const float ia = 1.f / a, ic = 1.f / c;
     float m;
     {
         const float y = fminf(fmaxf(-b * x0 * ic, y0), y1);
@@ -80,20 +83,21 @@ __device__ __forceinline__ float rect_min_sigma(float a, float b, float c, float
 // Can the Gaussian (record r0 = {x,y,ca,cb}, r1.x = cc, tau = ln(255 o)) reach alpha >= 1/255 at any
 // pixel centre of the tile whose pixel origin is (ox, oy)?  The margin covers fp32 rounding of this
 // bound and of the per-pixel evaluation, so "false" implies every pixel would have skipped it.
-__device__ __forceinline__ bool tile_may_touch(const float4& r0, const float4& r1, float tau, float ox, float oy) {
+__device__ __forceinline__ bool tile_may_touch(const float4& r0, const float4& r1, float ia, float ic, float tau,
+                                               float ox, float oy) {
     const float x0 = ox + 0.5f - r0.x, x1 = x0 + 15.f;
     const float y0 = oy + 0.5f - r0.y, y1 = y0 + 15.f;
     float scale;
-    const float smin = rect_min_sigma(r0.z, r0.w, r1.x, x0, x1, y0, y1, scale);
+    const float smin = rect_min_sigma(r0.z, r0.w, r1.x, ia, ic, x0, x1, y0, y1, scale);
     return !(smin > tau + 1e-3f + 8e-6f * scale);
 }
 // the same for one 8x8 quadrant (q & 1 = right half, q >> 1 = lower half)
-__device__ __forceinline__ bool quadrant_may_touch(const float4& r0, const float4& r1, float tau, float ox, float oy,
-                                                   int q) {
+__device__ __forceinline__ bool quadrant_may_touch(const float4& r0, const float4& r1, float ia, float ic, float tau,
+                                                   float ox, float oy, int q) {
     const float x0 = ox + (float)((q & 1) << 3) + 0.5f - r0.x, x1 = x0 + 7.f;
     const float y0 = oy + (float)((q >> 1) << 3) + 0.5f - r0.y, y1 = y0 + 7.f;
     float scale;
-    const float smin = rect_min_sigma(r0.z, r0.w, r1.x, x0, x1, y0, y1, scale);
+    const float smin = rect_min_sigma(r0.z, r0.w, r1.x, ia, ic, x0, x1, y0, y1, scale);
     return !(smin > tau + 1e-3f + 8e-6f * scale);
 }
 // per-quadrant survivor masks of the 64 staged Gaussians (one per lane).  NQ = 4: the whole tile;
@@ -102,12 +106,13 @@ template <int NQ>
 __device__ __forceinline__ void quadrant_masks(bool present, const float4& r0, const float4& r1, float tau, float ox,
                                                float oy, int q0, u64* mq) {
     bool k[NQ];
+    const float ia = __builtin_amdgcn_rcpf(r0.z), ic = __builtin_amdgcn_rcpf(r1.x);
     if constexpr (NQ == 4) {
-        const bool tile_keep = present && tile_may_touch(r0, r1, tau, ox, oy);
+        const bool tile_keep = present && tile_may_touch(r0, r1, ia, ic, tau, ox, oy);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) k[q] = tile_keep && quadrant_may_touch(r0, r1, tau, ox, oy, q);
+        for (int q = 0; q < 4; ++q) k[q] = tile_keep && quadrant_may_touch(r0, r1, ia, ic, tau, ox, oy, q);
     } else {
-        k[0] = present && quadrant_may_touch(r0, r1, tau, ox, oy, q0);
+        k[0] = present && quadrant_may_touch(r0, r1, ia, ic, tau, ox, oy, q0);
     }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) mq[q] = __ballot(k[q]);
@@ -588,7 +593,7 @@ __device__ __forceinline__ void bwd_tile(int tile, int q0, float (*s_acc)[12], i
             if (t >= 0 && k < 12) {
                 float v = s_acc[t][k];
                 if (k == 4 || k == 6) v *= 0.5f;
-                if (k == 7) v = -v / opac;
+                if (k == 7) v = -v * __builtin_amdgcn_rcpf(opac);   // (an IEEE division is 11 instructions for the whole wave)
                 if (v != 0.f) atomicAdd(&vsplat[(size_t)id * QED_VSPLAT_FLOATS + k], v);
             }
         }
