@@ -50,69 +50,61 @@ __device__ __forceinline__ float bcast(float v, int t) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), t));
 }
 
-// ---- exact-conservative tile culling ---------------------------------------------------------------
-// ia, ic = 1/a, 1/c to within an ulp (v_rcp_f32, once per Gaussian for the tile and its four quadrants -- as IEEE
-// divisions inside this function they were a third of the staging instructions): they only place the point on an
-// edge at which the quadratic is evaluated, and a point that is off the minimiser by one part in 1e7 raises the
-// result by one part in 1e14 -- the margin the callers add is eleven orders of magnitude wider.
-__device__ __forceinline__ float rect_min_sigma(float a, float b, float c, float ia, float ic, float x0, float x1,
-                                                float y0, float y1, float& scale) {
-    const float ax = fmaxf(fabsf(x0), fabsf(x1)), ay = fmaxf(fabsf(y0), fabsf(y1));
-    scale = a * ax * ax + c * ay * ay + fabsf(b) * ax * ay;
-    if (x0 <= 0.f && x1 >= 0.f && y0 <= 0.f && y1 >= 0.f) return 0.f;
-    float m;
-    {
-        const float y = fminf(fmaxf(-b * x0 * ic, y0), y1);
-        m = 0.5f * (a * x0 * x0 + c * y * y) + b * x0 * y;
-    }
-    {
-        const float y = fminf(fmaxf(-b * x1 * ic, y0), y1);
-        m = fminf(m, 0.5f * (a * x1 * x1 + c * y * y) + b * x1 * y);
-    }
-    {
-        const float x = fminf(fmaxf(-b * y0 * ia, x0), x1);
-        m = fminf(m, 0.5f * (a * x * x + c * y0 * y0) + b * x * y0);
-    }
-    {
-        const float x = fminf(fmaxf(-b * y1 * ia, x0), x1);
-        m = fminf(m, 0.5f * (a * x * x + c * y1 * y1) + b * x * y1);
-    }
-    return m;
+// ---- exact-conservative culling of (Gaussian, 8x8 quadrant) pairs -----------------------------------------------
+// alpha >= 1/255  <=>  sigma(d) = (a dx^2 + c dy^2)/2 + b dx dy <= tau = ln(255 o).  sigma is convex, so over the
+// rectangle of a quadrant's pixel centres its minimum is 0 if the mean lies inside and otherwise sits on one of the
+// four edges; along an edge it is a 1-D quadratic whose minimiser is clamped to the edge (v_med3).  A pair whose
+// minimum exceeds tau by more than the rounding margin is one every pixel would have skipped.
+//
+// sigma minimised over t in [lo, hi] on the line where the other coordinate is fixed:
+//   h = (own diagonal term)/2 * fixed^2,  bb = b * fixed,  s = -bb / (other diagonal term),  ho = (other term)/2
+__device__ __forceinline__ float edge_min(float h, float bb, float s, float ho, float lo, float hi) {
+    const float t = __builtin_amdgcn_fmed3f(s, lo, hi);
+    return __builtin_fmaf(t, __builtin_fmaf(ho, t, bb), h);
 }
 
-// Can the Gaussian (record r0 = {x,y,ca,cb}, r1.x = cc, tau = ln(255 o)) reach alpha >= 1/255 at any
-// pixel centre of the tile whose pixel origin is (ox, oy)?  The margin covers fp32 rounding of this
-// bound and of the per-pixel evaluation, so "false" implies every pixel would have skipped it.
-__device__ __forceinline__ bool tile_may_touch(const float4& r0, const float4& r1, float ia, float ic, float tau,
-                                               float ox, float oy) {
-    const float x0 = ox + 0.5f - r0.x, x1 = x0 + 15.f;
-    const float y0 = oy + 0.5f - r0.y, y1 = y0 + 15.f;
-    float scale;
-    const float smin = rect_min_sigma(r0.z, r0.w, r1.x, ia, ic, x0, x1, y0, y1, scale);
-    return !(smin > tau + 1e-3f + 8e-6f * scale);
+// Everything a lane needs about its staged Gaussian to test rectangles of the tile at pixel origin (ox, oy).
+// ia, ic = 1/a, 1/c to within an ulp (v_rcp_f32): they only place the point on an edge at which sigma is
+// evaluated, and a point off the minimiser by one part in 1e7 raises the value by one part in 1e14 -- the margin
+// is eleven orders of magnitude wider.  The margin uses the tile's extent for all four quadrants.
+struct CullGauss {
+    float b, ha, hc, ia, ic, X0, Y0, thr;
+};
+__device__ __forceinline__ CullGauss cull_setup(const float4& r0, const float4& r1, float tau, float ox, float oy) {
+    CullGauss g;
+    const float a = r0.z, c = r1.x;
+    g.b = r0.w; g.ha = 0.5f * a; g.hc = 0.5f * c;
+    g.ia = __builtin_amdgcn_rcpf(a); g.ic = __builtin_amdgcn_rcpf(c);
+    g.X0 = ox + 0.5f - r0.x; g.Y0 = oy + 0.5f - r0.y;
+    const float ax = fmaxf(fabsf(g.X0), fabsf(g.X0 + 15.f)), ay = fmaxf(fabsf(g.Y0), fabsf(g.Y0 + 15.f));
+    const float scale = a * ax * ax + c * ay * ay + fabsf(g.b) * ax * ay;
+    g.thr = tau + 1e-3f + 8e-6f * scale;
+    return g;
 }
-// the same for one 8x8 quadrant (q & 1 = right half, q >> 1 = lower half)
-__device__ __forceinline__ bool quadrant_may_touch(const float4& r0, const float4& r1, float ia, float ic, float tau,
-                                                   float ox, float oy, int q) {
-    const float x0 = ox + (float)((q & 1) << 3) + 0.5f - r0.x, x1 = x0 + 7.f;
-    const float y0 = oy + (float)((q >> 1) << 3) + 0.5f - r0.y, y1 = y0 + 7.f;
-    float scale;
-    const float smin = rect_min_sigma(r0.z, r0.w, r1.x, ia, ic, x0, x1, y0, y1, scale);
-    return !(smin > tau + 1e-3f + 8e-6f * scale);
+// quadrant (i, j) = (right half, lower half).  The per-line terms of the four x- and four y-values of a tile are
+// common subexpressions of the four quadrants' tests (two quadrants share each line).
+__device__ __forceinline__ bool quadrant_may_touch(const CullGauss& g, int i, int j) {
+    const float xl = g.X0 + (float)(8 * i), xh = xl + 7.f, yl = g.Y0 + (float)(8 * j), yh = yl + 7.f;
+    auto vline = [&](float X) { const float bb = g.b * X; return edge_min(g.ha * X * X, bb, -bb * g.ic, g.hc, yl, yh); };
+    auto hline = [&](float Y) { const float bb = g.b * Y; return edge_min(g.hc * Y * Y, bb, -bb * g.ia, g.ha, xl, xh); };
+    const float m = fminf(fminf(vline(xl), vline(xh)), fminf(hline(yl), hline(yh)));
+    // (& and |, not && and ||: branch-free, so the line terms are shared between quadrants instead of being
+    // recomputed inside four separately predicated blocks)
+    const bool inside = (xl <= 0.f) & (xh >= 0.f) & (yl <= 0.f) & (yh >= 0.f);
+    return inside | !(m > g.thr);
 }
 // per-quadrant survivor masks of the 64 staged Gaussians (one per lane).  NQ = 4: the whole tile;
 // NQ = 1: only quadrant q0 (a wave that owns one 8x8 quadrant of a tile, see composite_fwd_kernel)
 template <int NQ>
 __device__ __forceinline__ void quadrant_masks(bool present, const float4& r0, const float4& r1, float tau, float ox,
                                                float oy, int q0, u64* mq) {
+    const CullGauss g = cull_setup(r0, r1, tau, ox, oy);
     bool k[NQ];
-    const float ia = __builtin_amdgcn_rcpf(r0.z), ic = __builtin_amdgcn_rcpf(r1.x);
     if constexpr (NQ == 4) {
-        const bool tile_keep = present && tile_may_touch(r0, r1, ia, ic, tau, ox, oy);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) k[q] = tile_keep && quadrant_may_touch(r0, r1, ia, ic, tau, ox, oy, q);
+        for (int q = 0; q < 4; ++q) k[q] = present & quadrant_may_touch(g, q & 1, q >> 1);
     } else {
-        k[0] = present && quadrant_may_touch(r0, r1, ia, ic, tau, ox, oy, q0);
+        k[0] = present & quadrant_may_touch(g, q0 & 1, q0 >> 1);
     }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) mq[q] = __ballot(k[q]);
