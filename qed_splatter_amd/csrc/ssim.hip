@@ -135,14 +135,49 @@ ssim_fwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
     // cache line fully used.
     const int spy = tid / PW, spx = tid - spy * PW;
     const bool stager = tid < T::RPP * PW;
+    // Two loops: the first contains NOTHING but the loads (no branch on `channels`, no bounds test, no arithmetic
+    // on a loaded value), so all of them are issued back to back; the second composites / zeroes with selects.
+    // Written as one loop, every iteration ended in a branch and the disassembly showed seven serialised round
+    // trips (load, wait, composite, next load) per workgroup.
     float xs[T::LOADS][3], ys[T::LOADS][3];
+    {
+        Float3 graw[T::LOADS];
+        float4 praw[T::LOADS];
+        float araw[T::LOADS];
+        size_t pix[T::LOADS];
 #pragma unroll
-    for (int j = 0; j < T::LOADS; ++j) {
-        const int iy = oy + spy + T::RPP * j, ix = ox + spx;
-        load_pixel<COMPOSITE>(pred, alpha, bg, gt, channels, (size_t)min(iy, H - 1) * W + min(ix, W - 1), xs[j], ys[j]);
-        if (!(iy < H && ix < W)) {
+        for (int j = 0; j < T::LOADS; ++j)
+            pix[j] = (size_t)min(oy + spy + T::RPP * j, H - 1) * W + min(ox + spx, W - 1);
+        if (COMPOSITE && channels == 4) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { xs[j][k] = 0.f; ys[j][k] = 0.f; }
+            for (int j = 0; j < T::LOADS; ++j) {
+                graw[j] = *reinterpret_cast<const Float3*>(gt + pix[j] * 3);
+                praw[j] = *reinterpret_cast<const float4*>(pred + pix[j] * 4);
+                araw[j] = alpha[pix[j]];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < T::LOADS; ++j) {
+                graw[j] = *reinterpret_cast<const Float3*>(gt + pix[j] * 3);
+                const Float3 v = *reinterpret_cast<const Float3*>(pred + pix[j] * 3);
+                praw[j] = make_float4(v.a, v.b, v.c, 0.f);
+                araw[j] = COMPOSITE ? alpha[pix[j]] : 1.f;
+            }
+        }
+        float bgc[3] = {0.f, 0.f, 0.f};
+        if constexpr (COMPOSITE) { bgc[0] = bg[0]; bgc[1] = bg[1]; bgc[2] = bg[2]; }
+#pragma unroll
+        for (int j = 0; j < T::LOADS; ++j) {
+            const bool in = (oy + spy + T::RPP * j < H) & (ox + spx < W);
+            const float r[3] = {praw[j].x, praw[j].y, praw[j].z};
+            const float g[3] = {graw[j].a, graw[j].b, graw[j].c};
+            const float om = 1.f - araw[j];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float c = COMPOSITE ? fminf(fmaxf(r[k] + om * bgc[k], 0.f), 1.f) : r[k];
+                xs[j][k] = in ? c : 0.f;
+                ys[j][k] = in ? g[k] : 0.f;
+            }
         }
     }
     float acc = 0.f;
