@@ -211,6 +211,9 @@ __device__ __forceinline__ void sh_color_dyn(int deg, const float* sh0, const fl
 // ================================================================================================
 // forward
 // ================================================================================================
+// ONE_CAM (C == 1, the training case): the camera index is the constant 0 instead of a per-thread 64-bit
+// division, so the view matrix / intrinsics are fetched once per wave through the scalar cache
+template <bool ONE_CAM>
 __global__ void __launch_bounds__(256)
 project_fwd_kernel(int N, int C, const float* __restrict__ means, const float* __restrict__ quats,
                    const float* __restrict__ scales, const float* __restrict__ opacities,
@@ -226,14 +229,20 @@ project_fwd_kernel(int N, int C, const float* __restrict__ means, const float* _
     const long long total = (long long)C * N;
     int ntiles = 0;
     if (slot < total) {
-        const int c = (int)(slot / N);
+        const int c = ONE_CAM ? 0 : (int)(slot / N);
         const int n = (int)(slot - (long long)c * N);
         const Cam cam = load_cam(viewmats, Ks, c);
         float mean[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
         float q[4] = {quats[4 * n], quats[4 * n + 1], quats[4 * n + 2], quats[4 * n + 3]};
+        float s[3] = {scales[3 * n], scales[3 * n + 1], scales[3 * n + 2]};
+        float op_raw = opacities[n];
+        // all eleven parameter floats are requested together and have arrived here: left to itself the compiler
+        // sinks each load into the block that first needs it (mean | near-plane test | quats, scales | visibility
+        // | opacity), four dependent round trips per Gaussian where one will do
+        asm volatile("" : "+v"(mean[0]), "+v"(mean[1]), "+v"(mean[2]), "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]),
+                          "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(op_raw));
         const float qin = rsqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
         q[0] *= qin; q[1] *= qin; q[2] *= qin; q[3] *= qin;
-        float s[3] = {scales[3 * n], scales[3 * n + 1], scales[3 * n + 2]};
         if (flags & QED_F_LOG_SCALES) { s[0] = __expf(s[0]); s[1] = __expf(s[1]); s[2] = __expf(s[2]); }
         Proj p;
         project_one(cam, mean, q, s, width, height, eps2d, near_plane, far_plane, radius_clip, p);
@@ -245,7 +254,7 @@ project_fwd_kernel(int N, int C, const float* __restrict__ means, const float* _
         if (p.valid) {
             rad = (int)p.radius;
             mx = p.mx; my = p.my; z = p.z; ca = p.ca; cb = p.cb; cc = p.cc;
-            op = opacities[n];
+            op = op_raw;
             if (flags & QED_F_LOGIT_OPAC) op = sigmoidf_dev(op);
             if (flags & QED_F_ANTIALIASED) op *= p.comp;
             if (sh_degree >= 0) {
@@ -742,10 +751,14 @@ extern "C" int qed_project_fwd(int32_t N, int32_t C, const float* means, const f
                     block_sums, "null output");
     const long long total = (long long)C * N;
     const unsigned grid = (unsigned)((total + 255) / 256);
-    hipLaunchKernelGGL(project_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, N, C, means, quats, scales,
-                       opacities, sh0, sh0_stride, shN, shN_stride, sh_degree, viewmats, Ks, width, height, tile_w,
-                       tile_h, eps2d, near_plane, far_plane, radius_clip, flags, radii, means2d, depths, conics,
-                       opac_out, colors_out, (float4*)splats, tiles_per_gauss, block_sums);
+#define QED_LAUNCH_PF(ONE)                                                                                           \
+    hipLaunchKernelGGL(project_fwd_kernel<ONE>, dim3(grid), dim3(256), 0, (hipStream_t)stream, N, C, means, quats,   \
+                       scales, opacities, sh0, sh0_stride, shN, shN_stride, sh_degree, viewmats, Ks, width, height,  \
+                       tile_w, tile_h, eps2d, near_plane, far_plane, radius_clip, flags, radii, means2d, depths,     \
+                       conics, opac_out, colors_out, (float4*)splats, tiles_per_gauss, block_sums)
+    if (C == 1) QED_LAUNCH_PF(true);
+    else QED_LAUNCH_PF(false);
+#undef QED_LAUNCH_PF
     return check_launch("qed_project_fwd");
 }
 
