@@ -60,32 +60,6 @@ __device__ __forceinline__ float pred_at(const float* __restrict__ pred, const f
 
 struct __attribute__((packed, aligned(4))) Float3 { float a, b, c; };
 
-// all three channels of one pixel with as few (and as wide) requests as possible: 16 B of render,
-// 4 B of alpha, 12 B of ground truth.  x = predicted colour, y = ground truth.
-template <bool COMPOSITE>
-__device__ __forceinline__ void load_pixel(const float* __restrict__ pred, const float* __restrict__ alpha,
-                                           const float* __restrict__ bg, const float* __restrict__ gt, int channels,
-                                           size_t pix, float (&x)[3], float (&y)[3]) {
-    const Float3 g = *reinterpret_cast<const Float3*>(gt + pix * 3);
-    y[0] = g.a; y[1] = g.b; y[2] = g.c;
-    if constexpr (COMPOSITE) {
-        float r[3];
-        if (channels == 4) {
-            const float4 v = *reinterpret_cast<const float4*>(pred + pix * 4);
-            r[0] = v.x; r[1] = v.y; r[2] = v.z;
-        } else {
-            const Float3 v = *reinterpret_cast<const Float3*>(pred + pix * 3);
-            r[0] = v.a; r[1] = v.b; r[2] = v.c;
-        }
-        const float om = 1.f - alpha[pix];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) x[k] = fminf(fmaxf(r[k] + om * bg[k], 0.f), 1.f);
-    } else {
-        const Float3 v = *reinterpret_cast<const Float3*>(pred + pix * 3);
-        x[0] = v.a; x[1] = v.b; x[2] = v.c;
-    }
-}
-
 // 4 adjacent window sums of a row: out[o] = sum_d w[d] v[o + d], o = 0..3, from 14 consecutive inputs
 __device__ __forceinline__ float4 window4(const float (&v)[16], const float (&w)[kWin]) {
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
