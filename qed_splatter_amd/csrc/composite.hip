@@ -25,6 +25,7 @@
 //     reduced over the 64 lanes with v_permlane32_swap / v_permlane16_swap (the number of live
 //     values halves per level) + one DPP row reduction, parked in LDS and flushed with ONE
 //     64-byte-row atomic request per (tile, Gaussian) that actually contributed.
+#include <stdlib.h>
 #include "qed_common.h"
 
 namespace qed {
@@ -628,6 +629,12 @@ using namespace qed;
 // 1.2 x 4096 for the backward kernel), independent of the image size; an image with fewer tiles than that is
 // composited by quadrant waves only (it could not fill the device with whole-tile waves anyway).
 static long long big_tiles(long long n_tiles, double small_waves_per_slot, int waves_per_simd) {
+    // test hook (tests/test_gpu_parity.py): force one launch shape so that small images exercise all of them
+    if (const char* e = getenv("QED_COMPOSITE_WAVES")) {
+        if (e[0] == 't') return n_tiles;          // "tile": whole-tile waves only
+        if (e[0] == 'q') return 0;                // "quadrant": quadrant waves only
+        if (e[0] == 'h') return n_tiles / 2;      // "half": first half whole-tile, second half quadrant waves
+    }
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;

@@ -153,6 +153,48 @@ def test_composite_forward(cuda, mode, w, h, n):
     assert float(alpha.min()) >= 0.0 and float(alpha.max()) <= 1.0
 
 
+@pytest.mark.parametrize("shape", ["tile", "half", "quadrant"])
+def test_composite_launch_shapes_agree_with_oracle_and_each_other(cuda, monkeypatch, shape):
+    """The compositing kernels deal whole-tile waves first and one wave per 8x8 quadrant for the last tiles; which
+    tiles get which depends on the image size and the device.  QED_COMPOSITE_WAVES forces each shape on a small
+    image: the images of all shapes must be bit-identical (the default shape is the one the oracle tests see) and
+    the gradients equal up to the order of the atomic sums."""
+    import os
+    from qed_splatter_amd.model import get_viewmat
+    from qed_splatter_amd.rasterization import rasterization
+    w, h, n = 200, 136, 8000                       # 13 x 9 = 117 tiles: "half" splits after tile 58 (partial group)
+    sc = scene(n, w, h, seed=31)
+    ps = {k: sc[k].to(cuda).requires_grad_(True) for k in PARAM_NAMES}
+    def inputs():                                   # fresh activation graph per run
+        return dict(means=ps["means"], quats=torch.nn.functional.normalize(ps["quats"], dim=-1),
+                    scales=ps["scales"].exp(), opacities=torch.sigmoid(ps["opacities"]).squeeze(-1),
+                    colors=torch.cat([ps["features_dc"][:, None, :], ps["features_rest"]], dim=1),
+                    viewmats=get_viewmat(sc["camera_to_worlds"][:1].to(cuda)), Ks=sc["Ks"][:1].to(cuda), width=w,
+                    height=h, render_mode="RGB+D", sh_degree=3, absgrad=True)
+
+    g = torch.Generator().manual_seed(5)
+    wr = torch.rand(1, h, w, 4, generator=g).to(cuda)
+    wa = torch.rand(1, h, w, 1, generator=g).to(cuda)
+
+    def run(which):
+        if which is None:
+            monkeypatch.delenv("QED_COMPOSITE_WAVES", raising=False)
+        else:
+            monkeypatch.setenv("QED_COMPOSITE_WAVES", which)
+        assert os.environ.get("QED_COMPOSITE_WAVES") == which
+        render, alpha, _ = rasterization(**inputs())
+        grads = torch.autograd.grad((render * wr).sum() + (alpha * wa).sum(), [ps[k] for k in PARAM_NAMES])
+        return render.detach(), alpha.detach(), grads
+
+    r0, a0, g0 = run("tile")
+    r1, a1, g1 = run(shape)
+    assert torch.equal(r1, r0) and torch.equal(a1, a0)          # same per-pixel arithmetic in every shape
+    for k, x1, x0 in zip(PARAM_NAMES, g1, g0):
+        assert_close(x1, x0, 2e-5, f"{shape} vs tile: grad {k}")  # atomics reorder the per-Gaussian sums
+    r2, a2, g2 = run(None)                                         # the default rule (all-quadrant at this size)
+    assert torch.equal(r2, r0) and torch.equal(a2, a0)
+
+
 def test_composite_early_termination_and_background(cuda):
     """Dense opaque scene: most pixels terminate early (T <= 1e-4); with a background colour."""
     w, h, n = 96, 80, 20000
