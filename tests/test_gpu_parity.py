@@ -136,8 +136,11 @@ def _oracle_composite_inputs(info, channels):
     return m2, con, col, op
 
 
+@pytest.mark.parametrize("waves", [None, "tile"])      # default launch shape at these sizes: quadrant waves only
 @pytest.mark.parametrize("mode,w,h,n", [("RGB+D", 200, 136, 8000), ("RGB", 64, 48, 1500), ("RGB+D", 33, 17, 300)])
-def test_composite_forward(cuda, mode, w, h, n):
+def test_composite_forward(cuda, monkeypatch, mode, w, h, n, waves):
+    if waves:
+        monkeypatch.setenv("QED_COMPOSITE_WAVES", waves)
     sc = scene(n, w, h, seed=21)
     _, render, alpha, info = _raster_gpu(sc, cuda, w, h, render_mode=mode)
     ch = 4 if mode == "RGB+D" else 3
@@ -216,8 +219,11 @@ def test_composite_early_termination_and_background(cuda):
 # --------------------------------------------------------------------------------------------------
 # K7: compositing backward
 # --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("waves", [None, "tile"])
 @pytest.mark.parametrize("mode,w,h,n", [("RGB+D", 120, 88, 4000), ("RGB", 64, 48, 1500)])
-def test_composite_backward(cuda, mode, w, h, n):
+def test_composite_backward(cuda, monkeypatch, mode, w, h, n, waves):
+    if waves:
+        monkeypatch.setenv("QED_COMPOSITE_WAVES", waves)
     sc = scene(n, w, h, seed=33)
     a, render, alpha, info = _raster_gpu(sc, cuda, w, h, render_mode=mode, grad=True)
     ch = 4 if mode == "RGB+D" else 3
