@@ -3,8 +3,10 @@
 size, aspect, SH degree, rasterize mode, opacity / scale distributions and masks (a wider net than the fixed
 pytest cases).  Prints one line per case and a summary; exit code 1 on any violation.
 
-Losses must agree to 1e-4 (they agree to ~1e-7); gradients to 2e-4 of the group's largest magnitude over the
-Gaussians that are NOT listed in a tile holding a "threshold pixel" -- a pixel where the fp32 kernels and the
+Losses must agree to 1e-4 (they agree to ~1e-7); gradients to 2e-4 of the group's largest magnitude (the tests'
+definition; normalising by the largest magnitude among the KEPT Gaussians only flagged two of 100 dense scenes
+where 14 % / 28 % of weak Gaussians were left and fp32 cancellation noise of 2e-11 / 3e-8 absolute showed),
+compared over the Gaussians that are NOT listed in a tile holding a "threshold pixel" -- a pixel where the fp32 kernels and the
 fp64 oracle may legitimately take different sides of a non-smooth point: alpha >= 1/255, T <= 1e-4 (the oracle's
 margin), the colour clamp to [0,1], and the kinks of the two L1 terms (prediction == target within rounding).
 Gaussians within rounding of the SH colour clamp or of the Jacobian clamp at the frustum rim are left out too.
@@ -117,7 +119,7 @@ for case in (range(n_cases) if only is None else [only]):
         if keep.any():
             err = (a - b).abs().reshape(n, -1).amax(dim=1)
             err[~keep] = 0
-            e = float(err.max() / (b[keep].abs().max() + 1e-30))
+            e = float(err.max() / (b.abs().max() + 1e-30))        # of the reference tensor's largest magnitude
             if e > worst:
                 i = int(err.argmax())
                 worst, worst_at = e, (f"{k}[{i}] pre={pre[i].tolist()} radius={int(radii[0, i])} "
