@@ -66,24 +66,37 @@ sort_scan_kernel(const int* __restrict__ n_dev, int nblocks_max, int* __restrict
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (tid == 0) s_carry = 0;
     __syncthreads();
-    for (int b0 = 0; b0 < nb; b0 += kSortThreads) {
-        const int i = b0 + tid;
-        const int v = i < nb ? row[i] : 0;
-        int x = v;
+    // eight 256-wide slices per outer step: their loads are issued together (unconditional, clamped index), so a
+    // row of 1 640 block counts costs one memory round trip instead of seven dependent ones
+    constexpr int kSlices = 8;
+    for (int b0 = 0; b0 < nb; b0 += kSlices * kSortThreads) {
+        int vals[kSlices];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int y = __shfl_up(x, o, 64);
-            if (lane >= o) x += y;
+        for (int j = 0; j < kSlices; ++j) {
+            const int i = b0 + j * kSortThreads + tid;
+            vals[j] = row[i < nb ? i : nb - 1];
         }
-        if (lane == 63) s_wave[wid] = x;
-        __syncthreads();
-        int wb = 0;
-        for (int w = 0; w < wid; ++w) wb += s_wave[w];
-        const int carry = s_carry;
-        if (i < nb) row[i] = carry + wb + x - v;
-        __syncthreads();
-        if (tid == kSortThreads - 1) s_carry = carry + wb + x;
-        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kSlices; ++j) {
+            const int i = b0 + j * kSortThreads + tid;
+            if (b0 + j * kSortThreads >= nb) break;              // block-uniform
+            const int v = i < nb ? vals[j] : 0;
+            int x = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int y = __shfl_up(x, o, 64);
+                if (lane >= o) x += y;
+            }
+            if (lane == 63) s_wave[wid] = x;
+            __syncthreads();
+            int wb = 0;
+            for (int w = 0; w < wid; ++w) wb += s_wave[w];
+            const int carry = s_carry;
+            if (i < nb) row[i] = carry + wb + x - v;
+            __syncthreads();
+            if (tid == kSortThreads - 1) s_carry = carry + wb + x;
+            __syncthreads();
+        }
     }
     if (tid == 0) digit_tot[blockIdx.x] = s_carry;
 }
