@@ -42,10 +42,18 @@ sort_hist_kernel(const KeyT* __restrict__ keys, const int* __restrict__ n_dev, i
 #pragma unroll
     for (int w = 0; w < kSortWaves; ++w) s_hist[w][tid] = 0;
     __syncthreads();
+    // all KPT keys requested together (unconditional, clamped index), then counted: a load under `if (i < n)`
+    // followed by its use is one dependent round trip per key
+    KeyT key[KPT];
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {
         const long long i = base + k * kSortThreads + tid;
-        if (i < n) atomicAdd(&s_hist[wid][digit_of<KeyT>(keys[i], shift, mask)], 1);
+        key[k] = keys[i < n ? i : (long long)n - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        const long long i = base + k * kSortThreads + tid;
+        if (i < n) atomicAdd(&s_hist[wid][digit_of<KeyT>(key[k], shift, mask)], 1);
     }
     __syncthreads();
     int tot = 0;
