@@ -96,16 +96,19 @@ __device__ __forceinline__ bool quadrant_may_touch(const CullGauss& g, int i, in
 }
 // per-quadrant survivor masks of the 64 staged Gaussians (one per lane).  NQ = 4: the whole tile;
 // NQ = 1: only quadrant q0 (a wave that owns one 8x8 quadrant of a tile, see composite_fwd_kernel)
+// q0 carries the quadrant of a one-quadrant wave in bits 0-1 and, in bit 2, the test hook "do not cull" (every
+// staged Gaussian reaches the per-pixel code; results must not change -- tests/test_gpu_parity.py)
 template <int NQ>
 __device__ __forceinline__ void quadrant_masks(bool present, const float4& r0, const float4& r1, float tau, float ox,
                                                float oy, int q0, u64* mq) {
     const CullGauss g = cull_setup(r0, r1, tau, ox, oy);
+    const bool keep_all = (q0 >> 2) & 1;
     bool k[NQ];
     if constexpr (NQ == 4) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) k[q] = present & quadrant_may_touch(g, q & 1, q >> 1);
+        for (int q = 0; q < 4; ++q) k[q] = present & (keep_all | quadrant_may_touch(g, q & 1, q >> 1));
     } else {
-        k[0] = present & quadrant_may_touch(g, q0 & 1, q0 >> 1);
+        k[0] = present & (keep_all | quadrant_may_touch(g, q0 & 1, (q0 >> 1) & 1));
     }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) mq[q] = __ballot(k[q]);
@@ -166,11 +169,12 @@ __device__ __forceinline__ void fwd_quadrant(f2 pq, f2 XY, f2 AC, float B, float
 // One wave composites either a whole 16x16 tile (NQ = 4: four pixels per lane, one per 8x8 quadrant) or a
 // single quadrant q0 of it (NQ = 1: one pixel per lane).
 template <int CH, int NQ>
-__device__ __forceinline__ void fwd_tile(int tile, int q0, int C, const float4* __restrict__ splats,
+__device__ __forceinline__ void fwd_tile(int tile, int qf, int C, const float4* __restrict__ splats,
                                          const int* __restrict__ flatten_ids, const int* __restrict__ offsets, int width,
                                          int height, int tile_w, int tile_h, const float* __restrict__ backgrounds,
                                          float* __restrict__ render, float* __restrict__ alpha_out,
                                          int* __restrict__ last_ids) {
+    const int q0 = qf & 3;                               // bit 2 of qf: culling off (test hook)
     const int n_tiles = tile_w * tile_h;
     const int cam = tile / n_tiles;
     const int t_in = tile - cam * n_tiles;
@@ -227,7 +231,7 @@ __device__ __forceinline__ void fwd_tile(int tile, int q0, int C, const float4* 
     for (int b = 0; b < nb && !all_done; ++b) {
         // ---- stage this lane's Gaussian: cull per quadrant, pre-scale the conic by -log2(e) ----
         u64 mq[NQ];
-        quadrant_masks<NQ>(present, r0, r1, r2.z, ox, oy, q0, mq);
+        quadrant_masks<NQ>(present, r0, r1, r2.z, ox, oy, qf, mq);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) mq[q] = done[q] == ~0ull ? 0ull : uniform_u64(mq[q]);
         u64 km = or_masks(mq);
@@ -332,16 +336,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QED_K6_
 composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __restrict__ flatten_ids,
                      const int* __restrict__ offsets, int width, int height, int tile_w, int tile_h,
                      const float* __restrict__ backgrounds, float* __restrict__ render, float* __restrict__ alpha_out,
-                     int* __restrict__ last_ids, int n_big) {
+                     int* __restrict__ last_ids, int n_big_flags) {
     const int n_total = C * tile_w * tile_h;
     const int b = blockIdx.x;
+    const int keep_all = (n_big_flags >> 30) << 2;      // test hook, see quadrant_masks
+    const int n_big = n_big_flags & 0x3fffffff;
     if (b < n_big) {
-        fwd_tile<CH, 4>(xcd_remap(b, n_total), 0, C, splats, flatten_ids, offsets, width, height, tile_w, tile_h,
+        fwd_tile<CH, 4>(xcd_remap(b, n_total), keep_all, C, splats, flatten_ids, offsets, width, height, tile_w, tile_h,
                         backgrounds, render, alpha_out, last_ids);
     } else {
         int t, q;
         small_wave(b - n_big, n_total - n_big, t, q);
-        fwd_tile<CH, 1>(xcd_remap(n_big + t, n_total), q, C, splats, flatten_ids, offsets, width, height,
+        fwd_tile<CH, 1>(xcd_remap(n_big + t, n_total), q | keep_all, C, splats, flatten_ids, offsets, width, height,
                         tile_w, tile_h, backgrounds, render, alpha_out, last_ids);
     }
 }
@@ -436,12 +442,13 @@ __device__ __forceinline__ void bwd_quadrant(f2 pq, f2 XY, f2 AC, float B, float
 // Values 4, 6 and 7 are accumulated un-scaled (sum v_sigma dx^2, sum v_sigma dy^2, sum v_sigma) and
 // scaled by 0.5, 0.5 and -1/opacity once per (tile, Gaussian) at flush time.
 template <int CH, int NQ>
-__device__ __forceinline__ void bwd_tile(int tile, int q0, float (*s_acc)[12], int C, const float4* __restrict__ splats,
+__device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_acc)[12], int C, const float4* __restrict__ splats,
                                          const int* __restrict__ flatten_ids, const int* __restrict__ offsets, int width,
                                          int height, int tile_w, int tile_h, const float* __restrict__ backgrounds,
                                          const float* __restrict__ render_alpha, const int* __restrict__ last_ids,
                                          const float* __restrict__ v_render, const float* __restrict__ v_alpha,
                                          float* __restrict__ vsplat) {
+    const int q0 = qf & 3;                               // bit 2 of qf: culling off (test hook)
     const int n_tiles = tile_w * tile_h;
     const int cam = tile / n_tiles;
     const int t_in = tile - cam * n_tiles;
@@ -514,7 +521,7 @@ __device__ __forceinline__ void bwd_tile(int tile, int q0, float (*s_acc)[12], i
     for (int b = 0; b < nb; ++b) {
         const int batch_hi = eff_end - 1 - b * kBatch;            // sorted index gathered by lane 0
         u64 mq[NQ];
-        quadrant_masks<NQ>(present, r0, r1, r2.z, ox, oy, q0, mq);
+        quadrant_masks<NQ>(present, r0, r1, r2.z, ox, oy, qf, mq);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             mq[q] = uniform_u64(mq[q]);
@@ -604,17 +611,19 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
                      const int* __restrict__ offsets, int width, int height, int tile_w, int tile_h,
                      const float* __restrict__ backgrounds, const float* __restrict__ render_alpha,
                      const int* __restrict__ last_ids, const float* __restrict__ v_render,
-                     const float* __restrict__ v_alpha, float* __restrict__ vsplat, int n_big) {
+                     const float* __restrict__ v_alpha, float* __restrict__ vsplat, int n_big_flags) {
     __shared__ float s_acc[kBatch][12];
     const int n_total = C * tile_w * tile_h;
     const int b = blockIdx.x;
+    const int keep_all = (n_big_flags >> 30) << 2;
+    const int n_big = n_big_flags & 0x3fffffff;
     if (b < n_big) {
-        bwd_tile<CH, 4>(xcd_remap(b, n_total), 0, s_acc, C, splats, flatten_ids, offsets, width, height, tile_w, tile_h,
+        bwd_tile<CH, 4>(xcd_remap(b, n_total), keep_all, s_acc, C, splats, flatten_ids, offsets, width, height, tile_w, tile_h,
                         backgrounds, render_alpha, last_ids, v_render, v_alpha, vsplat);
     } else {
         int t, q;
         small_wave(b - n_big, n_total - n_big, t, q);
-        bwd_tile<CH, 1>(xcd_remap(n_big + t, n_total), q, s_acc, C, splats, flatten_ids, offsets, width, height,
+        bwd_tile<CH, 1>(xcd_remap(n_big + t, n_total), q | keep_all, s_acc, C, splats, flatten_ids, offsets, width, height,
                         tile_w, tile_h, backgrounds, render_alpha, last_ids, v_render, v_alpha, vsplat);
     }
 }
@@ -647,6 +656,12 @@ static long long big_tiles(long long n_tiles, double small_waves_per_slot, int w
     return n_tiles > n_small ? n_tiles - n_small : 0;
 }
 
+// test hook: QED_COMPOSITE_NOCULL=1 turns the quadrant culling off (bit 30 of the kernels' n_big argument)
+static int no_cull_flag() {
+    const char* e = getenv("QED_COMPOSITE_NOCULL");
+    return (e && e[0] == '1') ? (1 << 30) : 0;
+}
+
 extern "C" int qed_composite_fwd(int32_t C, int32_t N, const float* splats, const int32_t* flatten_ids,
                                  const int32_t* offsets, int32_t width, int32_t height, int32_t tile_w,
                                  int32_t tile_h, int32_t channels, const float* backgrounds, float* render,
@@ -666,11 +681,11 @@ extern "C" int qed_composite_fwd(int32_t C, int32_t N, const float* splats, cons
     if (channels == 4)
         hipLaunchKernelGGL(composite_fwd_kernel<4>, dim3(blocks), dim3(64), 0, st, C, (const float4*)splats,
                            flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render, alpha, last_ids,
-                           (int)n_big);
+                           (int)n_big | no_cull_flag());
     else
         hipLaunchKernelGGL(composite_fwd_kernel<3>, dim3(blocks), dim3(64), 0, st, C, (const float4*)splats,
                            flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render, alpha, last_ids,
-                           (int)n_big);
+                           (int)n_big | no_cull_flag());
     return check_launch("qed_composite_fwd");
 }
 
@@ -694,10 +709,10 @@ extern "C" int qed_composite_bwd(int32_t C, int32_t N, const float* splats, cons
     if (channels == 4)
         hipLaunchKernelGGL(composite_bwd_kernel<4>, dim3(blocks), dim3(64), 0, st, C, (const float4*)splats,
                            flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render_alpha, last_ids,
-                           v_render, v_alpha, vsplat, (int)n_big);
+                           v_render, v_alpha, vsplat, (int)n_big | no_cull_flag());
     else
         hipLaunchKernelGGL(composite_bwd_kernel<3>, dim3(blocks), dim3(64), 0, st, C, (const float4*)splats,
                            flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render_alpha, last_ids,
-                           v_render, v_alpha, vsplat, (int)n_big);
+                           v_render, v_alpha, vsplat, (int)n_big | no_cull_flag());
     return check_launch("qed_composite_bwd");
 }

@@ -198,6 +198,41 @@ def test_composite_launch_shapes_agree_with_oracle_and_each_other(cuda, monkeypa
     assert torch.equal(r2, r0) and torch.equal(a2, a0)
 
 
+@pytest.mark.parametrize("waves", ["tile", "quadrant"])
+def test_quadrant_culling_never_changes_a_result(cuda, monkeypatch, waves):
+    """The compositing kernels skip (Gaussian, 8x8 quadrant) pairs whose bound says no pixel can reach alpha >= 1/255.
+    QED_COMPOSITE_NOCULL=1 sends every staged Gaussian through the per-pixel code instead: images, alphas and last
+    ids must be bit-identical (a culled pair is one every pixel would have skipped), gradients equal up to the
+    order of the atomic sums."""
+    from qed_splatter_amd.model import get_viewmat
+    from qed_splatter_amd.rasterization import rasterization
+    w, h, n = 216, 120, 9000
+    sc = scene(n, w, h, seed=33)
+    sc["scales"] = sc["scales"] + 0.8                              # larger splats: more partially covered quadrants
+    ps = {k: sc[k].to(cuda).requires_grad_(True) for k in PARAM_NAMES}
+    g = torch.Generator().manual_seed(6)
+    wr = torch.rand(1, h, w, 4, generator=g).to(cuda)
+    wa = torch.rand(1, h, w, 1, generator=g).to(cuda)
+    monkeypatch.setenv("QED_COMPOSITE_WAVES", waves)
+
+    def run(nocull):
+        monkeypatch.setenv("QED_COMPOSITE_NOCULL", "1" if nocull else "0")
+        render, alpha, info = rasterization(
+            means=ps["means"], quats=torch.nn.functional.normalize(ps["quats"], dim=-1), scales=ps["scales"].exp(),
+            opacities=torch.sigmoid(ps["opacities"]).squeeze(-1),
+            colors=torch.cat([ps["features_dc"][:, None, :], ps["features_rest"]], dim=1),
+            viewmats=get_viewmat(sc["camera_to_worlds"][:1].to(cuda)), Ks=sc["Ks"][:1].to(cuda), width=w, height=h,
+            render_mode="RGB+D", sh_degree=3, absgrad=True)
+        grads = torch.autograd.grad((render * wr).sum() + (alpha * wa).sum(), [ps[k] for k in PARAM_NAMES])
+        return render.detach(), alpha.detach(), grads
+
+    r0, a0, g0 = run(True)
+    r1, a1, g1 = run(False)
+    assert torch.equal(r1, r0) and torch.equal(a1, a0)
+    for k, x1, x0 in zip(PARAM_NAMES, g1, g0):
+        assert_close(x1, x0, 2e-5, f"culled vs unculled: grad {k}")
+
+
 def test_composite_early_termination_and_background(cuda):
     """Dense opaque scene: most pixels terminate early (T <= 1e-4); with a background colour."""
     w, h, n = 96, 80, 20000
