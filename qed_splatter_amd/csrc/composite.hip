@@ -5,18 +5,21 @@
 // Design (CDNA4-first, not a warp-32 translation):
 //   * ONE 64-lane wave per 16x16 tile.  Lane l owns four pixels, the same (l & 7, l >> 3) position
 //     in each of the tile's four 8x8 quadrants.  A workgroup is a single wave, so the kernel is
-//     wave-synchronous: no workgroup barriers, no inter-wave imbalance, early-out per tile.
-//   * The tile's run of the depth-sorted list is streamed in batches of 64: every lane gathers one
-//     48-byte splat record (three 16-byte loads) for the NEXT batch while the current batch is
-//     consumed.  Records never go through LDS: the current Gaussian's ten scalars are broadcast
-//     with v_readlane into SGPRs and enter the VALU as scalar operands.
-//   * Exact-conservative cull by ballot: each lane bounds the minimum of its Gaussian's quadratic
-//     form sigma over the tile's pixel-centre rectangle (convex: 0 if the mean is inside, else
-//     attained on an edge).  alpha >= 1/255 needs sigma <= ln(255 o), so a Gaussian whose bound
-//     exceeds that (plus an fp32 rounding margin) cannot pass the alpha test at any pixel of the
-//     tile.  A 64-bit ballot gives the survivors; the loop walks its set bits front to back with
-//     scalar instructions.  Results are identical to walking the whole list, but typically more
-//     than half of the 3-sigma-bounding-box list entries never reach the inner loop.
+//     wave-synchronous: no workgroup barriers, no inter-wave imbalance, early-out per tile.  The LAST
+//     tiles of a launch are dealt as four one-quadrant waves each (one pixel per lane): finer work
+//     items fill the end of the launch (see composite_fwd_kernel, big_tiles(), small_wave()).
+//   * The tile's run of the depth-sorted list is streamed in batches of 64 through a two-deep
+//     software pipeline: while batch b is composited, the 48-byte records (three 16-byte loads per
+//     lane) of b+1 and the ids of b+2 are in flight, every prefetch an unconditional load from a
+//     clamped index.  Records never go through LDS: the current Gaussian's ten scalars are
+//     broadcast with v_readlane into SGPRs and enter the VALU as scalar operands.
+//   * Exact-conservative cull by ballot, per 8x8 quadrant: each lane bounds the minimum of its
+//     Gaussian's quadratic form sigma over the quadrant's pixel-centre rectangle (convex: 0 if the
+//     mean is inside, else attained on an edge).  alpha >= 1/255 needs sigma <= ln(255 o), so a
+//     Gaussian whose bound exceeds that (plus an fp32 rounding margin) cannot pass the alpha test at
+//     any pixel of the quadrant.  64-bit ballots give one survivor mask per quadrant; the loop walks
+//     the set bits with scalar instructions.  Results are identical to walking the whole list
+//     (QED_COMPOSITE_NOCULL=1 does that: tested bit-identical), at 1.5-1.65x the speed.
 //   * The inner loop is branch-free: 4 independent pixel chains per lane; every predicate ("done",
 //     "accepted", "valid") is a 64-bit scalar mask fed straight to v_cndmask.  The conic is
 //     pre-scaled by -log2(e) at staging so the exponent is a bare v_exp_f32 of a 5-instruction
