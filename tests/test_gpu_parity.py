@@ -750,6 +750,41 @@ def test_adam_with_sh_gradients_rebuilt_in_the_optimiser_equals_plain_step(cuda,
     assert bool((o0.exp_avg[b[5]:] != 0).any()) == (min(model_step, 3) > 0)
 
 
+@pytest.mark.parametrize("cfg_degree,n", [(2, 1003), (1, 517)])
+def test_adam_with_sh_gradients_rebuilt_for_models_with_fewer_coefficient_rows(cuda, cfg_degree, n):
+    """qed_adam_step_sh with features_rest [N, 8, 3] / [N, 3, 3] (config sh_degree 2 / 1): row width, LDS size and
+    the float4 / scalar-edge split all depend on the row count."""
+    from qed_splatter_amd.model import FlatAdam, PinholeCameras, QEDSplatterModel, QEDSplatterModelConfig
+    w, h = 96, 64
+    sc = scene(n, w, h, seed=23)
+    rows = (cfg_degree + 1) ** 2 - 1
+    K = sc["Ks"][0]
+    cam = PinholeCameras(sc["camera_to_worlds"][:1].to(cuda), K[0, 0], K[1, 1], K[0, 2], K[1, 2], w, h)
+    batch = {"image": sc["gt_rgb"].to(cuda), "depth_image": sc["gt_depth"].to(cuda)}
+    runs = []
+    for fused in (False, True):
+        ps = {k: sc[k].to(cuda) for k in PARAM_NAMES}
+        ps["features_rest"] = ps["features_rest"][:, :rows].contiguous()
+        m = QEDSplatterModel(QEDSplatterModelConfig(sh_degree=cfg_degree, sh_degree_interval=1), **ps)
+        m.step = 100
+        opt = FlatAdam(m)
+        for _ in range(2):
+            for p in m.parameters():
+                p.grad = None
+            m.backward_fused(m.fused_loss(cam, batch, compact_sh_grad=fused))
+            opt.step(fused_sh=fused)
+        torch.cuda.synchronize()
+        runs.append((m, opt))
+    (m0, o0), (m1, o1) = runs
+    b = m0.group_begin
+    assert m0.flat_params.numel() == n * (14 + 3 * rows)
+    for name, x1, x0 in (("params", m1.flat_params, m0.flat_params), ("exp_avg", o1.exp_avg, o0.exp_avg),
+                         ("exp_avg_sq", o1.exp_avg_sq, o0.exp_avg_sq)):
+        assert_close(x1[b[4]:], x0[b[4]:], 1e-5, f"SH groups: {name}")
+        assert_close(x1[:b[4]], x0[:b[4]], 1e-5, f"geometry groups: {name}")
+    assert bool((o0.exp_avg[b[5]:] != 0).any())
+
+
 def test_adam_with_sh_gradients_from_several_views_equals_rebuild_then_step(cuda):
     """Data-parallel form: the views gathered by exchange_grads_compact(rebuild=False) feed qed_adam_step_sh
     directly == rebuilding the averaged coefficient gradients (qed_sh_grad_from_views) and the plain step."""
