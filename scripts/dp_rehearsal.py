@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Two-rank rehearsal of the data-parallel step on ONE GPU (gloo, both ranks on cuda:0):
 allreduce_and_step (chunked, pipelined) and exchange_grads_compact (geometry all-reduce + gathered colour
-gradients) must leave the same parameters as allreduce_flat_grad + step.
+gradients, rebuilt either before the optimiser or inside it) must leave the same parameters as
+allreduce_flat_grad + step.
 
     QED_BENCH_REHEARSE=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \\
         --master-port 29533 scripts/dp_rehearsal.py
@@ -29,7 +30,7 @@ names = ("means", "scales", "quats", "opacities", "features_dc", "features_rest"
 K = sc["Ks"][0]
 cam = PinholeCameras(sc["camera_to_worlds"][rank:rank + 1].to(dev), float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), w, h)
 batch = {"image": sc["gt_rgb"].to(dev), "depth_image": sc["gt_depth"].to(dev)}
-models = [QEDSplatterModel(QEDSplatterModelConfig(sh_degree_interval=1), **{k: sc[k].to(dev) for k in names}) for _ in range(3)]
+models = [QEDSplatterModel(QEDSplatterModelConfig(sh_degree_interval=1), **{k: sc[k].to(dev) for k in names}) for _ in range(4)]
 opts = [FlatAdam(m, means_schedule=FlatAdam.MEANS_SCHEDULE) for m in models]
 for m in models:
     m.step = 30000
@@ -37,15 +38,18 @@ for step in range(4):
     for i, (m, o) in enumerate(zip(models, opts)):
         for p in m.parameters():
             p.grad = None
-        m.backward_fused(m.fused_loss(cam, batch, compact_sh_grad=(i == 2)))
+        m.backward_fused(m.fused_loss(cam, batch, compact_sh_grad=(i >= 2)))
         if i == 0:
             allreduce_flat_grad(m, world)
             o.step()
         elif i == 1:
             allreduce_and_step(m, o, world, n_chunks=4)
-        else:
+        elif i == 2:
             exchange_grads_compact(m, world)
             o.step()
+        else:                                   # gathered views feed the optimiser directly (qed_adam_step_sh)
+            exchange_grads_compact(m, world, rebuild=False)
+            o.step(fused_sh=True)
 torch.cuda.synchronize()
 # the two models see gradients that differ in the last bits (atomic summation order in the compositing
 # backward), so "same" is up to that noise amplified by four Adam steps
@@ -54,7 +58,12 @@ gathered = [torch.empty_like(models[1].flat_params) for _ in range(world)]
 dist.all_gather(gathered, models[1].flat_params.detach())
 replicas = all(torch.equal(gathered[0], t) for t in gathered)
 same2 = bool(((models[0].flat_params - models[2].flat_params).abs() <= 1e-5 + 1e-4 * models[0].flat_params.abs()).all())
-print(f"rank {rank}: chunked == plain: {same}; compact exchange == plain: {same2}; replicas identical: {replicas}", flush=True)
-same = same and same2
+same3 = bool(((models[0].flat_params - models[3].flat_params).abs() <= 1e-5 + 1e-4 * models[0].flat_params.abs()).all())
+gathered3 = [torch.empty_like(models[3].flat_params) for _ in range(world)]
+dist.all_gather(gathered3, models[3].flat_params.detach())
+replicas = replicas and all(torch.equal(gathered3[0], t) for t in gathered3)
+print(f"rank {rank}: chunked == plain: {same}; compact exchange == plain: {same2}; views -> optimiser == plain: {same3}; "
+      f"replicas identical: {replicas}", flush=True)
+same = same and same2 and same3
 dist.destroy_process_group()
 sys.exit(0 if same and replicas else 1)
