@@ -8,7 +8,7 @@ static tensors: copy a new camera / ground truth into them before ``replay()``.
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, Optional
+from typing import Callable, Dict
 
 import torch
 

@@ -2,7 +2,6 @@
 the symbols include/qed_splat.h declares (no compute calls: there is no GPU here)."""
 from __future__ import annotations
 
-import ctypes
 import os
 import re
 import subprocess

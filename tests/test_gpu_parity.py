@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from oracle import splat_oracle as O
-from tests.util import PARAM_NAMES, REL_TOL, activated, assert_close, max_rel, scene, to_dev
+from tests.util import PARAM_NAMES, REL_TOL, activated, assert_close, scene, to_dev
 
 pytestmark = pytest.mark.gpu
 
