@@ -242,18 +242,23 @@ adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restric
     const AdamCoef co{beta1, beta2, eps, inv_bc1, inv_bc2_sqrt};
     auto upd = [&](float pp, float gg, float& mm, float& vv, float lr) { return adam_update(co, pp, gg, mm, vv, lr); };
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        // gradient and moments: read / written once per step -> non-temporal, so that they do not displace the
+        // parameters (re-read by the next projection pass) from the last-level cache
+        typedef float v4f __attribute__((ext_vector_type(4)));
         float4 pp = reinterpret_cast<float4*>(p)[i];
-        const float4 gg = reinterpret_cast<const float4*>(g)[i];
-        float4 mm = reinterpret_cast<float4*>(m)[i];
-        float4 vv = reinterpret_cast<float4*>(v)[i];
+        const v4f g4 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(g) + i);
+        const v4f m4 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(m) + i);
+        const v4f v4 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(v) + i);
+        const float4 gg = make_float4(g4.x, g4.y, g4.z, g4.w);
+        float4 mm = make_float4(m4.x, m4.y, m4.z, m4.w), vv = make_float4(v4.x, v4.y, v4.z, v4.w);
         const long long e = i << 2;
         pp.x = upd(pp.x, gg.x, mm.x, vv.x, lr_of(e));
         pp.y = upd(pp.y, gg.y, mm.y, vv.y, lr_of(e + 1));
         pp.z = upd(pp.z, gg.z, mm.z, vv.z, lr_of(e + 2));
         pp.w = upd(pp.w, gg.w, mm.w, vv.w, lr_of(e + 3));
         reinterpret_cast<float4*>(p)[i] = pp;
-        reinterpret_cast<float4*>(m)[i] = mm;
-        reinterpret_cast<float4*>(v)[i] = vv;
+        __builtin_nontemporal_store((v4f){mm.x, mm.y, mm.z, mm.w}, reinterpret_cast<v4f*>(m) + i);
+        __builtin_nontemporal_store((v4f){vv.x, vv.y, vv.z, vv.w}, reinterpret_cast<v4f*>(v) + i);
     }
     // tail (total not a multiple of 4)
     if (blockIdx.x == 0 && threadIdx.x < (total & 3)) {
@@ -284,16 +289,30 @@ __device__ __forceinline__ void adam_one(const AdamCoef& a, float* __restrict__ 
 
 __device__ __forceinline__ void adam_vec(const AdamCoef& a, float* __restrict__ p, float* __restrict__ m,
                                          float* __restrict__ v, long long e, const float4& gg, float lr) {
+    // The moments are touched once per step and by nobody else: non-temporal loads / stores keep them from
+    // displacing the parameters, which the next projection pass reads again, in the last-level cache.
+    typedef float v4f __attribute__((ext_vector_type(4)));
     float4 pp = *reinterpret_cast<float4*>(p + e);
+#ifndef QED_ADAM_TEMPORAL
+    const v4f m4 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(m + e));
+    const v4f v4 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(v + e));
+    float4 mm = make_float4(m4.x, m4.y, m4.z, m4.w), vv = make_float4(v4.x, v4.y, v4.z, v4.w);
+#else
     float4 mm = *reinterpret_cast<float4*>(m + e);
     float4 vv = *reinterpret_cast<float4*>(v + e);
+#endif
     pp.x = adam_update(a, pp.x, gg.x, mm.x, vv.x, lr);
     pp.y = adam_update(a, pp.y, gg.y, mm.y, vv.y, lr);
     pp.z = adam_update(a, pp.z, gg.z, mm.z, vv.z, lr);
     pp.w = adam_update(a, pp.w, gg.w, mm.w, vv.w, lr);
     *reinterpret_cast<float4*>(p + e) = pp;
+#ifndef QED_ADAM_TEMPORAL
+    __builtin_nontemporal_store((v4f){mm.x, mm.y, mm.z, mm.w}, reinterpret_cast<v4f*>(m + e));
+    __builtin_nontemporal_store((v4f){vv.x, vv.y, vv.z, vv.w}, reinterpret_cast<v4f*>(v + e));
+#else
     *reinterpret_cast<float4*>(m + e) = mm;
     *reinterpret_cast<float4*>(v + e) = vv;
+#endif
 }
 
 // Adam over elements [lo, hi) by one workgroup: float4 over the 16-byte aligned interior, the <= 3 + 3 elements
