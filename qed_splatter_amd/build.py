@@ -31,10 +31,13 @@ def _stale(out: Path, deps) -> bool:
     return any(Path(d).stat().st_mtime > t for d in deps)
 
 
-def build_lib(force: bool = False, verbose: bool = False) -> Path:
+def build_lib(force: bool = False, verbose: bool = False, variant: str = "", extra_flags=()) -> Path:
+    """``variant`` / ``extra_flags``: a development build beside the product library (objects under
+    build/<variant>/, library lib/libqed_splat_<variant>.so; select it with QED_SPLAT_LIB=...)."""
     LIB_DIR.mkdir(exist_ok=True)
-    obj_dir = PKG / "build"
-    obj_dir.mkdir(exist_ok=True)
+    obj_dir = PKG / "build" / variant if variant else PKG / "build"
+    obj_dir.mkdir(exist_ok=True, parents=True)
+    lib_path = LIB_DIR / f"libqed_splat_{variant}.so" if variant else LIB_PATH
     headers = [CSRC / "qed_common.h", PKG.parent / "include" / "qed_splat.h"]
     objs = []
     procs = []
@@ -43,7 +46,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> Path:
         o = obj_dir / (Path(src).stem + ".o")
         objs.append(o)
         if force or _stale(o, [s, *headers]):
-            cmd = [HIPCC, *FLAGS, "-c", str(s), "-o", str(o)]
+            cmd = [HIPCC, *FLAGS, *extra_flags, "-c", str(s), "-o", str(o)]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -57,13 +60,17 @@ def build_lib(force: bool = False, verbose: bool = False) -> Path:
             print(out)
     if failed:
         raise RuntimeError("hipcc failed; see messages above")
-    if force or procs or _stale(LIB_PATH, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB_PATH), *map(str, objs)]
+    if force or procs or _stale(lib_path, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib_path), *map(str, objs)]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-    return LIB_PATH
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build_lib(force="--force" in sys.argv, verbose=True))
+    # python -m qed_splatter_amd.build [--force] [--variant NAME -DFLAG ...]
+    argv = sys.argv[1:]
+    variant = argv[argv.index("--variant") + 1] if "--variant" in argv else ""
+    print(build_lib(force="--force" in argv, verbose=True, variant=variant,
+                    extra_flags=[a for a in argv if a.startswith("-D") or a.startswith("-m")]))

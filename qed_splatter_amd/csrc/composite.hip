@@ -38,6 +38,15 @@ typedef unsigned long long u64;
 constexpr int kBatch = 64;
 constexpr float kLog2e = 1.4426950408889634f;
 
+// Diagnostic build only (-DQED_COMPOSITE_STATS; scripts/composite_stats.py): how much work each stage of the
+// compositing kernels really does.  Wave-uniform counts, added by lane 0.
+#ifdef QED_COMPOSITE_STATS
+__device__ unsigned long long g_stats[32];
+#define QED_STAT(i, n) do { if (threadIdx.x == 0) atomicAdd(&g_stats[i], (unsigned long long)(n)); } while (0)
+#else
+#define QED_STAT(i, n) do { } while (0)
+#endif
+
 // per-lane select by a wave-uniform 64-bit mask held in an SGPR pair: bit set -> a, else b
 __device__ __forceinline__ float sel(u64 m, float a, float b) {
     float d;
@@ -157,6 +166,7 @@ __device__ __forceinline__ void fwd_quadrant(f2 pq, f2 XY, f2 AC, float B, float
     const u64 m_term = m_ok & __ballot(nT <= kTMin);
     done |= m_term;
     const u64 m_acc = m_ok & ~m_term;
+    QED_STAT(5, __builtin_popcountll(m_acc));
     const float w = sel(m_acc, at, 0.f);
     const f2 ww = {w, w};
     s.out01 += col01 * ww;
@@ -238,6 +248,7 @@ __device__ __forceinline__ void fwd_tile(int tile, int qf, int C, const float4* 
 #pragma unroll
         for (int q = 0; q < NQ; ++q) mq[q] = done[q] == ~0ull ? 0ull : uniform_u64(mq[q]);
         u64 km = or_masks(mq);
+        QED_STAT(0, 1); QED_STAT(1, min(kBatch, end - (start + b * kBatch))); QED_STAT(2, __builtin_popcountll(km));
         const float gx = r0.x, gy = r0.y;
         const float gA = -0.5f * kLog2e * r0.z, gB = -kLog2e * r0.w, gC = -0.5f * kLog2e * r1.x;
         const float gop = r1.y, gr = r1.z, gg = r1.w, gb = r2.x, gd = r2.y;
@@ -256,11 +267,13 @@ __device__ __forceinline__ void fwd_tile(int tile, int qf, int C, const float4* 
             const float B = bcast(gB, t), op = bcast(gop, t);
             const f2 col01 = {bcast(gr, t), bcast(gg, t)};
             const f2 col23 = {bcast(gb, t), CH == 4 ? bcast(gd, t) : 0.f};
+            QED_STAT(4, 1);
             int idx_v;                                  // one VGPR copy per Gaussian, not per quadrant
             asm volatile("v_mov_b32 %0, %1" : "=v"(idx_v) : "s"(batch_start + t));
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 if (!(mq[q] & bit)) continue;           // wave-uniform: this quadrant cannot see Gaussian t
+                QED_STAT(3, 1);
                 fwd_quadrant<CH>(pq[q], XY, AC, B, op, col01, col23, idx_v, done[q], px[q]);
                 if (done[q] == ~0ull) {                 // quadrant finished: drop it from the masks
                     mq[q] = 0;
@@ -412,6 +425,7 @@ __device__ __forceinline__ void bwd_quadrant(f2 pq, f2 XY, f2 AC, float B, float
     const float a = fminf(kAlphaMax, opv);
     const u64 m_valid = __ballot(s.bin_final >= idx) & __ballot(p <= 0.f) & __ballot(a >= kAlphaMin);
     any_valid |= m_valid;
+    QED_STAT(14, __builtin_popcountll(m_valid));
     // branch-free: an invalid pixel contributes zeros and keeps its state
     const float ra = __builtin_amdgcn_rcpf(1.f - a);
     const float Tn = sel(m_valid, s.T * ra, s.T);
@@ -536,6 +550,8 @@ __device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_acc)[12], i
         u64 km = 0;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) km |= mq[q];
+        QED_STAT(8, 1); QED_STAT(9, min(kBatch, batch_hi + 1 - start)); QED_STAT(10, __builtin_popcountll(km));
+        QED_STAT(NQ == 4 ? 16 : 17, b == 0 ? 1 : 0);
         const float gx = r0.x, gy = r0.y, gca = r0.z, gcb = r0.w, gcc = r1.x;
         const float gop = r1.y, gr = r1.z, gg = r1.w, gb = r2.x, gd = r2.y;
         const int gid = rid;
@@ -562,9 +578,11 @@ __device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_acc)[12], i
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 if (!(mq[q] & bit)) continue;           // wave-uniform: this quadrant cannot see Gaussian t
+                QED_STAT(11, 1);
                 bwd_quadrant<CH>(pq[q], XY, AC, B, op, cab, cbc, col01, col23, idx, px[q], any_valid, g);
             }
             if (any_valid == 0) continue;
+            QED_STAT(12, 1);
             const float gv[12] = {g.vxy.x, g.vxy.y, g.ax, g.ay, g.c01.x, g.c01.y, g.c2, g.s0,
                                   g.rg.x, g.rg.y, g.bd.x, g.bd.y};
             float w[3];
@@ -582,6 +600,7 @@ __device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_acc)[12], i
         __syncthreads();                                // single wave: orders the LDS parking vs the flush
         // flush: 16 lanes per Gaussian, 4 Gaussians per instruction -> one 64-byte row per request
         while (touched) {
+            QED_STAT(13, 1);
             int ts[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -634,6 +653,19 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
 }  // namespace qed
 
 using namespace qed;
+
+#ifdef QED_COMPOSITE_STATS
+// diagnostic build only: copy the 32 counters to the host (synchronises) and optionally clear them
+extern "C" int qed_debug_composite_stats(unsigned long long* out, int reset) {
+    (void)hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stats), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[32] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 // Number of leading tiles (in dispatch order) composited by whole-tile waves; the rest get one wave per
 // quadrant.  The quadrant waves are there to fill the end of the launch: their number is a multiple of the

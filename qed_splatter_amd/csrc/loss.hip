@@ -131,20 +131,22 @@ loss_grad_kernel(int n_pix, const float* __restrict__ render, const float* __res
         const PixelEval p = eval_pixel<CH>(render, alpha, bg, i);
         float vr[4] = {0.f, 0.f, 0.f, 0.f};
         float va = 0.f;
+        // the parent's loss multiplies BOTH images by the mask before L1 and SSIM (SplatfactoModel.get_loss_dict,
+        // behind model.py:83-85); the depth term does the same at model.py:93-97
+        const float m = mask ? mask[i] : 1.f;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const float diff = p.rgb[k] - gt_rgb[3 * i + k];
+            const float diff = p.rgb[k] * m - gt_rgb[3 * i + k] * m;
             l1 += fabsf(diff);
             const float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
             const bool pass = p.pre[k] >= 0.f && p.pre[k] <= 1.f;     // torch.clamp backward (inclusive)
-            // v_rgb_extra: gradient of an additional term on the same clamped colour (SSIM, ssim.hip)
-            const float g_in = w_rgb * sg + (v_rgb_extra ? v_rgb_extra[3 * i + k] : 0.f);
+            // v_rgb_extra: gradient of an additional term w.r.t. the same (unmasked) clamped colour (SSIM, ssim.hip)
+            const float g_in = w_rgb * sg * m + (v_rgb_extra ? v_rgb_extra[3 * i + k] : 0.f);
             const float g = pass ? g_in : 0.f;
             vr[k] = g;
             va -= g * bg[k];
         }
         if constexpr (CH == 4) {
-            const float m = mask ? mask[i] : 1.f;
             const float dg = gt_depth[i] * m;
             const float dsel = p.a > 0.f ? p.d_render : dmax;          // model.py:306
             const float dp = dsel * m;
@@ -180,7 +182,8 @@ loss_finalize_kernel(int n_pix, int n_blocks, int has_depth, float* __restrict__
                      float extra_scale, float extra_offset) {
     float nv = 0.f, dm = -3.0e38f, tl = 0.f, td = 0.f;
     for (int b = threadIdx.x; b < n_blocks; b += 256) {
-        if (has_depth) { nv += loss_part(sums, 0)[b]; dm = fmaxf(dm, loss_part(sums, 1)[b]); }
+        if (has_depth) nv += loss_part(sums, 0)[b];                      // has_depth < 0: a valid count but no max row
+        if (has_depth > 0) dm = fmaxf(dm, loss_part(sums, 1)[b]);
         tl += loss_part(sums, 2)[b];
         td += loss_part(sums, 3)[b];
     }
@@ -195,11 +198,148 @@ loss_finalize_kernel(int n_pix, int n_blocks, int has_depth, float* __restrict__
         const float nvalid = s[0][0] + s[0][1] + s[0][2] + s[0][3];
         const float dmax = fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3]));
         const float tot_l1 = s[2][0] + s[2][1] + s[2][2] + s[2][3], tot_d = s[3][0] + s[3][1] + s[3][2] + s[3][3];
-        sums[0] = tot_l1; sums[1] = tot_d; sums[2] = nvalid; sums[3] = has_depth ? dmax : 0.f;
+        sums[0] = tot_l1; sums[1] = tot_d; sums[2] = nvalid; sums[3] = has_depth > 0 ? dmax : 0.f;
         losses[0] = rgb_weight * tot_l1 / (3.f * (float)n_pix);
         if (extra_sum != nullptr) losses[0] += extra_offset + extra_scale * extra_sum[0];
         losses[1] = nvalid > 0.f ? depth_lambda * tot_d / nvalid : 0.f;       // empty -> 0.0 (model.py:111-114)
         losses[2] = losses[0] + losses[1];
+    }
+}
+
+
+// =====================================================================================================
+// The same arithmetic split the way the reference's call sequence splits it: get_outputs() returns rgb /
+// depth images (model.py:295-297, 304-306), get_loss_dict() turns them into two scalar losses (the parent's
+// main loss behind model.py:83-85 and the depth term of :87-116) that the trainer sums and differentiates.
+// Each half is one autograd node on the host side (qed_splatter_amd/model.py: _PostProcess, _ImageLosses).
+// =====================================================================================================
+
+// per-workgroup maxima of the rendered depth channel -> part[blockIdx.x]
+__global__ void __launch_bounds__(256)
+post_max_kernel(int n_pix, const float* __restrict__ render, float* __restrict__ part) {
+    float dmax = -3.0e38f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n_pix; i += (size_t)gridDim.x * 256)
+        dmax = fmaxf(dmax, render[4 * i + 3]);
+    dmax = wave_max(dmax);
+    __shared__ float s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = dmax;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+}
+
+// rgb = clamp(render[..., :3] + (1 - alpha) bg, 0, 1); depth = alpha > 0 ? render[..., 3] : max(render[..., 3])
+template <int CH>
+__global__ void __launch_bounds__(256)
+post_fwd_kernel(int n_pix, const float* __restrict__ render, const float* __restrict__ alpha,
+                const float* __restrict__ bg, const float* __restrict__ part, int n_part, float* __restrict__ rgb,
+                float* __restrict__ depth) {
+    float dmax = 0.f;
+    if constexpr (CH == 4) {
+        __shared__ float s[4];
+        float dm = -3.0e38f;
+        for (int b = threadIdx.x; b < n_part; b += 256) dm = fmaxf(dm, part[b]);
+        dm = wave_max(dm);
+        if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = dm;
+        __syncthreads();
+        dmax = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+    }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n_pix; i += (size_t)gridDim.x * 256) {
+        const PixelEval p = eval_pixel<CH>(render, alpha, bg, i);
+        rgb[3 * i] = p.rgb[0]; rgb[3 * i + 1] = p.rgb[1]; rgb[3 * i + 2] = p.rgb[2];
+        if constexpr (CH == 4) depth[i] = p.a > 0.f ? p.d_render : dmax;
+    }
+}
+
+// backward of the above: v_rgb[H,W,3], v_depth[H,W] (either may be NULL = no gradient) -> v_render, v_alpha
+template <int CH>
+__global__ void __launch_bounds__(256)
+post_bwd_kernel(int n_pix, const float* __restrict__ render, const float* __restrict__ alpha,
+                const float* __restrict__ bg, const float* __restrict__ v_rgb, const float* __restrict__ v_depth,
+                float* __restrict__ v_render, float* __restrict__ v_alpha) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n_pix; i += (size_t)gridDim.x * 256) {
+        const PixelEval p = eval_pixel<CH>(render, alpha, bg, i);
+        float vr[4] = {0.f, 0.f, 0.f, 0.f}, va = 0.f;
+        if (v_rgb != nullptr) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const bool pass = p.pre[k] >= 0.f && p.pre[k] <= 1.f;     // torch.clamp backward (inclusive)
+                const float g = pass ? v_rgb[3 * i + k] : 0.f;
+                vr[k] = g;
+                va -= g * bg[k];
+            }
+        }
+        if constexpr (CH == 4) {
+            // the max of model.py:306 is detached: pixels with alpha == 0 pass no depth gradient
+            if (v_depth != nullptr && p.a > 0.f) vr[3] = v_depth[i];
+            *reinterpret_cast<float4*>(v_render + 4 * i) = make_float4(vr[0], vr[1], vr[2], vr[3]);
+        } else {
+            v_render[3 * i] = vr[0]; v_render[3 * i + 1] = vr[1]; v_render[3 * i + 2] = vr[2];
+        }
+        v_alpha[i] = va;
+    }
+}
+
+// get_loss_dict on images: per-workgroup partials of sum |m rgb - m gt| (row 2), sum |m d - m dgt| over valid pixels
+// (row 3) and their number (row 0)
+__global__ void __launch_bounds__(256)
+image_loss_reduce_kernel(int n_pix, const float* __restrict__ rgb, const float* __restrict__ depth,
+                         const float* __restrict__ gt_rgb, const float* __restrict__ gt_depth,
+                         const float* __restrict__ mask, float* __restrict__ sums) {
+    float l1 = 0.f, dsum = 0.f, nv = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n_pix; i += (size_t)gridDim.x * 256) {
+        const float m = mask ? mask[i] : 1.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) l1 += fabsf(rgb[3 * i + k] * m - gt_rgb[3 * i + k] * m);
+        if (depth != nullptr) {
+            const float dp = depth[i] * m, dg = gt_depth[i] * m;
+            if (isfinite(dp) && isfinite(dg) && dg > 0.f) { dsum += fabsf(dp - dg); nv += 1.f; }
+        }
+    }
+    l1 = wave_sum(l1); dsum = wave_sum(dsum); nv = wave_sum(nv);
+    __shared__ float s[3][4];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s[0][w] = l1; s[1][w] = dsum; s[2][w] = nv; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        loss_part(sums, 2)[blockIdx.x] = s[0][0] + s[0][1] + s[0][2] + s[0][3];
+        loss_part(sums, 3)[blockIdx.x] = s[1][0] + s[1][1] + s[1][2] + s[1][3];
+        loss_part(sums, 0)[blockIdx.x] = s[2][0] + s[2][1] + s[2][2] + s[2][3];
+    }
+}
+
+// gradients of the two losses w.r.t. the images, each scaled by its upstream gradient (device scalars: the trainer
+// sums the loss dict and calls backward, and may weight or scale the terms).  v_rgb holds the SSIM part on entry
+// when `accumulate` (qed_ssim_bwd, already scaled) and receives the L1 part on top.
+__global__ void __launch_bounds__(256)
+image_loss_grad_kernel(int n_pix, const float* __restrict__ rgb, const float* __restrict__ depth,
+                       const float* __restrict__ gt_rgb, const float* __restrict__ gt_depth,
+                       const float* __restrict__ mask, const float* __restrict__ sums, float rgb_weight,
+                       float depth_lambda, const float* __restrict__ g_main, const float* __restrict__ g_depth,
+                       int accumulate, float* __restrict__ v_rgb, float* __restrict__ v_depth) {
+    const float gm = g_main ? g_main[0] : 0.f, gd = g_depth ? g_depth[0] : 0.f;
+    const float w_rgb = gm * rgb_weight / (3.f * (float)n_pix);
+    const float nvalid = sums[2];
+    const float w_d = nvalid > 0.f ? gd * depth_lambda / nvalid : 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n_pix; i += (size_t)gridDim.x * 256) {
+        const float m = mask ? mask[i] : 1.f;
+        if (v_rgb != nullptr) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float diff = rgb[3 * i + k] * m - gt_rgb[3 * i + k] * m;
+                const float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+                const float g = w_rgb * sg * m;
+                v_rgb[3 * i + k] = accumulate ? v_rgb[3 * i + k] + g : g;
+            }
+        }
+        if (v_depth != nullptr) {
+            const float dp = depth[i] * m, dg = gt_depth[i] * m;
+            float g = 0.f;
+            if (isfinite(dp) && isfinite(dg) && dg > 0.f) {
+                const float diff = dp - dg;
+                g = w_d * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) * m;
+            }
+            v_depth[i] = g;
+        }
     }
 }
 
@@ -500,6 +640,73 @@ extern "C" int qed_loss_grad(int32_t n_pix, int32_t channels, const float* rende
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, n_pix, (int)grid, channels == 4 ? 1 : 0, sums_rw,
                        rgb_weight, depth_lambda, losses, extra_sum, extra_scale, extra_offset);
     return check_launch("qed_loss_grad");
+}
+
+
+extern "C" int qed_post_process_fwd(int32_t n_pix, int32_t channels, const float* render, const float* alpha,
+                                    const float* background, float* rgb, float* depth, float* workspace,
+                                    void* stream) {
+    QED_REQUIRE(n_pix > 0 && (channels == 3 || channels == 4), "bad arguments");
+    QED_REQUIRE(render && alpha && background && rgb, "null buffers");
+    QED_REQUIRE(channels == 3 || (depth && workspace), "depth output and workspace required with a depth channel");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = reduce_grid(n_pix);
+    if (channels == 4) {
+        hipLaunchKernelGGL(post_max_kernel, dim3(grid), dim3(256), 0, st, n_pix, render, workspace);
+        hipLaunchKernelGGL(post_fwd_kernel<4>, dim3(stream_grid(n_pix)), dim3(256), 0, st, n_pix, render, alpha,
+                           background, workspace, (int)grid, rgb, depth);
+    } else {
+        hipLaunchKernelGGL(post_fwd_kernel<3>, dim3(stream_grid(n_pix)), dim3(256), 0, st, n_pix, render, alpha,
+                           background, workspace, 0, rgb, depth);
+    }
+    return check_launch("qed_post_process_fwd");
+}
+
+extern "C" int qed_post_process_bwd(int32_t n_pix, int32_t channels, const float* render, const float* alpha,
+                                    const float* background, const float* v_rgb, const float* v_depth,
+                                    float* v_render, float* v_alpha, void* stream) {
+    QED_REQUIRE(n_pix > 0 && (channels == 3 || channels == 4), "bad arguments");
+    QED_REQUIRE(render && alpha && background && v_render && v_alpha, "null buffers");
+    hipStream_t st = (hipStream_t)stream;
+    if (channels == 4)
+        hipLaunchKernelGGL(post_bwd_kernel<4>, dim3(stream_grid(n_pix)), dim3(256), 0, st, n_pix, render, alpha,
+                           background, v_rgb, v_depth, v_render, v_alpha);
+    else
+        hipLaunchKernelGGL(post_bwd_kernel<3>, dim3(stream_grid(n_pix)), dim3(256), 0, st, n_pix, render, alpha,
+                           background, v_rgb, v_depth, v_render, v_alpha);
+    return check_launch("qed_post_process_bwd");
+}
+
+extern "C" int qed_image_losses_fwd(int32_t n_pix, const float* rgb, const float* depth, const float* gt_rgb,
+                                    const float* gt_depth, const float* mask, float rgb_weight, float depth_lambda,
+                                    const float* extra_sum, float extra_scale, float extra_offset, float* sums,
+                                    float* losses, void* stream) {
+    QED_REQUIRE(n_pix > 0, "bad arguments");
+    QED_REQUIRE(rgb && gt_rgb && sums && losses, "null buffers");
+    QED_REQUIRE(depth == nullptr || gt_depth, "gt_depth required with a depth image");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = reduce_grid(n_pix);
+    hipLaunchKernelGGL(image_loss_reduce_kernel, dim3(grid), dim3(256), 0, st, n_pix, rgb, depth, gt_rgb, gt_depth, mask,
+                       sums);
+    // has_depth = -1: fold row 0 (the valid count) but no row of maxima
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, n_pix, (int)grid, -1, sums, rgb_weight,
+                       depth_lambda, losses, extra_sum, extra_scale, extra_offset);
+    return check_launch("qed_image_losses_fwd");
+}
+
+extern "C" int qed_image_losses_bwd(int32_t n_pix, const float* rgb, const float* depth, const float* gt_rgb,
+                                    const float* gt_depth, const float* mask, const float* sums, float rgb_weight,
+                                    float depth_lambda, const float* g_main, const float* g_depth,
+                                    int32_t accumulate, float* v_rgb, float* v_depth, void* stream) {
+    QED_REQUIRE(n_pix > 0, "bad arguments");
+    QED_REQUIRE(rgb && gt_rgb && sums, "null buffers");
+    QED_REQUIRE(v_depth == nullptr || (depth && gt_depth), "depth images required for a depth gradient");
+    QED_REQUIRE(!accumulate || v_rgb, "accumulate needs v_rgb");
+    if (v_rgb == nullptr && v_depth == nullptr) return QED_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(image_loss_grad_kernel, dim3(stream_grid(n_pix)), dim3(256), 0, st, n_pix, rgb, depth, gt_rgb,
+                       gt_depth, mask, sums, rgb_weight, depth_lambda, g_main, g_depth, (int)accumulate, v_rgb, v_depth);
+    return check_launch("qed_image_losses_bwd");
 }
 
 static int adam_launch(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t n_groups,

@@ -78,14 +78,16 @@ __device__ __forceinline__ void read16(const float* __restrict__ p, float (&v)[1
     }
 }
 
-template <bool COMPOSITE, class T>
+// MASKED: both images are multiplied by mask[H,W] before the SSIM (the parent's loss does that to the rendered and
+// the ground-truth image when the batch holds a mask: SplatfactoModel.get_loss_dict behind model.py:83-85)
+template <bool COMPOSITE, bool MASKED, class T>
 #ifndef QED_SSIM_FWD_WAVES
 #define QED_SSIM_FWD_WAVES 4
 #endif
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QED_SSIM_FWD_WAVES, QED_SSIM_FWD_WAVES)))
 ssim_fwd_kernel(int H, int W, int channels, const float* __restrict__ pred, const float* __restrict__ alpha,
-                const float* __restrict__ bg, const float* __restrict__ gt, float* __restrict__ maps,
-                float* __restrict__ ssim_sum) {
+                const float* __restrict__ bg, const float* __restrict__ gt, const float* __restrict__ mask,
+                float* __restrict__ maps, float* __restrict__ ssim_sum) {
     constexpr int TW = T::TW, PW = T::PW, PH = T::PH, SP = T::SP, SH = T::SH, CB = T::CB;
     __shared__ __attribute__((aligned(16))) float s_x[PH * SP], s_y[PH * SP];
     __shared__ __attribute__((aligned(16))) float s_h[4][PH * SH];
@@ -118,10 +120,13 @@ ssim_fwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
         Float3 graw[T::LOADS];
         float4 praw[T::LOADS];
         float araw[T::LOADS];
+        float mraw[T::LOADS];
         size_t pix[T::LOADS];
 #pragma unroll
         for (int j = 0; j < T::LOADS; ++j)
             pix[j] = (size_t)min(oy + spy + T::RPP * j, H - 1) * W + min(ox + spx, W - 1);
+#pragma unroll
+        for (int j = 0; j < T::LOADS; ++j) mraw[j] = MASKED ? mask[pix[j]] : 1.f;
         if (COMPOSITE && channels == 4) {
 #pragma unroll
             for (int j = 0; j < T::LOADS; ++j) {
@@ -149,8 +154,8 @@ ssim_fwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const float c = COMPOSITE ? fminf(fmaxf(r[k] + om * bgc[k], 0.f), 1.f) : r[k];
-                xs[j][k] = in ? c : 0.f;
-                ys[j][k] = in ? g[k] : 0.f;
+                xs[j][k] = in ? (MASKED ? c * mraw[j] : c) : 0.f;
+                ys[j][k] = in ? (MASKED ? g[k] * mraw[j] : g[k]) : 0.f;
             }
         }
     }
@@ -232,12 +237,14 @@ ssim_fwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
     if (tid == 0) atomicAdd(ssim_sum, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
 }
 
-// v_pred[H,W,3] = scale * d(sum of the SSIM map)/d pred
-template <bool COMPOSITE, class T>
+// v_pred[H,W,3] = scale * (scale_dev ? scale_dev[0] : 1) * d(sum of the SSIM map)/d pred, pred = the colour BEFORE the
+// mask multiply (MASKED: x = m pred, y = m gt entered the SSIM, so the chain rule adds one factor m)
+template <bool COMPOSITE, bool MASKED, class T>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, const float* __restrict__ alpha,
-                const float* __restrict__ bg, const float* __restrict__ gt, const float* __restrict__ maps,
-                float scale, float* __restrict__ v_pred) {
+                const float* __restrict__ bg, const float* __restrict__ gt, const float* __restrict__ mask,
+                const float* __restrict__ maps, float scale, const float* __restrict__ scale_dev,
+                float* __restrict__ v_pred) {
     constexpr int TW = T::TW, PW = T::PW, PH = T::PH, SP = T::SP, SH = T::SH, CB = T::CB;
     __shared__ __attribute__((aligned(16))) float s_m[3][PH * SP];
     __shared__ __attribute__((aligned(16))) float s_h[3][PH * SH];
@@ -255,7 +262,11 @@ ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
     const bool stager = tid < T::RPP * PW;
     const int tx = tid % TW, ty0 = (tid / TW) * CB;
     const int ix = ox + tx;
+    if (scale_dev != nullptr) scale *= scale_dev[0];
     float r0[CB], r1[CB];            // channels 0 and 1 wait for channel 2: one 12-byte store per pixel
+    float mo[CB];
+#pragma unroll
+    for (int o = 0; o < CB; ++o) mo[o] = MASKED ? mask[(size_t)min(oy + ty0 + o, H - 1) * W + min(ix, W - 1)] : 1.f;
 #pragma unroll 1
     for (int k = 0; k < 3; ++k) {
         const float* m = maps + (size_t)k * 3 * n_out;
@@ -277,6 +288,7 @@ ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
             const size_t pix = (size_t)min(oy + ty0 + o, H - 1) * W + min(ix, W - 1);
             xo[o] = pred_at<COMPOSITE>(pred, alpha, bg, channels, pix, k);
             yo[o] = gt[pix * 3 + k];
+            if constexpr (MASKED) { xo[o] *= mo[o]; yo[o] *= mo[o]; }
         }
         __syncthreads();
         if (stager) {
@@ -315,7 +327,8 @@ ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
         }
 #pragma unroll
         for (int o = 0; o < CB; ++o) {
-            const float r = scale * (g[0][o] + 2.f * xo[o] * g[1][o] + yo[o] * g[2][o]);
+            float r = scale * (g[0][o] + 2.f * xo[o] * g[1][o] + yo[o] * g[2][o]);
+            if constexpr (MASKED) r *= mo[o];
             if (k == 0) r0[o] = r;
             else if (k == 1) r1[o] = r;
             else {
@@ -342,36 +355,36 @@ extern "C" int64_t qed_ssim_maps_floats(int32_t height, int32_t width) {
 }
 
 extern "C" int qed_ssim_fwd(int32_t height, int32_t width, int32_t channels, const float* pred, const float* alpha,
-                            const float* background, const float* gt_rgb, float* maps, float* ssim_sum,
-                            void* stream) {
+                            const float* background, const float* gt_rgb, const float* mask, float* maps,
+                            float* ssim_sum, void* stream) {
     QED_REQUIRE(height > kHalo && width > kHalo, "image smaller than the 11 x 11 SSIM window");
     QED_REQUIRE(pred && gt_rgb && maps && ssim_sum, "null buffers");
     QED_REQUIRE(alpha == nullptr || (background && (channels == 3 || channels == 4)), "composite mode needs a background");
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(ssim_sum, 0, sizeof(float), st) != hipSuccess) { set_error("qed_ssim_fwd: memset failed"); return QED_E_LAUNCH; }
     const dim3 grid(((width - kHalo + Tile::TW - 1) / Tile::TW) * ((height - kHalo + Tile::TH - 1) / Tile::TH));
-    if (alpha != nullptr)
-        hipLaunchKernelGGL((ssim_fwd_kernel<true, Tile>), grid, dim3(256), 0, st, height, width, channels, pred, alpha,
-                           background, gt_rgb, maps, ssim_sum);
-    else
-        hipLaunchKernelGGL((ssim_fwd_kernel<false, Tile>), grid, dim3(256), 0, st, height, width, 3, pred, alpha,
-                           background, gt_rgb, maps, ssim_sum);
+#define QED_SSIM_FWD(COMP, MASK, CHN)                                                                               \
+    hipLaunchKernelGGL((ssim_fwd_kernel<COMP, MASK, Tile>), grid, dim3(256), 0, st, height, width, CHN, pred, alpha,   \
+                       background, gt_rgb, mask, maps, ssim_sum)
+    if (alpha != nullptr) { if (mask) QED_SSIM_FWD(true, true, channels); else QED_SSIM_FWD(true, false, channels); }
+    else { if (mask) QED_SSIM_FWD(false, true, 3); else QED_SSIM_FWD(false, false, 3); }
+#undef QED_SSIM_FWD
     return check_launch("qed_ssim_fwd");
 }
 
 extern "C" int qed_ssim_bwd(int32_t height, int32_t width, int32_t channels, const float* pred, const float* alpha,
-                            const float* background, const float* gt_rgb, const float* maps, float scale,
-                            float* v_pred, void* stream) {
+                            const float* background, const float* gt_rgb, const float* mask, const float* maps,
+                            float scale, const float* scale_dev, float* v_pred, void* stream) {
     QED_REQUIRE(height > kHalo && width > kHalo, "image smaller than the 11 x 11 SSIM window");
     QED_REQUIRE(pred && gt_rgb && maps && v_pred, "null buffers");
     QED_REQUIRE(alpha == nullptr || (background && (channels == 3 || channels == 4)), "composite mode needs a background");
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(((width + Tile::TW - 1) / Tile::TW) * ((height + Tile::TH - 1) / Tile::TH));
-    if (alpha != nullptr)
-        hipLaunchKernelGGL((ssim_bwd_kernel<true, Tile>), grid, dim3(256), 0, st, height, width, channels, pred, alpha,
-                           background, gt_rgb, maps, scale, v_pred);
-    else
-        hipLaunchKernelGGL((ssim_bwd_kernel<false, Tile>), grid, dim3(256), 0, st, height, width, 3, pred, alpha,
-                           background, gt_rgb, maps, scale, v_pred);
+#define QED_SSIM_BWD(COMP, MASK, CHN)                                                                               \
+    hipLaunchKernelGGL((ssim_bwd_kernel<COMP, MASK, Tile>), grid, dim3(256), 0, st, height, width, CHN, pred, alpha,   \
+                       background, gt_rgb, mask, maps, scale, scale_dev, v_pred)
+    if (alpha != nullptr) { if (mask) QED_SSIM_BWD(true, true, channels); else QED_SSIM_BWD(true, false, channels); }
+    else { if (mask) QED_SSIM_BWD(false, true, 3); else QED_SSIM_BWD(false, false, 3); }
+#undef QED_SSIM_BWD
     return check_launch("qed_ssim_bwd");
 }
