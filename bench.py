@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-api-path", action="store_true", help="skip timing the reference-shaped eager route")
     ap.add_argument("--cpu-sample-div", type=int, default=4, help="CPU sample = config / div^2 (area and N)")
     ap.add_argument("--sync-m", action="store_true", help="read the intersection count back every step")
     ap.add_argument("--graph", dest="graph", action="store_true", default=None,
@@ -103,6 +104,60 @@ def cpu_baseline(args):
     }
 
 
+def api_path_ms(args, sc, dev, optimizer: str) -> float:
+    """ms per training step through the REFERENCE's own call sequence, eager dispatch, same scene and same steps
+    (W warm-up + K timed from the initial parameters) as the headline number:
+
+        zero_grad -> get_outputs(camera) -> get_metrics_dict -> get_loss_dict -> sum(loss_dict) -> backward ->
+        one optimiser per parameter group (config.py:44-68) stepped in turn -> the means' ExponentialDecay scheduler
+
+    (/root/reference/qed_splatter/model.py:199-321, 120-197, 73-118 driven by Nerfstudio's Trainer.train_iteration).
+    ``optimizer``: "qed" = QedAdam (a torch.optim.Optimizer subclass AdamOptimizerConfig._target can name; the six
+    instances share one fused launch), "torch" = six torch.optim.Adam exactly as the reference configures them."""
+    import functools
+    from qed_splatter_amd.model import (FlatAdam, PinholeCameras, QEDSplatterModel, QEDSplatterModelConfig, QedAdam,
+                                        exponential_decay_lr)
+    n, w, h = args.gaussians, args.width, args.height
+    cfg = QEDSplatterModelConfig.synthetic(sh_degree=3, sh_degree_interval=1)
+    model = QEDSplatterModel(cfg, **{k: sc[k].clone() for k in ("means", "scales", "quats", "opacities", "features_dc",
+                                                                  "features_rest")})
+    model.step = 30000
+    model.train()
+    K = sc["Ks"][0].cpu()
+    cam = PinholeCameras(sc["camera_to_worlds"], float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), w, h)
+    batch = {"image": sc["gt_rgb"].contiguous(), "depth_image": sc["gt_depth"].contiguous()}
+    cls = QedAdam if optimizer == "qed" else torch.optim.Adam
+    lrs = FlatAdam.DEFAULT_LRS                                   # = config.py:44-68
+    opts = {k: cls([model.gauss_params[k]], lr=lrs[k], eps=1e-15) for k in
+            ("means", "features_dc", "features_rest", "opacities", "scales", "quats")}        # config.py's order
+    lr_final, max_steps = FlatAdam.MEANS_SCHEDULE
+    sched = torch.optim.lr_scheduler.LambdaLR(
+        opts["means"], lambda s: exponential_decay_lr(s, lrs["means"], lr_final, max_steps) / lrs["means"])
+
+    def step():
+        for o in opts.values():
+            o.zero_grad(set_to_none=True)
+        outputs = model.get_outputs(cam)
+        metrics = model.get_metrics_dict(outputs, batch)
+        loss_dict = model.get_loss_dict(outputs, batch, metrics)
+        functools.reduce(torch.add, loss_dict.values()).backward()
+        for o in opts.values():
+            o.step()
+        sched.step()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    del model, opts
+    torch.cuda.empty_cache()
+    return dt / args.steps * 1e3
+
+
 def launch_ranks(args) -> int:
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as FRESH child processes
     (one per GPU, torch.distributed.run over 127.0.0.1) before this process has made any GPU call, relay their
@@ -157,7 +212,7 @@ def main():
 
     n, w, h = args.gaussians, args.width, args.height
     sc = make_scene(n, w, h, rank, dev)
-    cfg = QEDSplatterModelConfig(sh_degree=3, sh_degree_interval=1)
+    cfg = QEDSplatterModelConfig.synthetic(sh_degree=3, sh_degree_interval=1)
     model = QEDSplatterModel(cfg, **{k: sc[k] for k in ("means", "scales", "quats", "opacities", "features_dc",
                                                          "features_rest")})
     model.step = 30000                       # full SH degree
@@ -435,6 +490,20 @@ def main():
             "roofline": roof,
         }
         log(f"timed region: {ms_step:.3f} ms/step")
+        if world == 1 and not args.no_api_path:
+            # the reference-shaped route, driver-timed in the same run (see api_path_ms)
+            api_qed = api_path_ms(args, sc, dev, "qed")
+            api_torch = api_path_ms(args, sc, dev, "torch")
+            out["api_path_ms_per_step"] = api_qed
+            out["api_path_torch_adam_ms_per_step"] = api_torch
+            out["api_path"] = {
+                "sequence": "zero_grad, get_outputs, get_metrics_dict, get_loss_dict, sum, backward, six per-group "
+                            "optimisers stepped in turn, means scheduler; eager dispatch; same scene, warm-up and steps",
+                "api_path_ms_per_step": "optimisers = QedAdam (torch.optim.Optimizer subclass; the six instances share "
+                                        "one fused launch)",
+                "api_path_torch_adam_ms_per_step": "optimisers = torch.optim.Adam as config.py:44-68 builds them",
+                "iters_per_s": 1e3 / api_qed}
+            log(f"reference-shaped route: {api_qed:.3f} ms/step (QedAdam), {api_torch:.3f} ms/step (torch.optim.Adam)")
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

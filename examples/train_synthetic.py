@@ -39,7 +39,7 @@ def main():
     K = sc["Ks"][0]
     cam = PinholeCameras(sc["camera_to_worlds"].to(dev), float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]),
                          a.width, a.height)
-    cfg = QEDSplatterModelConfig(sh_degree_interval=1)
+    cfg = QEDSplatterModelConfig.synthetic(sh_degree_interval=1)
     # ground truth = a render of the unperturbed scene
     gt_model = QEDSplatterModel(cfg, **{k: sc[k].to(dev) for k in NAMES})
     gt_model.step = 10_000

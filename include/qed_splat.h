@@ -196,7 +196,9 @@ int qed_composite_bwd(int32_t C, int32_t N, const float* splats, const int32_t* 
  * sums[0..3] = {sum|rgb-gt|, sum|d-dgt|, n_valid, max depth}); pass 2 (qed_loss_grad) writes v_render[H,W,channels] and v_alpha[H,W] for
  *   loss = rgb_weight * mean|rgb - gt| + depth_lambda * sum|d - dgt| / n_valid
  * and the scalar losses -> losses[0..2] = {rgb term, depth term, their sum}.  mask[H,W] may be
- * NULL (model.py:93-97).  An additional term on the same clamped colour (the SSIM part of the
+ * NULL; when given it multiplies the rendered AND the ground-truth image before the L1 (and the SSIM)
+ * term, as the parent's get_loss_dict does behind model.py:83-85, and both depths (model.py:93-97).
+ * An additional term on the same clamped colour (the SSIM part of the
  * parent's loss, qed_ssim_* below) enters through v_rgb_extra[H,W,3] = its gradient w.r.t. rgb and
  * extra_sum: losses[0] += extra_offset + extra_scale * extra_sum[0]; both pointers may be NULL. */
 int qed_loss_reduce(int32_t n_pix, int32_t channels, const float* render, const float* alpha,
@@ -215,13 +217,47 @@ int qed_loss_grad(int32_t n_pix, int32_t channels, const float* render, const fl
  * together with alpha[H,W] and background[3], in which case the colour clamp(render + (1-alpha) bg)
  * of model.py:296-297 is formed on the fly.  qed_ssim_fwd writes ssim_sum[0] = sum of the SSIM map
  * (SSIM = ssim_sum / (3 (H-10)(W-10))) and the coefficient maps (qed_ssim_maps_floats floats) that
- * qed_ssim_bwd turns into v_pred[H,W,3] = scale * d ssim_sum / d colour. */
+ * qed_ssim_bwd turns into v_pred[H,W,3] = scale * (scale_dev ? scale_dev[0] : 1) * d ssim_sum / d colour
+ * (scale_dev: an upstream gradient that lives in device memory).  mask[H,W] (may be NULL) multiplies
+ * both images before the SSIM, as the parent's loss does; v_pred is the gradient w.r.t. the colour
+ * BEFORE that multiply. */
 int64_t qed_ssim_maps_floats(int32_t height, int32_t width);
 int qed_ssim_fwd(int32_t height, int32_t width, int32_t channels, const float* pred, const float* alpha,
-                 const float* background, const float* gt_rgb, float* maps, float* ssim_sum, void* stream);
+                 const float* background, const float* gt_rgb, const float* mask, float* maps,
+                 float* ssim_sum, void* stream);
 int qed_ssim_bwd(int32_t height, int32_t width, int32_t channels, const float* pred, const float* alpha,
-                 const float* background, const float* gt_rgb, const float* maps, float scale,
-                 float* v_pred, void* stream);
+                 const float* background, const float* gt_rgb, const float* mask, const float* maps,
+                 float scale, const float* scale_dev, float* v_pred, void* stream);
+
+/* ---- the same arithmetic behind the reference's OWN call sequence --------------------------------
+ * get_outputs() returns images and get_loss_dict() turns them into a dict of scalar losses that the
+ * trainer sums and differentiates; each half is one autograd node on the host side.
+ *
+ * qed_post_process_fwd/bwd = model.py:295-297 + 304-306:
+ *   rgb[H,W,3] = clamp(render[..., :3] + (1 - alpha) background, 0, 1)
+ *   depth[H,W] = alpha > 0 ? render[..., 3] : max(render[..., 3])      (channels == 4; max is detached)
+ * workspace: QED_LOSS_SUMS_FLOATS floats.  bwd: v_rgb / v_depth (either may be NULL) -> v_render, v_alpha.
+ *
+ * qed_image_losses_fwd/bwd = the parent's main loss (behind model.py:83-85) + the depth term (:87-116):
+ *   losses[0] = rgb_weight * mean|m rgb - m gt| + extra_offset + extra_scale * extra_sum[0]
+ *   losses[1] = depth_lambda * sum|m d - m dgt| / n_valid   (finite & dgt > 0; 0 when nothing is valid)
+ * with extra_* the SSIM term (qed_ssim_fwd on the same images).  depth / gt_depth / mask may be NULL.
+ * sums: QED_LOSS_SUMS_FLOATS floats, kept for the backward.  bwd: v_rgb = g_main[0] * d losses[0] / d rgb
+ * (accumulate != 0: added to what qed_ssim_bwd left there), v_depth = g_depth[0] * d losses[1] / d depth;
+ * g_main / g_depth are DEVICE scalars (NULL = 0): the trainer may weight or scale each term. */
+int qed_post_process_fwd(int32_t n_pix, int32_t channels, const float* render, const float* alpha,
+                         const float* background, float* rgb, float* depth, float* workspace, void* stream);
+int qed_post_process_bwd(int32_t n_pix, int32_t channels, const float* render, const float* alpha,
+                         const float* background, const float* v_rgb, const float* v_depth,
+                         float* v_render, float* v_alpha, void* stream);
+int qed_image_losses_fwd(int32_t n_pix, const float* rgb, const float* depth, const float* gt_rgb,
+                         const float* gt_depth, const float* mask, float rgb_weight, float depth_lambda,
+                         const float* extra_sum, float extra_scale, float extra_offset, float* sums,
+                         float* losses, void* stream);
+int qed_image_losses_bwd(int32_t n_pix, const float* rgb, const float* depth, const float* gt_rgb,
+                         const float* gt_depth, const float* mask, const float* sums, float rgb_weight,
+                         float depth_lambda, const float* g_main, const float* g_depth, int32_t accumulate,
+                         float* v_rgb, float* v_depth, void* stream);
 
 /* ---- per-step evaluation metrics (model.py:120-197, metrics.py:84-156) ----------
  * One streaming pass, results left in DEVICE memory (the reference synchronises ~12 times per step

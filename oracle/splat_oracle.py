@@ -551,12 +551,38 @@ def rgb_metrics(pred: Tensor, gt: Tensor):
     return mse, 10.0 * torch.log10(1.0 / mse), ssim(pred, gt)
 
 
-def main_loss(rgb: Tensor, gt: Tensor, ssim_lambda: float = 0.2) -> Tensor:
-    """SplatfactoModel main loss: (1 - l) * L1 + l * (1 - SSIM)."""
+def main_loss(rgb: Tensor, gt: Tensor, ssim_lambda: float = 0.2, mask: Optional[Tensor] = None) -> Tensor:
+    """SplatfactoModel main loss (nerfstudio 1.1.x get_loss_dict, reached through super() at model.py:83-85):
+    (1 - l) * L1 + l * (1 - SSIM), with BOTH images multiplied by batch["mask"] [H,W,1] first when there is one
+    ("Set masked part of both ground-truth and rendered image to black")."""
+    if mask is not None:
+        m = mask.to(rgb.dtype).reshape(rgb.shape[0], rgb.shape[1], 1)
+        rgb, gt = rgb * m, gt.to(rgb.dtype) * m
     out = (1 - ssim_lambda) * rgb_l1_loss(rgb, gt)
     if ssim_lambda > 0:
         out = out + ssim_lambda * (1 - ssim(rgb, gt))
     return out
+
+
+def scale_reg(scales: Tensor, step: int, use_scale_regularization: bool = False, max_gauss_ratio: float = 10.0) -> Tensor:
+    """The parent's scale regulariser (same method): every 10th step, when enabled,
+    0.1 * mean(max(max_i exp(s_i) / min_i exp(s_i), max_gauss_ratio) - max_gauss_ratio); otherwise 0."""
+    if use_scale_regularization and step % 10 == 0:
+        e = torch.exp(scales)
+        r = e.amax(dim=-1) / e.amin(dim=-1)
+        return 0.1 * (torch.maximum(r, torch.tensor(max_gauss_ratio, dtype=r.dtype)) - max_gauss_ratio).mean()
+    return torch.zeros((), dtype=scales.dtype)
+
+
+def resize_image(image: Tensor, d: int) -> Tensor:
+    """The parent's resize_image (its _downscale_if_required / get_gt_img, called at model.py:88,91,94): d x d box
+    filter with stride d -- OpenCV's "area" downscaling; trailing rows / columns that do not fill a box are dropped."""
+    if d <= 1:
+        return image
+    H, W, C = image.shape
+    h, w = H // d, W // d
+    return image[:h * d, :w * d].to(torch.float64 if image.dtype == torch.float64 else torch.float32) \
+        .reshape(h, d, w, d, C).mean(dim=(1, 3))
 
 
 # ----------------------------------------------------------------------------------

@@ -51,8 +51,12 @@ SIGNATURES = {
     "qed_backproject_depth": (C.c_int, [_I, _I, _P, _F, _F, _F, _F, _P, _F, _I, _L, _P, _P, _P, _P, _P]),
     "qed_image_metrics": (C.c_int, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
     "qed_ssim_maps_floats": (C.c_int64, [_I, _I]),
-    "qed_ssim_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
-    "qed_ssim_bwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P]),
+    "qed_ssim_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "qed_ssim_bwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P]),
+    "qed_post_process_fwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "qed_post_process_bwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "qed_image_losses_fwd": (C.c_int, [_I, _P, _P, _P, _P, _P, _F, _F, _P, _F, _F, _P, _P, _P]),
+    "qed_image_losses_bwd": (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _I, _P, _P, _P]),
     "qed_adam_step": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _F, _F, _F, _I, _P]),
     "qed_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _F, _F, _F, _P, _P]),
     "qed_adam_step_sh": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _P, _F, _F, _F, _I, _P, _I, _F, _F, _I, _I, _I, _P, _I,

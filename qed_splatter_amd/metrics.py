@@ -64,7 +64,8 @@ def ssim_value(pred_rgb: Tensor, gt_rgb: Tensor) -> Tensor:
         raise L.QedSplatError("image smaller than the 11 x 11 SSIM window")
     maps = torch.empty(n_maps, dtype=torch.float32, device=p.device)
     ssum = torch.empty(1, dtype=torch.float32, device=p.device)
-    L.check(lib.qed_ssim_fwd(H, W, 3, L.ptr(p), None, None, L.ptr(g), L.ptr(maps), L.ptr(ssum), _stream()), "qed_ssim_fwd")
+    L.check(lib.qed_ssim_fwd(H, W, 3, L.ptr(p), None, None, L.ptr(g), None, L.ptr(maps), L.ptr(ssum), _stream()),
+            "qed_ssim_fwd")
     return ssum.view(()) / (3.0 * (H - 10) * (W - 10))
 
 

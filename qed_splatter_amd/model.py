@@ -22,6 +22,7 @@ Two ways to run a training step:
 from __future__ import annotations
 
 import math
+import weakref
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Union
 
@@ -65,13 +66,29 @@ class QEDSplatterModelConfig:
     sh_degree_interval: int = 1000
     rasterize_mode: str = "classic"
     use_bilateral_grid: bool = False
-    background_color: str = "black"          # "random" | "black" | "white"
-    ssim_lambda: float = 0.2                 # parent's main loss: (1-l) L1 + l (1-SSIM); SSIM is 8f "next"
-    num_downscales: int = 0
+    # the defaults below are SplatfactoModelConfig's (nerfstudio 1.1.x), which the reference's config.py:39-42 leaves
+    # untouched: random training background, two halvings of the resolution that end at steps 3000 / 6000
+    background_color: str = "random"         # "random" | "black" | "white"
+    ssim_lambda: float = 0.2                 # parent's main loss: (1-l) L1 + l (1-SSIM)
+    num_downscales: int = 2
     resolution_schedule: int = 3000
-    # fused_loss() only (not a reference field): list each Gaussian only in the tiles of its 3-sigma square
-    # where some pixel can reach alpha >= 1/255 (QED_F_TIGHT_TILES); same images and gradients, shorter lists
+    use_scale_regularization: bool = False
+    max_gauss_ratio: float = 10.0
+    # ---- not reference fields ----
+    # list each Gaussian only in the tiles of its 3-sigma square where some pixel can reach alpha >= 1/255
+    # (QED_F_TIGHT_TILES): same images and gradients, shorter lists; info["flatten_ids"] etc. become subsets
     tight_tile_lists: bool = True
+    # get_outputs(): after the first (calibrating) call do not read the intersection count back every step; a
+    # buffer overflow then makes the NEXT call raise (the frame in between rendered empty)
+    async_intersection_count: bool = True
+
+    @classmethod
+    def synthetic(cls, **kw) -> "QEDSplatterModelConfig":
+        """The configuration of the synthetic benchmark / parity scenes (fixed black background, full
+        resolution from step 0); every other field keeps the reference's default."""
+        kw.setdefault("background_color", "black")
+        kw.setdefault("num_downscales", 0)
+        return cls(**kw)
 
 
 class PinholeCameras:
@@ -122,6 +139,16 @@ class PinholeCameras:
 
 GROUP_ORDER = ("means", "scales", "quats", "opacities", "features_dc", "features_rest")
 
+_UNIT_GRADS: Dict = {}
+
+
+def _unit_grad(device) -> Tensor:
+    """One cached 0-dim tensor 1.0 per device: the seed gradient of backward_fused()."""
+    one = _UNIT_GRADS.get(device)
+    if one is None:
+        one = _UNIT_GRADS[device] = torch.ones((), dtype=torch.float32, device=device)
+    return one
+
 
 def _is_camera(obj) -> bool:
     return all(hasattr(obj, a) for a in ("camera_to_worlds", "get_intrinsics_matrices", "width", "height"))
@@ -141,8 +168,8 @@ class _SSIM(torch.autograd.Function):
             raise L.QedSplatError("qed_ssim_maps_floats: image smaller than the 11 x 11 SSIM window")
         maps = torch.empty(n_maps, dtype=torch.float32, device=pred.device)
         ssum = torch.empty(1, dtype=torch.float32, device=pred.device)
-        L.check(lib.qed_ssim_fwd(H, W, 3, L.ptr(pred), None, None, L.ptr(gt), L.ptr(maps), L.ptr(ssum), _stream()),
-                "qed_ssim_fwd")
+        L.check(lib.qed_ssim_fwd(H, W, 3, L.ptr(pred), None, None, L.ptr(gt), None, L.ptr(maps), L.ptr(ssum),
+                                 _stream()), "qed_ssim_fwd")
         ctx.save_for_backward(pred, gt, maps)
         return ssum.view(()) / (3.0 * (H - 10) * (W - 10))
 
@@ -151,15 +178,133 @@ class _SSIM(torch.autograd.Function):
         pred, gt, maps = ctx.saved_tensors
         H, W, _ = pred.shape
         v_pred = torch.empty_like(pred)
-        L.check(L.load().qed_ssim_bwd(H, W, 3, L.ptr(pred), None, None, L.ptr(gt), L.ptr(maps),
-                                      1.0 / (3.0 * (H - 10) * (W - 10)), L.ptr(v_pred), _stream()), "qed_ssim_bwd")
-        return v_pred * v, None
+        v = v.to(torch.float32).reshape(1).contiguous()            # upstream gradient, multiplied inside the kernel
+        L.check(L.load().qed_ssim_bwd(H, W, 3, L.ptr(pred), None, None, L.ptr(gt), None, L.ptr(maps),
+                                      1.0 / (3.0 * (H - 10) * (W - 10)), L.ptr(v), L.ptr(v_pred), _stream()),
+                "qed_ssim_bwd")
+        return v_pred, None
 
 
 def ssim(pred: Tensor, gt: Tensor) -> Tensor:
     """Mean SSIM of two float32 [H,W,3] images in [0,1] (differentiable in ``pred``)."""
     assert pred.dim() == 3 and pred.shape[-1] == 3 and pred.shape == gt.shape
     return _SSIM.apply(pred.to(torch.float32), gt.to(torch.float32))
+
+
+def _f32_image(t: Tensor, numel: int, what: str, dev) -> Tensor:
+    """A batch tensor as the kernels read it: float32, contiguous, on the model's device, ``numel`` elements
+    (bool masks and uint8 images are converted; anything of another size is refused before a launch)."""
+    if t.dtype == torch.uint8 and what != "mask":
+        t = t.float() / 255.0
+    t = t.to(device=dev, dtype=torch.float32).contiguous()
+    if t.numel() != numel:
+        raise L.QedSplatError(f"{what}: {tuple(t.shape)} holds {t.numel()} values, the render needs {numel}")
+    return t
+
+
+class _PostProcess(torch.autograd.Function):
+    """model.py:295-297 + 304-306 as ONE node: rgb = clamp(render[..., :3] + (1 - alpha) background, 0, 1) and
+    depth = where(alpha > 0, render[..., 3:4], render[..., 3:4].detach().max())."""
+
+    @staticmethod
+    def forward(ctx, render, alpha, background):
+        lib = L.load()
+        ctx.set_materialize_grads(False)
+        if not render.is_cuda:
+            raise L.QedSplatError("get_outputs needs GPU tensors: there is no CPU path in the product")
+        C, H, W, CH = render.shape
+        dev = render.device
+        render, alpha = render.contiguous(), alpha.contiguous()
+        background = background.to(torch.float32).contiguous()
+        rgb = torch.empty(C, H, W, 3, dtype=torch.float32, device=dev)
+        depth = torch.empty(C, H, W, 1, dtype=torch.float32, device=dev) if CH == 4 else None
+        ws = torch.empty(L.LOSS_SUMS_FLOATS, dtype=torch.float32, device=dev) if CH == 4 else None
+        L.check(lib.qed_post_process_fwd(C * H * W, CH, L.ptr(render), L.ptr(alpha), L.ptr(background), L.ptr(rgb),
+                                         L.ptr(depth), L.ptr(ws), _stream()), "qed_post_process_fwd")
+        ctx.save_for_backward(render, alpha, background)
+        if depth is None:
+            return rgb
+        return rgb, depth
+
+    @staticmethod
+    def backward(ctx, v_rgb, v_depth=None):
+        render, alpha, background = ctx.saved_tensors
+        C, H, W, CH = render.shape
+        if v_rgb is None and v_depth is None:
+            return None, None, None
+        v_rgb = v_rgb.to(torch.float32).contiguous() if v_rgb is not None else None
+        v_depth = v_depth.to(torch.float32).contiguous() if v_depth is not None else None
+        v_render = torch.empty_like(render)
+        v_alpha = torch.empty_like(alpha)
+        L.check(L.load().qed_post_process_bwd(C * H * W, CH, L.ptr(render), L.ptr(alpha), L.ptr(background), L.ptr(v_rgb),
+                                              L.ptr(v_depth), L.ptr(v_render), L.ptr(v_alpha), _stream()),
+                "qed_post_process_bwd")
+        return v_render, v_alpha, None
+
+
+class _ImageLosses(torch.autograd.Function):
+    """get_loss_dict on the images get_outputs returned: the parent's main loss (1 - l) L1 + l (1 - SSIM) with the
+    mask multiplied into both images (behind model.py:83-85) and the masked depth-L1 term (model.py:87-116), as two
+    scalars.  The trainer sums the loss dict and differentiates, possibly with weights or a GradScaler: the backward
+    multiplies each term's gradient by its upstream gradient, read from device memory."""
+
+    @staticmethod
+    def forward(ctx, rgb, depth, gt_rgb, gt_depth, mask, ssim_lambda, depth_lambda):
+        lib = L.load()
+        ctx.set_materialize_grads(False)
+        if not rgb.is_cuda:
+            raise L.QedSplatError("get_loss_dict needs GPU tensors: there is no CPU path in the product")
+        H, W, _ = rgb.shape
+        dev = rgb.device
+        n_pix = H * W
+        rgb = rgb.contiguous()
+        depth = depth.contiguous() if depth is not None else None
+        st = _stream()
+        sums = torch.empty(L.LOSS_SUMS_FLOATS, dtype=torch.float32, device=dev)
+        losses = torch.empty(3, dtype=torch.float32, device=dev)
+        maps = None
+        extra = (None, 0.0, 0.0)
+        if ssim_lambda > 0.0:
+            n_out = 3.0 * (H - 10) * (W - 10)
+            n_maps = lib.qed_ssim_maps_floats(H, W)
+            if n_maps < 0:
+                raise L.QedSplatError("image smaller than the 11 x 11 SSIM window")
+            maps = torch.empty(n_maps, dtype=torch.float32, device=dev)
+            ssum = torch.empty(1, dtype=torch.float32, device=dev)
+            L.check(lib.qed_ssim_fwd(H, W, 3, L.ptr(rgb), None, None, L.ptr(gt_rgb), L.ptr(mask), L.ptr(maps),
+                                     L.ptr(ssum), st), "qed_ssim_fwd")
+            extra = (L.ptr(ssum), -ssim_lambda / n_out, ssim_lambda)
+        L.check(lib.qed_image_losses_fwd(n_pix, L.ptr(rgb), L.ptr(depth), L.ptr(gt_rgb), L.ptr(gt_depth), L.ptr(mask),
+                                         1.0 - ssim_lambda, depth_lambda, *extra, L.ptr(sums), L.ptr(losses), st),
+                "qed_image_losses_fwd")
+        ctx.save_for_backward(rgb, depth, gt_rgb, gt_depth, mask, maps, sums)
+        ctx.lams = (float(ssim_lambda), float(depth_lambda))
+        return losses[0:1].view(()), losses[1:2].view(())
+
+    @staticmethod
+    def backward(ctx, g_main, g_depth):
+        lib = L.load()
+        rgb, depth, gt_rgb, gt_depth, mask, maps, sums = ctx.saved_tensors
+        ssim_lambda, depth_lambda = ctx.lams
+        H, W, _ = rgb.shape
+        st = _stream()
+
+        def scalar(g):
+            return None if g is None else g.to(torch.float32).reshape(1).contiguous()
+        g_main, g_depth = scalar(g_main), scalar(g_depth)
+        v_rgb = torch.empty_like(rgb) if (g_main is not None and ctx.needs_input_grad[0]) else None
+        v_depth = torch.empty_like(depth) if (g_depth is not None and depth is not None and ctx.needs_input_grad[1]) \
+            else None
+        acc = 0
+        if v_rgb is not None and ssim_lambda > 0.0:
+            n_out = 3.0 * (H - 10) * (W - 10)
+            L.check(lib.qed_ssim_bwd(H, W, 3, L.ptr(rgb), None, None, L.ptr(gt_rgb), L.ptr(mask), L.ptr(maps),
+                                     -ssim_lambda / n_out, L.ptr(g_main), L.ptr(v_rgb), st), "qed_ssim_bwd")
+            acc = 1
+        L.check(lib.qed_image_losses_bwd(H * W, L.ptr(rgb), L.ptr(depth), L.ptr(gt_rgb), L.ptr(gt_depth), L.ptr(mask),
+                                         L.ptr(sums), 1.0 - ssim_lambda, depth_lambda, L.ptr(g_main), L.ptr(g_depth), acc,
+                                         L.ptr(v_rgb), L.ptr(v_depth), st), "qed_image_losses_bwd")
+        return v_rgb, v_depth, None, None, None, None, None
 
 
 class _FusedImageLoss(torch.autograd.Function):
@@ -188,9 +333,10 @@ class _FusedImageLoss(torch.autograd.Function):
             v_rgb = torch.empty(H, W, 3, dtype=torch.float32, device=dev)
             ssum = torch.empty(1, dtype=torch.float32, device=dev)
             L.check(lib.qed_ssim_fwd(H, W, CH, L.ptr(render), L.ptr(alpha), L.ptr(background), L.ptr(gt_rgb),
-                                     L.ptr(maps), L.ptr(ssum), st), "qed_ssim_fwd")
+                                     L.ptr(mask), L.ptr(maps), L.ptr(ssum), st), "qed_ssim_fwd")
             L.check(lib.qed_ssim_bwd(H, W, CH, L.ptr(render), L.ptr(alpha), L.ptr(background), L.ptr(gt_rgb),
-                                     L.ptr(maps), -ssim_lambda / n_out, L.ptr(v_rgb), st), "qed_ssim_bwd")
+                                     L.ptr(mask), L.ptr(maps), -ssim_lambda / n_out, None, L.ptr(v_rgb), st),
+                    "qed_ssim_bwd")
             extra = (L.ptr(v_rgb), L.ptr(ssum), -ssim_lambda / n_out, ssim_lambda)
         args = (n_pix, CH, L.ptr(render), L.ptr(alpha), L.ptr(background), L.ptr(gt_rgb), L.ptr(gt_depth), L.ptr(mask))
         L.check(lib.qed_loss_reduce(*args, L.ptr(sums), st), "qed_loss_reduce")
@@ -207,7 +353,10 @@ class _FusedImageLoss(torch.autograd.Function):
         if v_total is None:
             return (None,) * 8
         v_render, v_alpha = ctx.saved_tensors
-        # the kernel wrote d(total)/d(render, alpha); the usual upstream gradient 1.0 needs no scaling pass
+        # the kernel wrote d(total)/d(render, alpha).  The usual upstream gradient is the cached unit tensor of
+        # backward_fused() and needs no scaling pass; anything else (a weighted loss, a GradScaler) is applied
+        if v_total.data_ptr() != _unit_grad(v_total.device).data_ptr():
+            v_render, v_alpha = v_render * v_total, v_alpha * v_total
         return v_render, v_alpha, None, None, None, None, None, None
 
 
@@ -308,24 +457,63 @@ class QEDSplatterModel(nn.Module):
     def get_param_groups(self) -> Dict[str, List[Tensor]]:
         return {n: [self.gauss_params[n]] for n in self.group_names}
 
-    # ---- inherited helpers model.py calls, minimal restatements ----
+    def _apply(self, fn, *args, **kwargs):
+        """model.to() / .cuda() / .float() replace every Parameter's data: gather the six groups into a fresh flat
+        buffer on the new device and re-create the Parameters as views of it (optimisers must be rebuilt, as after
+        any parameter replacement; FlatAdam / QedAdam detect a stale buffer and raise)."""
+        super()._apply(fn, *args, **kwargs)
+        ps = [self.gauss_params[n] for n in self.group_names]
+        if any(p.data_ptr() != self._flat.data_ptr() + 4 * b or p.device != self._flat.device
+               for p, b in zip(ps, self.group_begin)):
+            flat = torch.cat([p.detach().reshape(-1).to(torch.float32) for p in ps])
+            self.rebind_flat(flat, ps[0].shape[0])
+        return self
+
+    # ---- inherited helpers model.py calls (SURVEY a13): restatements of SplatfactoModel (nerfstudio 1.1.x) ----
     def _get_downscale_factor(self) -> int:
         if self.training:
             return 2 ** max(self.config.num_downscales - self.step // self.config.resolution_schedule, 0)
         return 1
 
+    def _downscale_if_required(self, image: Tensor) -> Tensor:
+        """The parent's resize_image: d x d box filter with stride d ("area" downscaling), float32."""
+        d = self._get_downscale_factor()
+        if d > 1:
+            image = image.to(torch.float32)
+            weight = torch.full((1, 1, d, d), 1.0 / (d * d), dtype=torch.float32, device=image.device)
+            return torch.nn.functional.conv2d(image.permute(2, 0, 1)[:, None, ...], weight, stride=d).squeeze(1).permute(1, 2, 0)
+        return image
+
     def _get_background_color(self) -> Tensor:
         dev = self.device
         if self.config.background_color == "random":
-            return torch.rand(3, device=dev) if self.training else torch.zeros(3, device=dev)
+            if self.training:
+                return torch.rand(3, device=dev)
+            # the parent's eval colour under "random" (populate_modules: self.background_color)
+            return torch.tensor([0.1490, 0.1647, 0.2157], device=dev)
         if self.config.background_color == "white":
             return torch.ones(3, device=dev)
         return torch.zeros(3, device=dev)
 
     def get_gt_img(self, image: Tensor) -> Tensor:
+        """uint8 -> float / 255, downscaled by the current factor, on the model's device (the parent's get_gt_img,
+        called at model.py:88,91,94)."""
         if image.dtype == torch.uint8:
             image = image.float() / 255.0
-        return image.to(self.device)
+        return self._downscale_if_required(image).to(self.device)
+
+    def composite_with_background(self, image: Tensor, background: Tensor) -> Tensor:
+        """RGBA ground truth composited onto the step's background (the parent does this to the GT image)."""
+        if image.shape[2] == 4:
+            alpha = image[..., -1].unsqueeze(-1).repeat((1, 1, 3))
+            return alpha * image[..., :3] + (1 - alpha) * background
+        return image
+
+    def _apply_bilateral_grid(self, rgb: Tensor, cam_idx: int, H: int, W: int) -> Tensor:
+        raise NotImplementedError(
+            "use_bilateral_grid: the bilateral grid lives in the Nerfstudio parent class (lib_bilagrid) and is out of "
+            "scope for this mirror (SURVEY a8); it is reached unchanged when the real QEDSplatterModel uses this "
+            "package's rasterization() (INTEGRATION.md)")
 
     def get_empty_outputs(self, width: int, height: int, background: Tensor) -> Dict[str, Tensor]:
         rgb = background.repeat(height, width, 1)
@@ -370,8 +558,18 @@ class QEDSplatterModel(nn.Module):
         BLOCK_WIDTH = 16                                                      # model.py:243
         camera_scale_fac = self._get_downscale_factor()
         camera.rescale_output_resolution(1 / camera_scale_fac)
-        viewmat = get_viewmat(optimized_camera_to_world)
-        K = camera.get_intrinsics_matrices().to(self.device)
+        intr = getattr(camera, "intrinsics_fxfycxcy", None)
+        if intr is not None and optimized_camera_to_world.dtype == torch.float32 \
+                and not optimized_camera_to_world.requires_grad and optimized_camera_to_world.is_cuda:
+            # get_viewmat + get_intrinsics_matrices in one launch (qed_camera_setup) instead of ~15 tiny eager ones
+            C = optimized_camera_to_world.shape[0]
+            viewmat = torch.empty(C, 4, 4, dtype=torch.float32, device=self.device)
+            K = torch.empty(C, 3, 3, dtype=torch.float32, device=self.device)
+            L.check(L.load().qed_camera_setup(C, L.ptr(optimized_camera_to_world.contiguous()), L.ptr(intr()),
+                                              L.ptr(viewmat), L.ptr(K), _stream()), "qed_camera_setup")
+        else:
+            viewmat = get_viewmat(optimized_camera_to_world)
+            K = camera.get_intrinsics_matrices().to(self.device)
         W, H = int(camera.width.item()), int(camera.height.item())
         self.last_size = (H, W)
         camera.rescale_output_resolution(camera_scale_fac)
@@ -384,6 +582,8 @@ class QEDSplatterModel(nn.Module):
             render_mode = "RGB"
 
         flags = L.F_LOG_SCALES | L.F_LOGIT_OPAC                               # exp / sigmoid fused (model.py:270-271)
+        if self.config.tight_tile_lists and W <= 16 * 1023 and H <= 16 * 2047:
+            flags |= L.F_TIGHT_TILES
         if self.config.sh_degree > 0:                                         # model.py:261-265
             sh_degree_to_use = min(self.step // self.config.sh_degree_interval, self.config.sh_degree)
             colors, sh_rest = features_dc_crop, features_rest_crop            # no torch.cat (model.py:241)
@@ -413,7 +613,9 @@ class QEDSplatterModel(nn.Module):
             rasterize_mode=self.config.rasterize_mode,
             _flags=flags,
             _sh_rest=sh_rest,
+            _sync=not (self.config.async_intersection_count and self.training),
         )
+        self.last_compact = False
         if self.training and self.info["means2d"].requires_grad:              # model.py:289-290
             self.info["means2d"].retain_grad()
         self.xys = self.info["means2d"]                                       # [1,N,2]
@@ -421,18 +623,17 @@ class QEDSplatterModel(nn.Module):
         alpha = alpha[:, ...]
 
         background = self._get_background_color()
-        rgb = render[:, ..., :3] + (1 - alpha) * background                   # model.py:296
-        rgb = torch.clamp(rgb, 0.0, 1.0)
+        # model.py:296-297 (composite + clamp) and :304-308 (depth fix-up) as one node with a fused backward
+        if render_mode == "RGB+D":
+            rgb, depth_im = _PostProcess.apply(render, alpha, background)
+            depth_im = depth_im.squeeze(0)
+        else:
+            rgb, depth_im = _PostProcess.apply(render, alpha, background), None
 
-        if self.config.use_bilateral_grid and self.training:                  # model.py:300-302 (pass-through)
+        if self.config.use_bilateral_grid and self.training:                  # model.py:300-302 (not built: raises)
             if getattr(camera, "metadata", None) is not None and "cam_idx" in camera.metadata:
                 rgb = self._apply_bilateral_grid(rgb, camera.metadata["cam_idx"], H, W)
 
-        if render_mode == "RGB+D":                                            # model.py:304-308
-            depth_im = render[:, ..., 3:4]
-            depth_im = torch.where(alpha > 0, depth_im, depth_im.detach().max()).squeeze(0)
-        else:
-            depth_im = None
         # model.py:310-311 `del render; torch.cuda.empty_cache()` is a per-call device sync +
         # allocator flush with no effect on results; deliberately not reproduced.
         self._last_render, self._last_alpha = render, alpha
@@ -447,37 +648,51 @@ class QEDSplatterModel(nn.Module):
         }
 
     # ---- a11: get_loss_dict (model.py:73-118) ----
-    def _parent_loss_dict(self, outputs, batch) -> Dict[str, Tensor]:
-        """SplatfactoModel's main loss (upstream of model.py:83-85):
-        (1 - ssim_lambda) * L1 + ssim_lambda * (1 - SSIM(gt, pred))."""
-        gt_img = self.get_gt_img(batch["image"])
-        Ll1 = torch.abs(gt_img - outputs["rgb"]).mean()
-        lam = self.config.ssim_lambda
-        main = (1 - lam) * Ll1
-        if lam > 0.0:
-            main = main + lam * (1 - ssim(outputs["rgb"], gt_img))
-        return {"main_loss": main}
+    def _scale_reg(self) -> Tensor:
+        """The parent's scale regulariser: 0 unless use_scale_regularization, then every 10th step
+        0.1 * mean(max(max_scale / min_scale, max_gauss_ratio) - max_gauss_ratio)."""
+        cfg = self.config
+        if cfg.use_scale_regularization and self.step % 10 == 0:
+            scale_exp = torch.exp(self.scales)
+            ratio = scale_exp.amax(dim=-1) / scale_exp.amin(dim=-1)
+            reg = torch.maximum(ratio, torch.tensor(cfg.max_gauss_ratio, device=ratio.device)) - cfg.max_gauss_ratio
+            return 0.1 * reg.mean()
+        zero = getattr(self, "_zero_loss", None)
+        if zero is None or zero.device != self.device:
+            zero = self._zero_loss = torch.tensor(0.0, device=self.device)
+        return zero
+
+    def _loss_mask(self, batch, shape) -> Optional[Tensor]:
+        """batch["mask"] [H,W,1] (bool or float; Nerfstudio's are bool) downscaled like the images, as float32."""
+        if "mask" not in batch:
+            return None
+        mask = batch["mask"]
+        if mask.dtype == torch.uint8:
+            raise TypeError("mask must be bool or floating point (a uint8 mask would scale the images by up to 255 in "
+                            "the parent's loss and by 1/255-steps in the depth term, model.py:91-97)")
+        mask = self._downscale_if_required(mask).to(self.device)
+        assert mask.shape[:2] == tuple(shape[:2]), f"mask {tuple(mask.shape)} vs image {tuple(shape)}"   # model.py:95
+        return mask.to(torch.float32).contiguous()
 
     def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, Tensor]:
-        loss_dict = self._parent_loss_dict(outputs, batch)                     # model.py:83-85
-        depth_out = outputs["depth"]
-        depth_batch = self.get_gt_img(batch["depth_image"])
+        """Same keys and values as the reference (model.py:73-118 on top of the parent's dict): main_loss =
+        (1 - l) L1 + l (1 - SSIM) of the masked images, scale_reg, depth_loss = depth_lambda * masked depth-L1
+        (0.0 when no pixel is valid, model.py:111-114).  One fused node instead of ~30 eager launches with boolean
+        gathers; each entry stays separately differentiable (the trainer sums and may weight them)."""
+        cfg = self.config
         pred_img = outputs["rgb"]
-        gt_img = self.get_gt_img(batch["image"])
-        if "mask" in batch:                                                    # model.py:93-97
-            mask = self.get_gt_img(batch["mask"])
-            assert mask.shape[:2] == gt_img.shape[:2] == pred_img.shape[:2]
-            depth_out = depth_out * mask
-            depth_batch = depth_batch * mask
-        valid_mask = torch.isfinite(depth_out) & torch.isfinite(depth_batch) & (depth_batch > 0.0)
-        valid_depth_out = depth_out[valid_mask]
-        valid_depth_batch = depth_batch[valid_mask]
-        if valid_depth_out.numel() > 0:                                        # model.py:111-114
-            loss = torch.abs(valid_depth_out - valid_depth_batch).mean()
-        else:
-            loss = torch.tensor(0.0, device=depth_out.device)
-        loss_dict["depth_loss"] = self.config.depth_lambda * loss             # model.py:116
-        return loss_dict
+        depth_out = outputs["depth"]
+        if depth_out is None:
+            raise TypeError("get_loss_dict needs outputs['depth'] (the reference fails the same way with "
+                            "output_depth_during_training=False, model.py:87,101)")
+        H, W = pred_img.shape[:2]
+        gt_img = self.composite_with_background(self.get_gt_img(batch["image"]), outputs["background"])
+        mask = self._loss_mask(batch, pred_img.shape)
+        gt_img = _f32_image(gt_img[..., :3] if gt_img.shape[-1] > 3 else gt_img, H * W * 3, "batch['image']", self.device)
+        depth_batch = _f32_image(self.get_gt_img(batch["depth_image"]), H * W, "batch['depth_image']", self.device)
+        main, depth = _ImageLosses.apply(pred_img, depth_out, gt_img, depth_batch, mask, float(cfg.ssim_lambda),
+                                         float(cfg.depth_lambda))
+        return {"main_loss": main, "scale_reg": self._scale_reg(), "depth_loss": depth}
 
     # ---- get_metrics_dict (model.py:120-197; SURVEY 8f rank 4) ----
     def get_metrics_dict(self, outputs, batch) -> Dict[str, Tensor]:
@@ -508,10 +723,7 @@ class QEDSplatterModel(nn.Module):
     def backward_fused(self, losses: Dict[str, Tensor]) -> None:
         """``losses["loss"].backward()`` without the per-step ``ones_like`` fill autograd would launch for the
         seed gradient (the fused loss kernel has already written d loss / d render for a seed of 1)."""
-        one = getattr(self, "_unit_grad", None)
-        if one is None or one.device != losses["loss"].device:
-            one = self._unit_grad = torch.ones((), dtype=torch.float32, device=losses["loss"].device)
-        losses["loss"].backward(gradient=one)
+        losses["loss"].backward(gradient=_unit_grad(losses["loss"].device))
 
     # ---- fused training step: model.py:199-321 + 73-118 in as few passes as possible ----
     def fused_loss(self, camera, batch, background: Optional[Tensor] = None, sync: bool = True,
@@ -522,18 +734,26 @@ class QEDSplatterModel(nn.Module):
         same quantities as get_outputs + get_loss_dict."""
         assert camera.shape[0] == 1, "Only one camera at a time"
         cfg = self.config
-        intr = getattr(camera, "intrinsics_fxfycxcy", None)
-        if intr is not None and camera.camera_to_worlds.dtype == torch.float32:
-            # a1 + a3 in one launch (qed_camera_setup) instead of ~15 tiny eager kernels
-            c2w = camera.camera_to_worlds.contiguous()
-            viewmat = torch.empty(1, 4, 4, dtype=torch.float32, device=self.device)
-            K = torch.empty(1, 3, 3, dtype=torch.float32, device=self.device)
-            L.check(L.load().qed_camera_setup(1, L.ptr(c2w), L.ptr(intr()), L.ptr(viewmat), L.ptr(K), _stream()),
-                    "qed_camera_setup")
-        else:
-            viewmat = get_viewmat(camera.camera_to_worlds).to(torch.float32)
-            K = camera.get_intrinsics_matrices().to(self.device, torch.float32)
-        W, H = int(camera.width[0]), int(camera.height[0])
+        # the coarse-to-fine schedule of get_outputs (model.py:244-250): render at 1/d of the camera's resolution
+        d = self._get_downscale_factor()
+        if d > 1:
+            camera.rescale_output_resolution(1 / d)
+        try:
+            intr = getattr(camera, "intrinsics_fxfycxcy", None)
+            if intr is not None and camera.camera_to_worlds.dtype == torch.float32 and camera.camera_to_worlds.is_cuda:
+                # a1 + a3 in one launch (qed_camera_setup) instead of ~15 tiny eager kernels
+                c2w = camera.camera_to_worlds.contiguous()
+                viewmat = torch.empty(1, 4, 4, dtype=torch.float32, device=self.device)
+                K = torch.empty(1, 3, 3, dtype=torch.float32, device=self.device)
+                L.check(L.load().qed_camera_setup(1, L.ptr(c2w), L.ptr(intr()), L.ptr(viewmat), L.ptr(K), _stream()),
+                        "qed_camera_setup")
+            else:
+                viewmat = get_viewmat(camera.camera_to_worlds).to(self.device, torch.float32)
+                K = camera.get_intrinsics_matrices().to(self.device, torch.float32)
+            W, H = int(camera.width[0]), int(camera.height[0])
+        finally:
+            if d > 1:
+                camera.rescale_output_resolution(d)
         self.last_size = (H, W)
         # tight tile lists: info["tiles_per_gauss"/"flatten_ids"/...] become subsets of gsplat's (nothing on the
         # training path reads them); images, alphas and gradients are unchanged
@@ -551,6 +771,13 @@ class QEDSplatterModel(nn.Module):
         else:
             deg, colors, sh_rest = None, self.features_dc, None
             flags |= L.F_SIGMOID_COLORS
+        # ground truth exactly as get_loss_dict prepares it (uint8 -> float, downscaled, on the device), checked
+        # against the render size BEFORE any kernel reads it through a raw pointer
+        bg = (background if background is not None else self._get_background_color()).to(self.device, torch.float32)
+        gt_rgb = self.composite_with_background(self.get_gt_img(batch["image"]), bg)
+        gt_rgb = _f32_image(gt_rgb[..., :3] if gt_rgb.shape[-1] > 3 else gt_rgb, H * W * 3, "batch['image']", self.device)
+        gt_depth = _f32_image(self.get_gt_img(batch["depth_image"]), H * W, "batch['depth_image']", self.device)
+        mask = self._loss_mask(batch, (H, W))
         render, alpha, self.info = rasterization(
             means=self.means, quats=self.quats, scales=self.scales, opacities=self.opacities, colors=colors,
             viewmats=viewmat, Ks=K, width=W, height=H, tile_size=16, packed=False, near_plane=0.01, far_plane=1e10,
@@ -559,13 +786,7 @@ class QEDSplatterModel(nn.Module):
         self.xys = self.info["means2d"]
         self.radii = self.info["radii"][0]
         self.last_viewmat, self.last_sh_degree = viewmat, deg
-        bg = background if background is not None else self._get_background_color()
-        gt_rgb = batch["image"]
-        gt_depth = batch["depth_image"]
-        mask = batch.get("mask")
-        assert gt_rgb.dtype == torch.float32 and gt_rgb.is_contiguous() and gt_depth.is_contiguous()
-        total, parts = _FusedImageLoss.apply(render, alpha, bg.contiguous(), gt_rgb, gt_depth,
-                                             mask.contiguous() if mask is not None else None,
+        total, parts = _FusedImageLoss.apply(render, alpha, bg.contiguous(), gt_rgb, gt_depth, mask,
                                              float(cfg.ssim_lambda), cfg.depth_lambda)
         return {"loss": total, "main_loss": parts[0], "depth_loss": parts[1]}
 
@@ -609,6 +830,7 @@ class FlatAdam:
         self.betas, self.eps = betas, eps
         self.exp_avg = torch.zeros_like(model.flat_params)
         self.exp_avg_sq = torch.zeros_like(model.flat_params)
+        self._flat_ptr = model.flat_params.data_ptr()
         self.t = 0
         # device-resident step state + learning rates: what a captured hipGraph replays against
         self.dev_state = torch.zeros(4, dtype=torch.float32, device=model.device)
@@ -629,6 +851,18 @@ class FlatAdam:
         begins = list(self.model.group_begin)
         self._begin = (C.c_int64 * len(begins))(*begins)
         self.exp_avg, self.exp_avg_sq = exp_avg, exp_avg_sq
+        self._flat_ptr = self.model.flat_params.data_ptr()
+
+    def _check(self, who: str, compact_ok: bool = False) -> None:
+        """Refuse to train on garbage: a flat buffer the Parameters no longer alias (model.to() / densification
+        without rebind()), or compact SH gradients consumed by a plain step."""
+        m = self.model
+        if m.flat_params.data_ptr() != self._flat_ptr or m.flat_params.device != self.exp_avg.device:
+            raise RuntimeError(f"FlatAdam.{who}: the model adopted a new flat parameter buffer (model.to() or "
+                               "densification); call rebind(exp_avg, exp_avg_sq) or build a new optimiser")
+        if not compact_ok and getattr(m, "last_compact", False):
+            raise RuntimeError(f"FlatAdam.{who}: the last backward wrote compact SH gradients "
+                               "(fused_loss(compact_sh_grad=True)); step with fused_sh=True")
 
     # ---- one step in pieces: lets a data-parallel job update a range of the flat buffer as soon as that
     # range of the gradient has been all-reduced, while later ranges are still on the wire ----
@@ -650,6 +884,7 @@ class FlatAdam:
         assert 0 <= lo <= hi <= self.model.flat_params.numel() and lo % 4 == 0
         if hi == lo:
             return
+        self._check("step_range")
         g = self.model.flat_grad()
         begins = [min(max(b - lo, 0), hi - lo) for b in self.model.group_begin]
         h_begin = (C.c_int64 * len(begins))(*begins)
@@ -673,6 +908,7 @@ class FlatAdam:
         g = self.model.flat_grad()
         if g is None:
             return
+        self._check("step", compact_ok=fused_sh)
         lib = L.load()
         sched = (-1, 0.0, 0.0, 0)
         if self.means_schedule is not None:                      # the rate of the step about to be taken
@@ -714,3 +950,184 @@ class FlatAdam:
         L.check(lib.qed_adam_step(L.ptr(p), L.ptr(g), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
                                   len(self.lr), C.cast(self._begin, C.c_void_p), C.cast(self._lr, C.c_void_p),
                                   self.betas[0], self.betas[1], self.eps, self.t, _stream()), "qed_adam_step")
+
+
+class _SharedFlatState:
+    """What the QedAdam instances of one model share: the moments over the whole flat buffer and this step's
+    bookkeeping (which groups have called step(), with which rate)."""
+
+    def __init__(self, flat: Tensor):
+        self.flat_ptr = flat.data_ptr()
+        self.numel = flat.numel()
+        self.exp_avg = torch.zeros_like(flat)
+        self.exp_avg_sq = torch.zeros_like(flat)
+        self.members = weakref.WeakValueDictionary()   # flat offset -> optimiser instance
+        self.pending: Dict[int, float] = {}            # flat offset -> lr of the step() call waiting to be launched
+        self.t: Dict[int, int] = {}                    # flat offset -> steps taken
+
+
+_FLAT_STATES: "weakref.WeakValueDictionary[int, _SharedFlatState]" = weakref.WeakValueDictionary()
+_ALL_QED_ADAMS: "weakref.WeakSet[QedAdam]" = weakref.WeakSet()
+
+
+class QedAdam(torch.optim.Optimizer):
+    """``torch.optim.Adam`` semantics (no weight decay, no amsgrad) for Parameters that are views of ONE flat buffer
+    -- the six Gaussian groups of ``QEDSplatterModel`` -- as a ``torch.optim.Optimizer`` subclass, so that
+    Nerfstudio's ``AdamOptimizerConfig(_target=QedAdam, lr=..., eps=1e-15)`` builds it unchanged for every group
+    of config.py:44-68 and its schedulers / GradScaler / checkpointing keep working (``param_groups[0]["lr"]`` is
+    read at every step).
+
+    Nerfstudio creates one optimiser PER GROUP and steps them one after the other; the instances of one flat
+    buffer find each other through a registry and the LAST one to be stepped launches a single ``qed_adam_step``
+    over the whole buffer with one rate per group (one pass at HBM speed instead of six times ~10 eager launches).
+    A group that is stepped twice before the others, or ``flush()``, updates just the waiting groups' ranges."""
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+        if weight_decay != 0.0:
+            raise NotImplementedError("QedAdam: weight_decay is not used by the reference (config.py:44-68)")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        ps = [p for g in self.param_groups for p in g["params"]]
+        if len(ps) != 1:
+            raise ValueError("QedAdam steps one parameter group of the flat buffer per instance "
+                             "(Nerfstudio builds one optimiser per group name)")
+        self._shared: Optional[_SharedFlatState] = None
+        _ALL_QED_ADAMS.add(self)
+
+    # -- registry ---------------------------------------------------------------------------------------
+    def _param(self) -> Tensor:
+        return self.param_groups[0]["params"][0]
+
+    def _attach(self) -> _SharedFlatState:
+        p = self._param()
+        if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+            raise L.QedSplatError("QedAdam needs contiguous float32 GPU parameters")
+        base = p.untyped_storage().data_ptr()
+        st = _FLAT_STATES.get(base)
+        if st is None or self._shared is not st:
+            if st is None:
+                flat = torch.empty(0, dtype=torch.float32, device=p.device).set_(
+                    p.untyped_storage(), 0, (p.untyped_storage().nbytes() // 4,))
+                st = _SharedFlatState(flat)
+                _FLAT_STATES[base] = st
+                st._keepalive_flat = flat
+            # every live instance whose Parameter is a view of this buffer is a member from the start: the fused
+            # launch waits for all of them, whichever is stepped first
+            for inst in list(_ALL_QED_ADAMS):
+                q = inst._param()
+                if q.is_cuda and q.untyped_storage().data_ptr() == base:
+                    inst._shared = st
+                    st.members[q.storage_offset()] = inst
+                    st.t.setdefault(q.storage_offset(), 0)
+        off = p.storage_offset()
+        st.members[off] = self
+        st.t.setdefault(off, 0)
+        return st
+
+    # -- stepping ---------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        p = self._param()
+        if p.grad is None:
+            return loss
+        st = self._attach()
+        off = p.storage_offset()
+        if off in st.pending:                  # stepped twice before the others: launch what is waiting first
+            self._launch(st, sorted(st.pending))
+        st.pending[off] = float(self.param_groups[0]["lr"])
+        if len(st.pending) == len(st.members):
+            self._launch(st, sorted(st.pending))
+        return loss
+
+    def flush(self) -> None:
+        """Launch the update of the groups that have called step() but are still waiting for the others."""
+        st = self._shared
+        if st is not None and st.pending:
+            self._launch(st, sorted(st.pending))
+
+    @staticmethod
+    def _launch(st: _SharedFlatState, offs) -> None:
+        import ctypes as C
+        lib = L.load()
+        members = [st.members[o] for o in offs]
+        ps = [m._param() for m in members]
+        g0 = ps[0].grad
+        # maximal runs of groups that are adjacent in the flat buffer, share betas / eps / step count and whose
+        # gradients are adjacent views of one allocation (what _ProjectSH.backward produces): one launch per run
+        runs, cur = [], [0]
+        for i in range(1, len(ps)):
+            a, b = ps[i - 1], ps[i]
+            ga, gb = a.grad, b.grad
+            same = (offs[i] == offs[i - 1] + a.numel()
+                    and gb.is_contiguous() and ga.is_contiguous()
+                    and gb.untyped_storage().data_ptr() == ga.untyped_storage().data_ptr()
+                    and gb.storage_offset() == ga.storage_offset() + ga.numel()
+                    and members[i].defaults_key() == members[i - 1].defaults_key()
+                    and st.t[offs[i]] == st.t[offs[i - 1]])
+            if same:
+                cur.append(i)
+            else:
+                runs.append(cur)
+                cur = [i]
+        runs.append(cur)
+        stream = _stream()
+        for run in runs:
+            first, last = run[0], run[-1]
+            lo, hi = offs[first], offs[last] + ps[last].numel()
+            g = ps[first].grad
+            beta1, beta2 = members[first].param_groups[0]["betas"]
+            eps = members[first].param_groups[0]["eps"]
+            t = st.t[offs[first]] + 1
+            if lo % 4 != 0 or g.data_ptr() % 16 != 0 or not g.is_contiguous() or g.dtype != torch.float32:
+                # a lone group whose range or gradient is not 16-byte aligned (only when the groups are stepped out
+                # of step with each other, or N is not a multiple of 4): the same update with eager torch ops
+                for i in run:
+                    o, n = offs[i], ps[i].numel()
+                    gi = ps[i].grad.reshape(-1).to(torch.float32)
+                    m, v = st.exp_avg[o:o + n], st.exp_avg_sq[o:o + n]
+                    m.mul_(beta1).add_(gi, alpha=1 - beta1)
+                    v.mul_(beta2).addcmul_(gi, gi, value=1 - beta2)
+                    denom = (v.sqrt() / math.sqrt(1 - beta2 ** t)).add_(eps)
+                    ps[i].data.reshape(-1).addcdiv_(m, denom, value=-st.pending[offs[i]] / (1 - beta1 ** t))
+                    st.t[offs[i]] = t
+                continue
+            begins = [offs[i] - lo for i in run] + [hi - lo]
+            lrs = [st.pending[offs[i]] for i in run]
+            h_begin = (C.c_int64 * len(begins))(*begins)
+            h_lr = (C.c_float * len(lrs))(*lrs)
+            flat = st._keepalive_flat
+            L.check(lib.qed_adam_step(L.ptr(flat[lo:hi]), g.data_ptr(), L.ptr(st.exp_avg[lo:hi]), L.ptr(st.exp_avg_sq[lo:hi]),
+                                      len(lrs), C.cast(h_begin, C.c_void_p), C.cast(h_lr, C.c_void_p), beta1, beta2, eps,
+                                      t, stream), "qed_adam_step")
+            for i in run:
+                st.t[offs[i]] = t
+        st.pending.clear()
+
+    def defaults_key(self):
+        g = self.param_groups[0]
+        return (tuple(g["betas"]), float(g["eps"]))
+
+    # -- checkpointing: this group's slice of the shared moments, in torch.optim.Adam's layout -----------
+    def state_dict(self):
+        sd = super().state_dict()
+        st = self._shared
+        if st is not None:
+            p = self._param()
+            off, n = p.storage_offset(), p.numel()
+            sd["state"] = {0: {"step": torch.tensor(float(st.t.get(off, 0))),
+                               "exp_avg": st.exp_avg[off:off + n].view(p.shape).clone(),
+                               "exp_avg_sq": st.exp_avg_sq[off:off + n].view(p.shape).clone()}}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state = state_dict.get("state", {})
+        super().load_state_dict({"state": {}, "param_groups": state_dict["param_groups"]})
+        if state:
+            st = self._attach()
+            p = self._param()
+            off, n = p.storage_offset(), p.numel()
+            s0 = state[0] if 0 in state else next(iter(state.values()))
+            st.exp_avg[off:off + n] = s0["exp_avg"].reshape(-1).to(st.exp_avg)
+            st.exp_avg_sq[off:off + n] = s0["exp_avg_sq"].reshape(-1).to(st.exp_avg_sq)
+            st.t[off] = int(s0["step"])
+

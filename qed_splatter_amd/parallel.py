@@ -19,6 +19,7 @@ def allreduce_flat_grad(model, world_size: int, group=None) -> torch.Tensor:
     g = model.flat_grad()
     if g is None:
         raise RuntimeError("no gradients to reduce: call backward() first")
+    _refuse_compact(model, "allreduce_flat_grad")
     if world_size <= 1:
         return g
     if dist.get_backend(group) == "nccl":
@@ -27,6 +28,14 @@ def allreduce_flat_grad(model, world_size: int, group=None) -> torch.Tensor:
         dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
         g.mul_(1.0 / world_size)
     return g
+
+
+def _refuse_compact(model, who: str) -> None:
+    """After fused_loss(compact_sh_grad=True) features_dc.grad holds colour gradients and features_rest.grad is
+    unwritten memory: only exchange_grads_compact / FlatAdam.step(fused_sh=True) may consume them."""
+    if getattr(model, "last_compact", False):
+        raise RuntimeError(f"{who}: the last backward wrote compact SH gradients (fused_loss(compact_sh_grad=True)); "
+                           "use exchange_grads_compact() / FlatAdam.step(fused_sh=True), or render without the flag")
 
 
 def exchange_grads_compact(model, world_size: int, group=None, views=None, rebuild: bool = True) -> torch.Tensor:
@@ -49,6 +58,8 @@ def exchange_grads_compact(model, world_size: int, group=None, views=None, rebui
     g = model.flat_grad()
     if g is None:
         raise RuntimeError("no gradients to exchange: call backward() first")
+    if not getattr(model, "last_compact", False):
+        raise RuntimeError("exchange_grads_compact needs gradients from fused_loss(..., compact_sh_grad=True)")
     names, begin, N = model.group_names, model.group_begin, model.num_points
     i_dc, i_rest = names.index("features_dc"), names.index("features_rest")
     assert i_dc == 4 and i_rest == 5, "group order: geometry groups first, then features_dc, features_rest"
@@ -92,6 +103,7 @@ def exchange_grads_compact(model, world_size: int, group=None, views=None, rebui
     L.check(L.load().qed_sh_grad_from_views(N, n_views, L.ptr(model.means), L.ptr(recv[:, nv:]), row, L.ptr(recv), row,
                                             deg, 1.0 / n_views, L.ptr(v_local), 3, L.ptr(g[begin[i_rest]:]), rest_w,
                                             torch.cuda.current_stream().cuda_stream), "qed_sh_grad_from_views")
+    model.last_compact = False                     # the flat gradient is complete again
     return g
 
 
@@ -109,6 +121,7 @@ def allreduce_and_step(model, optimizer, world_size: int, n_chunks: int = 4, gro
     g = model.flat_grad()
     if g is None:
         raise RuntimeError("no gradients to reduce: call backward() first")
+    _refuse_compact(model, "allreduce_and_step")
     total = g.numel()
     if world_size <= 1:
         optimizer.begin_step()

@@ -30,7 +30,7 @@ init = {k: sc[k] for k in ("means", "scales", "quats", "opacities", "features_dc
 
 
 def run(kind):
-    model = QEDSplatterModel(QEDSplatterModelConfig(sh_degree_interval=1, background_color="black"), **init)
+    model = QEDSplatterModel(QEDSplatterModelConfig.synthetic(sh_degree_interval=1, background_color="black"), **init)
     model.step = 30000
     model.train()
     opt = FlatAdam(model, means_schedule=FlatAdam.MEANS_SCHEDULE)

@@ -20,7 +20,7 @@ n, w, h = (int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv
 dev = torch.device("cuda:0")
 L.load()
 sc = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synthetic_scene(n, w, h, seed=1235).items()}
-model = QEDSplatterModel(QEDSplatterModelConfig(sh_degree_interval=1), **{k: sc[k] for k in
+model = QEDSplatterModel(QEDSplatterModelConfig.synthetic(sh_degree_interval=1), **{k: sc[k] for k in
                          ("means", "scales", "quats", "opacities", "features_dc", "features_rest")})
 model.step = 30000
 K = sc["Ks"][0].cpu()

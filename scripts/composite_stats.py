@@ -22,7 +22,7 @@ fn = lib._cdll.qed_debug_composite_stats
 fn.restype = C.c_int
 fn.argtypes = [C.c_void_p, C.c_int]
 sc = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synthetic_scene(n, w, h, seed=1235).items()}
-model = QEDSplatterModel(QEDSplatterModelConfig(sh_degree_interval=1), **{k: sc[k] for k in
+model = QEDSplatterModel(QEDSplatterModelConfig.synthetic(sh_degree_interval=1), **{k: sc[k] for k in
                          ("means", "scales", "quats", "opacities", "features_dc", "features_rest")})
 model.step = 30000
 K = sc["Ks"][0].cpu()

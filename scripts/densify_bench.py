@@ -17,7 +17,7 @@ L.load()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 500_000
 sc = synthetic_scene(n, 1920, 1080, seed=1235)
 for rep in range(3):
-    model = QEDSplatterModel(QEDSplatterModelConfig(), **{k: sc[k].to(dev) for k in
+    model = QEDSplatterModel(QEDSplatterModelConfig.synthetic(), **{k: sc[k].to(dev) for k in
                                                           ("means", "scales", "quats", "opacities", "features_dc", "features_rest")})
     opt = FlatAdam(model)
     model.last_size = (1080, 1920)

@@ -30,7 +30,7 @@ names = ("means", "scales", "quats", "opacities", "features_dc", "features_rest"
 K = sc["Ks"][0]
 cam = PinholeCameras(sc["camera_to_worlds"][rank:rank + 1].to(dev), float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), w, h)
 batch = {"image": sc["gt_rgb"].to(dev), "depth_image": sc["gt_depth"].to(dev)}
-models = [QEDSplatterModel(QEDSplatterModelConfig(sh_degree_interval=1), **{k: sc[k].to(dev) for k in names}) for _ in range(4)]
+models = [QEDSplatterModel(QEDSplatterModelConfig.synthetic(sh_degree_interval=1), **{k: sc[k].to(dev) for k in names}) for _ in range(4)]
 opts = [FlatAdam(m, means_schedule=FlatAdam.MEANS_SCHEDULE) for m in models]
 for m in models:
     m.step = 30000

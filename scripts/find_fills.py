@@ -16,7 +16,7 @@ torch.cuda.set_stream(torch.cuda.Stream())
 L.load()
 n, w, h = 50_000, 640, 360
 sc = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synthetic_scene(n, w, h, seed=1).items()}
-model = QEDSplatterModel(QEDSplatterModelConfig(sh_degree_interval=1), **{k: sc[k] for k in
+model = QEDSplatterModel(QEDSplatterModelConfig.synthetic(sh_degree_interval=1), **{k: sc[k] for k in
                          ("means", "scales", "quats", "opacities", "features_dc", "features_rest")})
 model.step = 30000
 K = sc["Ks"][0].cpu()

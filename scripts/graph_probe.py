@@ -13,7 +13,7 @@ variant = sys.argv[1]
 dev = torch.device("cuda:0"); L.load()
 import os; n, w, h = (int(x) for x in os.environ.get("PROBE_SIZE", "20000,320,240").split(","))
 sc = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synthetic_scene(n, w, h, seed=3).items()}
-model = QEDSplatterModel(QEDSplatterModelConfig(sh_degree_interval=1), **{k: sc[k] for k in ("means","scales","quats","opacities","features_dc","features_rest")})
+model = QEDSplatterModel(QEDSplatterModelConfig.synthetic(sh_degree_interval=1), **{k: sc[k] for k in ("means","scales","quats","opacities","features_dc","features_rest")})
 model.step = 30000
 K = sc["Ks"][0].cpu()
 cam = PinholeCameras(sc["camera_to_worlds"], float(K[0,0]), float(K[1,1]), float(K[0,2]), float(K[1,2]), w, h)

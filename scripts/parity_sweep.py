@@ -48,7 +48,7 @@ for case in (range(n_cases) if only is None else [only]):
     boost = float(os.environ.get("QED_SWEEP_SCALE_BOOST", "2.5"))
     sc["scales"] = sc["scales"] + float(torch.rand(1, generator=g)) * boost          # up to e^boost x larger splats
     sc["opacities"] = sc["opacities"] + (float(torch.rand(1, generator=g)) - 0.7) * 4
-    cfg = QEDSplatterModelConfig(sh_degree=3, sh_degree_interval=1, rasterize_mode=mode,
+    cfg = QEDSplatterModelConfig.synthetic(sh_degree=3, sh_degree_interval=1, rasterize_mode=mode,
                                  tight_tile_lists=os.environ.get("QED_SWEEP_TIGHT", "1") == "1")
     model = QEDSplatterModel(cfg, **{k: sc[k].to(dev) for k in NAMES})
     model.step = deg                                                                # active SH degree = deg

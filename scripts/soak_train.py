@@ -23,7 +23,7 @@ L.load()
 n, w, h, n_cams = 30000, 640, 360, 12
 sc = synthetic_scene(n, w, h, seed=5, n_cameras=n_cams)
 K = sc["Ks"][0]
-cfg = QEDSplatterModelConfig(sh_degree_interval=1000)
+cfg = QEDSplatterModelConfig.synthetic(sh_degree_interval=1000)
 gt_model = QEDSplatterModel(cfg, **{k: sc[k].to(dev) for k in NAMES})
 gt_model.step = 10_000
 gt_model.eval()

@@ -24,9 +24,9 @@ st = torch.cuda.current_stream().cuda_stream
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
 for it in range(iters):
     ev[0].record()
-    L.check(lib.qed_ssim_fwd(H, W, 4, L.ptr(render), L.ptr(alpha), L.ptr(bg), L.ptr(gt), L.ptr(maps), L.ptr(ssum), st), "f")
+    L.check(lib.qed_ssim_fwd(H, W, 4, L.ptr(render), L.ptr(alpha), L.ptr(bg), L.ptr(gt), None, L.ptr(maps), L.ptr(ssum), st), "f")
     ev[1].record()
-    L.check(lib.qed_ssim_bwd(H, W, 4, L.ptr(render), L.ptr(alpha), L.ptr(bg), L.ptr(gt), L.ptr(maps), -1e-7, L.ptr(v), st), "b")
+    L.check(lib.qed_ssim_bwd(H, W, 4, L.ptr(render), L.ptr(alpha), L.ptr(bg), L.ptr(gt), None, L.ptr(maps), -1e-7, None, L.ptr(v), st), "b")
     ev[2].record()
     torch.cuda.synchronize()
     print(f"fwd {ev[0].elapsed_time(ev[1]) * 1e3:.1f} us  bwd {ev[1].elapsed_time(ev[2]) * 1e3:.1f} us", flush=True)

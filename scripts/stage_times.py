@@ -33,7 +33,7 @@ def main():
     sc = synthetic_scene(a.gaussians, a.width, a.height, seed=a.seed)
     sc = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sc.items()}
     print(f"scene built in {time.time() - t0:.1f}s", flush=True)
-    model = QEDSplatterModel(QEDSplatterModelConfig(sh_degree_interval=1),
+    model = QEDSplatterModel(QEDSplatterModelConfig.synthetic(sh_degree_interval=1),
                              **{k: sc[k] for k in ("means", "scales", "quats", "opacities", "features_dc",
                                                    "features_rest")})
     model.step = 30000

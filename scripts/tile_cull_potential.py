@@ -18,7 +18,7 @@ dev = torch.device("cuda:0")
 L.load()
 n, w, h = 500_000, 1920, 1080
 sc = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synthetic_scene(n, w, h, seed=1235).items()}
-model = QEDSplatterModel(QEDSplatterModelConfig(sh_degree_interval=1), **{k: sc[k] for k in
+model = QEDSplatterModel(QEDSplatterModelConfig.synthetic(sh_degree_interval=1), **{k: sc[k] for k in
                          ("means", "scales", "quats", "opacities", "features_dc", "features_rest")})
 model.step = 30000
 model.eval()

@@ -7,7 +7,7 @@ from qed_splatter_amd.scene import synthetic_scene
 dev = torch.device("cuda:0"); L.load()
 n, w, h = 500000, 1920, 1080
 sc = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synthetic_scene(n, w, h, seed=1235).items()}
-model = QEDSplatterModel(QEDSplatterModelConfig(sh_degree_interval=1), **{k: sc[k] for k in ("means","scales","quats","opacities","features_dc","features_rest")})
+model = QEDSplatterModel(QEDSplatterModelConfig.synthetic(sh_degree_interval=1), **{k: sc[k] for k in ("means","scales","quats","opacities","features_dc","features_rest")})
 model.step = 30000
 K = sc["Ks"][0].cpu()
 cam = PinholeCameras(sc["camera_to_worlds"], float(K[0,0]), float(K[1,1]), float(K[0,2]), float(K[1,2]), w, h)

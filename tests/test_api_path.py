@@ -1,0 +1,402 @@
+"""GPU tests of the reference-shaped route -- get_outputs() -> get_loss_dict() -> sum -> backward() -> one optimiser per
+parameter group -- and of the parent-class semantics behind it (mask on both images, scale_reg, the
+coarse-to-fine resolution schedule), against the fp64 oracle and plain torch.  Reference-generated known answers
+(tests/golden/reference_kats.npz) are fed to the KERNELS here, not to a torch mirror."""
+from __future__ import annotations
+
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import splat_oracle as O
+from tests.util import PARAM_NAMES, REL_TOL, assert_close, assert_close_elem, scene
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _model(sc, dev, step=100, **cfg_kw):
+    from qed_splatter_amd.model import PinholeCameras, QEDSplatterModel, QEDSplatterModelConfig
+    cfg_kw.setdefault("sh_degree_interval", 1)
+    cfg = QEDSplatterModelConfig.synthetic(**cfg_kw)
+    m = QEDSplatterModel(cfg, **{k: sc[k].to(dev) for k in PARAM_NAMES})
+    m.step = step
+    K = sc["Ks"][0]
+    h, w = sc["gt_rgb"].shape[:2]
+    cam = PinholeCameras(sc["camera_to_worlds"][:1].to(dev), K[0, 0], K[1, 1], K[0, 2], K[1, 2], w, h)
+    batch = {"image": sc["gt_rgb"].to(dev), "depth_image": sc["gt_depth"].to(dev)}
+    return m, cam, batch
+
+
+# ---- the two fused nodes against plain torch (the statements of model.py:295-306 / the parent's loss) --------------
+@pytest.mark.parametrize("ch", [3, 4])
+def test_post_process_matches_torch_statements(cuda, ch):
+    from qed_splatter_amd.model import _PostProcess
+    g = torch.Generator().manual_seed(3)
+    H, W = 37, 53
+    render = (torch.rand(1, H, W, ch, generator=g) * 1.6 - 0.3).to(cuda).requires_grad_(True)
+    alpha = torch.rand(1, H, W, 1, generator=g)
+    alpha[0, :5] = 0.0                                                      # empty pixels take the max depth
+    alpha = alpha.to(cuda).requires_grad_(True)
+    bg = torch.tensor([0.2, 0.7, 0.4], device=cuda)
+    w_rgb = torch.rand(1, H, W, 3, generator=g).to(cuda)
+    w_d = torch.rand(1, H, W, 1, generator=g).to(cuda)
+    out = _PostProcess.apply(render, alpha, bg)
+    rgb, depth = (out, None) if ch == 3 else out
+    loss = (rgb * w_rgb).sum() + ((depth * w_d).sum() if depth is not None else 0.0)
+    loss.backward()
+    g_render, g_alpha = render.grad.clone(), alpha.grad.clone()
+    render.grad = alpha.grad = None
+    # model.py:296-297, 304-306 verbatim
+    rgb_t = torch.clamp(render[:, ..., :3] + (1 - alpha) * bg, 0.0, 1.0)
+    loss_t = (rgb_t * w_rgb).sum()
+    if ch == 4:
+        depth_t = render[:, ..., 3:4]
+        depth_t = torch.where(alpha > 0, depth_t, depth_t.detach().max())
+        loss_t = loss_t + (depth_t * w_d).sum()
+        assert torch.equal(depth, depth_t)
+    loss_t.backward()
+    assert float((rgb - rgb_t).abs().max()) <= 1e-6
+    assert float((g_render - render.grad).abs().max()) <= 1e-6
+    assert float((g_alpha - alpha.grad).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("lam", [0.0, 0.2])
+def test_image_losses_value_and_weighted_gradients(cuda, masked, lam):
+    """main / depth losses vs the fp64 oracle, and the backward under DIFFERENT upstream gradients per term."""
+    from qed_splatter_amd.model import _ImageLosses
+    g = torch.Generator().manual_seed(11)
+    H, W = 45, 70
+    rgb = torch.rand(H, W, 3, generator=g)
+    gt = torch.rand(H, W, 3, generator=g)
+    depth = torch.rand(H, W, 1, generator=g) * 9 + 1
+    gtd = torch.rand(H, W, 1, generator=g) * 9 + 1
+    gtd[torch.rand(H, W, 1, generator=g) < 0.1] = 0.0
+    gtd[3, 4] = float("nan")
+    gtd[5, 6] = float("inf")
+    mask = (torch.rand(H, W, 1, generator=g) > 0.3).float() if masked else None
+    a = rgb.to(cuda).requires_grad_(True)
+    d = depth.to(cuda).requires_grad_(True)
+    main, dl = _ImageLosses.apply(a, d, gt.to(cuda), gtd.to(cuda), mask.to(cuda) if masked else None, lam, 0.2)
+    (2.0 * main + 3.0 * dl).backward()
+    ar = rgb.double().requires_grad_(True)
+    dr = depth.double().requires_grad_(True)
+    main_r = O.main_loss(ar, gt.double(), lam, mask.double() if masked else None)
+    dl_r = O.depth_l1_loss(dr, gtd.double(), mask.double() if masked else None, 0.2)
+    (2.0 * main_r + 3.0 * dl_r).backward()
+    assert float(main) == pytest.approx(float(main_r), rel=2e-6)
+    assert float(dl) == pytest.approx(float(dl_r), rel=2e-6)
+    # |x - y| has a kink: exclude elements within fp32 rounding of it
+    ok = ((rgb - gt).abs() > 1e-6)
+    if masked:
+        ok = ok | (mask == 0)
+    assert_close_elem(a.grad.cpu()[ok], ar.grad[ok], f"v_rgb masked={masked} lambda={lam}", atol_frac=2e-6)
+    assert_close_elem(d.grad.cpu(), dr.grad, "v_depth", atol_frac=1e-6)
+
+
+def test_image_losses_no_valid_depth_and_errors(cuda):
+    from qed_splatter_amd._lib import QedSplatError
+    from qed_splatter_amd.model import _ImageLosses
+    H, W = 16, 20
+    rgb = torch.rand(H, W, 3, device=cuda, requires_grad=True)
+    d = torch.rand(H, W, 1, device=cuda, requires_grad=True)
+    main, dl = _ImageLosses.apply(rgb, d, torch.rand(H, W, 3, device=cuda), torch.zeros(H, W, 1, device=cuda), None, 0.2, 0.2)
+    assert float(dl) == 0.0                                              # model.py:111-114: 0.0, not NaN
+    (main + dl).backward()
+    assert float(d.grad.abs().max()) == 0.0 and bool(torch.isfinite(rgb.grad).all())
+    with pytest.raises(QedSplatError):                                    # smaller than the SSIM window
+        _ImageLosses.apply(torch.rand(8, 8, 3, device=cuda), None, torch.rand(8, 8, 3, device=cuda), None, None, 0.2, 0.2)
+
+
+# ---- reference-generated known answers through the kernels --------------------------------------------
+def test_reference_depth_l1_kats_through_both_kernel_paths(cuda, lib):
+    """The five depth-L1 cases the reference itself produced (masks, NaN, inf, zero GT, no valid pixel) and SURVEY's
+    0.0653 through (i) get_loss_dict's kernels and (ii) K8 (qed_loss_reduce / qed_loss_grad with alpha = 1 and the
+    depth in channel 3)."""
+    from qed_splatter_amd import _lib as L
+    from qed_splatter_amd.model import _ImageLosses
+    kats = np.load(os.path.join(GOLD, "reference_kats.npz"))
+    cases = [(kats[f"dl{i}_depth_out"], kats[f"dl{i}_depth_gt"], kats[f"dl{i}_mask"], float(kats[f"dl{i}_lambda"]),
+              float(kats[f"dl{i}_loss"])) for i in kats["dl_cases"]]
+    cases.append((kats["survey_depth_out"], kats["survey_depth_gt"], np.zeros(0), 0.2, float(kats["survey_loss"])))
+    st = torch.cuda.current_stream().cuda_stream
+    for d_out, d_gt, m, lam, want in cases:
+        H, W = d_out.shape[:2]
+        d = torch.from_numpy(d_out).float().reshape(H, W, 1).to(cuda)
+        g = torch.from_numpy(d_gt).float().reshape(H, W, 1).to(cuda)
+        mask = torch.from_numpy(m).float().reshape(H, W, 1).to(cuda) if m.size else None
+        rgb = torch.zeros(H, W, 3, device=cuda)
+        _, dl = _ImageLosses.apply(rgb, d, rgb, g, mask, 0.0, lam)
+        assert float(dl) == pytest.approx(want, rel=1e-6, abs=1e-9)
+        # K8: render = (0, 0, 0, depth), alpha = 1 (so the depth fix-up keeps every pixel)
+        render = torch.cat([torch.zeros(H, W, 3, device=cuda), d], dim=-1).contiguous()
+        alpha = torch.ones(H, W, 1, device=cuda)
+        bg = torch.zeros(3, device=cuda)
+        sums = torch.empty(L.LOSS_SUMS_FLOATS, device=cuda)
+        losses = torch.empty(3, device=cuda)
+        v_r, v_a = torch.empty_like(render), torch.empty_like(alpha)
+        args = (H * W, 4, L.ptr(render), L.ptr(alpha), L.ptr(bg), L.ptr(rgb), L.ptr(g), L.ptr(mask))
+        L.check(lib.qed_loss_reduce(*args, L.ptr(sums), st), "reduce")
+        L.check(lib.qed_loss_grad(*args, L.ptr(sums), 1.0, lam, L.ptr(v_r), L.ptr(v_a), L.ptr(losses), None, None, 0.0,
+                                  0.0, st), "grad")
+        assert float(losses[1]) == pytest.approx(want, rel=1e-6, abs=1e-9)
+        # NaN renders must not poison the gradient of the other pixels
+        assert bool(torch.isfinite(v_r).all())
+
+
+def test_reference_viewmat_kats_through_camera_setup(cuda, lib):
+    """The six rigid poses of reference_kats.npz (random rotations, SURVEY's known answer) through qed_camera_setup.
+    Bit-exact against the reference's own output except where R^T t is rounded differently: the kernel may contract
+    the 3-term dot product into FMAs (<= 1 ulp of the largest product), so the translation column gets 2 ulp."""
+    from qed_splatter_amd import _lib as L
+    kats = np.load(os.path.join(GOLD, "reference_kats.npz"))
+    c2w = torch.from_numpy(kats["viewmat_c2w"]).float().to(cuda).contiguous()
+    want = torch.from_numpy(kats["viewmat_out"]).float()
+    C = c2w.shape[0]
+    intr = torch.tensor([[500.0, 510.0, 320.0, 240.0]] * C, device=cuda)
+    vm = torch.empty(C, 4, 4, device=cuda)
+    Ks = torch.empty(C, 3, 3, device=cuda)
+    L.check(lib.qed_camera_setup(C, L.ptr(c2w), L.ptr(intr), L.ptr(vm), L.ptr(Ks), torch.cuda.current_stream().cuda_stream),
+            "qed_camera_setup")
+    vm = vm.cpu()
+    assert torch.equal(vm[:, :3, :3], want[:, :3, :3]) and torch.equal(vm[:, 3], want[:, 3])
+    scale = c2w[:, :3, 3].abs().max().item()
+    assert float((vm[:, :3, 3] - want[:, :3, 3]).abs().max()) <= 2 * np.spacing(np.float32(scale)) * 3
+    K0 = Ks.cpu()[0]
+    assert K0.tolist() == [[500.0, 0.0, 320.0], [0.0, 510.0, 240.0], [0.0, 0.0, 1.0]]
+
+
+# ---- parent-class semantics -----------------------------------------------------------------------------
+def test_masked_rgb_loss_api_fused_and_oracle_agree(cuda):
+    """The mask multiplies BOTH images before L1 and SSIM (parent) and both depths (model.py:93-97): API route, fused
+    route and the oracle agree, and masked-out pixels pass no colour gradient."""
+    w, h, n = 160, 112, 3000
+    sc = scene(n, w, h, seed=5)
+    mask = torch.ones(h, w, 1)
+    mask[:, : w // 3] = 0.0                                               # a masked-out band
+    m1, cam, batch = _model(sc, cuda)
+    batch["mask"] = (mask > 0).to(cuda)                                   # bool, as Nerfstudio delivers it
+    out = m1.get_outputs(cam)
+    out["rgb"].retain_grad()
+    ld = m1.get_loss_dict(out, batch)
+    assert set(ld) == {"main_loss", "scale_reg", "depth_loss"} and float(ld["scale_reg"]) == 0.0
+    sum(ld.values()).backward()
+    assert float(out["rgb"].grad[:, : w // 3].abs().max()) == 0.0
+    m2, cam2, batch2 = _model(sc, cuda)
+    batch2["mask"] = mask.to(cuda)
+    lf = m2.fused_loss(cam2, batch2)
+    lf["loss"].backward()
+    ps = {k: sc[k].double().requires_grad_(True) for k in PARAM_NAMES}
+    ref = O.splatfacto_outputs(ps["means"], ps["scales"], ps["quats"], ps["opacities"], ps["features_dc"],
+                               ps["features_rest"], sc["camera_to_worlds"][:1].double(), sc["Ks"][:1].double(), w, h,
+                               sc["background"].double(), radii_override=m1.info["radii"].cpu())
+    l_rgb = O.main_loss(ref["rgb"], sc["gt_rgb"].double(), 0.2, mask.double())
+    l_d = O.depth_l1_loss(ref["depth"], sc["gt_depth"].double(), mask.double(), 0.2)
+    for got in (ld, lf):
+        assert float(got["main_loss"]) == pytest.approx(float(l_rgb), rel=1e-4)
+        assert float(got["depth_loss"]) == pytest.approx(float(l_d), rel=1e-4)
+    (l_rgb + l_d).backward()
+    for name in PARAM_NAMES:
+        assert_close(m2.gauss_params[name].grad, m1.gauss_params[name].grad, 2e-5, f"fused vs api grad {name}")
+        assert_close(m1.gauss_params[name].grad.cpu(), ps[name].grad, 5e-4, f"api vs oracle grad {name}")
+
+
+def test_scale_regularization_matches_oracle(cuda):
+    w, h, n = 64, 48, 500
+    sc = scene(n, w, h, seed=9)
+    sc["scales"][:50, 0] += 3.0                                           # some very anisotropic Gaussians
+    m, cam, batch = _model(sc, cuda, step=20, use_scale_regularization=True)
+    out = m.get_outputs(cam)
+    ld = m.get_loss_dict(out, batch)
+    want = O.scale_reg(sc["scales"].double(), 20, True, 10.0)
+    assert float(want) > 0 and float(ld["scale_reg"]) == pytest.approx(float(want), rel=1e-5)
+    m.step = 21
+    assert float(m.get_loss_dict(m.get_outputs(cam), batch)["scale_reg"]) == 0.0      # only every 10th step
+
+
+def test_resolution_schedule_api_and_fused(cuda):
+    """num_downscales = 2 (the parent's default): renders at 1/4, 1/2, full resolution as the step passes the
+    schedule; the ground truth is box-filtered (the parent's resize_image); API and fused routes agree."""
+    w, h, n = 256, 192, 4000
+    sc = scene(n, w, h, seed=21)
+    for step, d in [(0, 4), (3000, 2), (6000, 1)]:
+        m1, cam, batch = _model(sc, cuda, step=step, num_downscales=2, resolution_schedule=3000, sh_degree_interval=1000)
+        assert m1._get_downscale_factor() == d
+        out = m1.get_outputs(cam)
+        assert out["rgb"].shape == (h // d, w // d, 3) and m1.last_size == (h // d, w // d)
+        assert int(cam.width[0]) == w                                     # the camera is restored (model.py:250)
+        gt = m1.get_gt_img(batch["image"])
+        assert_close(gt.cpu(), O.resize_image(sc["gt_rgb"], d), 1e-6, f"resize_image d={d}")
+        ld = m1.get_loss_dict(out, batch)
+        sum(ld.values()).backward()
+        m2, cam2, batch2 = _model(sc, cuda, step=step, num_downscales=2, resolution_schedule=3000,
+                                  sh_degree_interval=1000)
+        lf = m2.fused_loss(cam2, batch2)
+        lf["loss"].backward()
+        assert float(lf["main_loss"]) == pytest.approx(float(ld["main_loss"]), rel=1e-5)
+        assert float(lf["depth_loss"]) == pytest.approx(float(ld["depth_loss"]), rel=1e-5)
+        for name in PARAM_NAMES:
+            assert_close(m2.gauss_params[name].grad, m1.gauss_params[name].grad, 5e-5, f"d={d} grad {name}")
+    m1.eval()
+    assert m1._get_downscale_factor() == 1                                # eval renders at full resolution
+
+
+def test_background_colors_and_rgba_ground_truth(cuda):
+    from qed_splatter_amd.model import QEDSplatterModelConfig
+    sc = scene(200, 48, 32, seed=2)
+    m, cam, batch = _model(sc, cuda)
+    m.config = QEDSplatterModelConfig(sh_degree_interval=1)              # the parent's defaults: "random", 2 downscales
+    assert m.config.background_color == "random" and m.config.num_downscales == 2
+    m.train()
+    b1, b2 = m._get_background_color(), m._get_background_color()
+    assert b1.shape == (3,) and not torch.equal(b1, b2)
+    m.eval()
+    assert m._get_background_color().tolist() == pytest.approx([0.1490, 0.1647, 0.2157])
+    # RGBA ground truth is composited onto the step's background (parent's composite_with_background)
+    rgba = torch.rand(32, 48, 4, device=cuda)
+    bg = torch.tensor([0.3, 0.6, 0.9], device=cuda)
+    got = m.composite_with_background(rgba, bg)
+    want = rgba[..., 3:] * rgba[..., :3] + (1 - rgba[..., 3:]) * bg
+    assert torch.allclose(got, want)
+    m.train()
+    m.config.use_bilateral_grid = True
+    cam.metadata = {"cam_idx": 0}
+    with pytest.raises(NotImplementedError):
+        m.get_outputs(cam)
+
+
+# ---- input validation before raw pointers reach a kernel (ADVICE) -----------------------------------------------------
+def test_batch_validation_bool_mask_uint8_image_wrong_size(cuda):
+    from qed_splatter_amd._lib import QedSplatError
+    w, h, n = 96, 64, 800
+    sc = scene(n, w, h, seed=4)
+    m, cam, batch = _model(sc, cuda)
+    ref = m.fused_loss(cam, dict(batch, mask=(torch.rand(h, w, 1, device=cuda) > 0.2).float()))
+    torch.manual_seed(0)
+    mask = torch.rand(h, w, 1, device=cuda) > 0.2
+    a = m.fused_loss(cam, dict(batch, mask=mask))                         # bool mask: converted, not reinterpreted
+    b = m.fused_loss(cam, dict(batch, mask=mask.float()))
+    assert float(a["loss"]) == float(b["loss"]) and math.isfinite(float(ref["loss"]))
+    img8 = (batch["image"] * 255).round().to(torch.uint8)                 # cached uint8 images (config.py:38)
+    c = m.fused_loss(cam, dict(batch, image=img8.cpu()))                  # ... that live on the host
+    d = m.fused_loss(cam, dict(batch, image=img8.float() / 255.0))
+    assert float(c["loss"]) == float(d["loss"])
+    with pytest.raises(QedSplatError):
+        m.fused_loss(cam, dict(batch, image=batch["image"][: h // 2]))    # wrong size: refused before any launch
+    with pytest.raises(QedSplatError):
+        m.fused_loss(cam, dict(batch, depth_image=batch["depth_image"][:, : w - 1]))
+    with pytest.raises(TypeError):
+        m.fused_loss(cam, dict(batch, mask=(mask.to(torch.uint8) * 255)))
+    with pytest.raises(AssertionError):
+        m.fused_loss(cam, dict(batch, mask=mask[: h - 1]))
+
+
+def test_scaled_loss_backward_through_the_fused_node(cuda):
+    """(2 * loss).backward() gives 2 x the gradients (a weighted loss or a GradScaler upstream of the fused node)."""
+    w, h, n = 96, 64, 800
+    sc = scene(n, w, h, seed=4)
+    m1, cam1, batch1 = _model(sc, cuda)
+    m1.backward_fused(m1.fused_loss(cam1, batch1))
+    m2, cam2, batch2 = _model(sc, cuda)
+    (2.0 * m2.fused_loss(cam2, batch2)["loss"]).backward()
+    for name in PARAM_NAMES:
+        g1, g2 = m1.gauss_params[name].grad, m2.gauss_params[name].grad
+        assert_close(g2, 2.0 * g1, 2e-5, f"scaled grad {name}")       # atomics: summation order differs between runs
+
+
+# ---- optimiser ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1000, 1003])                               # 1003: group offsets not 16-byte aligned
+@pytest.mark.parametrize("flat_grads", [True, False])
+def test_qed_adam_six_instances_match_torch_adam(cuda, n, flat_grads):
+    """One QedAdam per parameter group (how Nerfstudio builds optimisers from config.py:44-68) == six torch.optim.Adam
+    on IDENTICAL gradients (two renders differ by atomic summation order, which Adam with eps = 1e-15 turns into
+    +-lr for near-zero gradients), with a scheduler on the means' rate.  flat_grads: the six gradients are adjacent
+    views of one allocation (what the projection backward produces -> one fused launch) or separate tensors."""
+    from qed_splatter_amd.model import FlatAdam, QedAdam
+    sc = scene(n, 96, 64, seed=8)
+    lrs = FlatAdam.DEFAULT_LRS
+    runs = []
+    for kind in ("qed", "torch"):
+        m, _, _ = _model(sc, cuda)
+        cls = QedAdam if kind == "qed" else torch.optim.Adam
+        opts = {k: cls([m.gauss_params[k]], lr=lrs[k], eps=1e-15) for k in m.group_names}
+        sched = torch.optim.lr_scheduler.LambdaLR(opts["means"], lambda s: 0.9 ** s)
+        gen = torch.Generator().manual_seed(5)
+        for _ in range(5):
+            flat = (torch.randn(m.flat_params.numel(), generator=gen) * 1e-3).to(cuda)
+            for k, b in zip(m.group_names, m.group_begin):
+                p = m.gauss_params[k]
+                g = flat[b:b + p.numel()].view(p.shape)
+                p.grad = g if flat_grads else g.clone()
+            for o in opts.values():
+                o.step()
+            sched.step()
+        runs.append((m, opts))
+    (mq, oq), (mt, ot) = runs
+    for k in PARAM_NAMES:
+        assert_close_elem(mq.gauss_params[k], mt.gauss_params[k], f"params {k} after 5 steps (n={n})", atol_frac=1e-6)
+    # checkpoint layout of torch.optim.Adam: per-group exp_avg / exp_avg_sq / step
+    sd_q, sd_t = oq["scales"].state_dict(), ot["scales"].state_dict()
+    assert float(sd_q["state"][0]["step"]) == float(sd_t["state"][0]["step"]) == 5.0
+    # (the kernel forms 1 - beta in fp32 from the fp32 beta: 1 - 0.999f differs from torch's double 1 - 0.999 by 1.3e-5)
+    assert_close(sd_q["state"][0]["exp_avg"], sd_t["state"][0]["exp_avg"], 1e-6, "exp_avg")
+    assert_close(sd_q["state"][0]["exp_avg_sq"], sd_t["state"][0]["exp_avg_sq"], 5e-5, "exp_avg_sq")
+    assert sd_q["param_groups"][0]["lr"] == sd_t["param_groups"][0]["lr"]
+    assert oq["means"].param_groups[0]["lr"] == pytest.approx(lrs["means"] * 0.9 ** 5)
+    # a group stepped on its own (out of step with the others) is updated on its own, with its own step count
+    for m_, o_ in ((mq, oq), (mt, ot)):
+        o_["quats"].step()
+    oq["quats"].flush()
+    assert_close_elem(mq.gauss_params["quats"], mt.gauss_params["quats"], "quats stepped alone", atol_frac=1e-6)
+    assert float(oq["quats"].state_dict()["state"][0]["step"]) == 6.0
+    oq["scales"].load_state_dict(sd_q)
+    assert float(oq["scales"].state_dict()["state"][0]["step"]) == 5.0
+
+
+def test_qed_adam_in_the_reference_call_sequence(cuda):
+    """zero_grad -> get_outputs -> get_metrics_dict -> get_loss_dict -> sum -> backward -> six optimisers: runs, lowers
+    the loss, and the six gradients arrive as adjacent views (one fused optimiser launch)."""
+    from qed_splatter_amd.model import FlatAdam, QedAdam
+    sc = scene(3000, 160, 112, seed=12)
+    m, cam, batch = _model(sc, cuda)
+    opts = {k: QedAdam([m.gauss_params[k]], lr=FlatAdam.DEFAULT_LRS[k], eps=1e-15) for k in m.group_names}
+    losses = []
+    for _ in range(12):
+        for o in opts.values():
+            o.zero_grad(set_to_none=True)
+        out = m.get_outputs(cam)
+        md = m.get_metrics_dict(out, batch)
+        ld = m.get_loss_dict(out, batch, md)
+        loss = sum(ld.values())
+        loss.backward()
+        assert m.flat_grad().data_ptr() == m.gauss_params["means"].grad.data_ptr()
+        for o in opts.values():
+            o.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0] and all(math.isfinite(x) for x in losses)
+    assert "rgb_psnr" in md and "depth_abs_rel" in md
+
+
+def test_flat_adam_refuses_stale_buffers_and_compact_gradients(cuda):
+    from qed_splatter_amd.model import FlatAdam
+    from qed_splatter_amd.parallel import allreduce_flat_grad
+    sc = scene(500, 64, 48, seed=3)
+    m, cam, batch = _model(sc, cuda)
+    opt = FlatAdam(m)
+    m.backward_fused(m.fused_loss(cam, batch, compact_sh_grad=True))
+    with pytest.raises(RuntimeError, match="compact"):
+        opt.step()                                                        # features_rest.grad is unwritten memory
+    with pytest.raises(RuntimeError, match="compact"):
+        allreduce_flat_grad(m, 1)
+    opt.step(fused_sh=True)
+    # model.to() replaces every Parameter's data: the model re-creates its flat buffer, the optimiser notices
+    m.cpu()
+    m.to(cuda)
+    assert m.gauss_params["scales"].data_ptr() == m.flat_params.data_ptr() + 4 * m.group_begin[1]
+    m.backward_fused(m.fused_loss(cam, batch))
+    with pytest.raises(RuntimeError, match="new flat parameter buffer"):
+        opt.step()

@@ -107,7 +107,7 @@ def test_oracle_schedule():
 # ---------------------------------------------------------------------------------------------------
 def _gpu_model(p, m, v, dev):
     from qed_splatter_amd.model import FlatAdam, QEDSplatterModel, QEDSplatterModelConfig
-    model = QEDSplatterModel(QEDSplatterModelConfig(), **{k: p[k].to(dev) for k in PARAM_NAMES})
+    model = QEDSplatterModel(QEDSplatterModelConfig.synthetic(), **{k: p[k].to(dev) for k in PARAM_NAMES})
     opt = FlatAdam(model)
     off = 0
     for name in model.group_names:

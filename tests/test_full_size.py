@@ -116,7 +116,7 @@ def test_config_b_fused_training_step_is_finite_and_reduces_loss(cuda):
     from qed_splatter_amd.model import FlatAdam, PinholeCameras, QEDSplatterModel, QEDSplatterModelConfig
     n, w, h = 500_000, 1920, 1080
     sc = _scene(n, w, h, 1235)
-    model = QEDSplatterModel(QEDSplatterModelConfig(sh_degree_interval=1), **{k: sc[k].to(cuda) for k in PARAM_NAMES})
+    model = QEDSplatterModel(QEDSplatterModelConfig.synthetic(sh_degree_interval=1), **{k: sc[k].to(cuda) for k in PARAM_NAMES})
     model.step = 30000
     K = sc["Ks"][0]
     cam = PinholeCameras(sc["camera_to_worlds"].to(cuda), float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), w, h)

@@ -392,7 +392,7 @@ def test_viewmat_gradient(cuda):
 # --------------------------------------------------------------------------------------------------
 def _model(sc, dev, **cfg_kw):
     from qed_splatter_amd.model import PinholeCameras, QEDSplatterModel, QEDSplatterModelConfig
-    cfg = QEDSplatterModelConfig(sh_degree_interval=1, **cfg_kw)
+    cfg = QEDSplatterModelConfig.synthetic(sh_degree_interval=1, **cfg_kw)
     m = QEDSplatterModel(cfg, **{k: sc[k].to(dev) for k in PARAM_NAMES})
     m.step = 100
     K = sc["Ks"][0]
@@ -423,7 +423,7 @@ def _oracle_step(sc, w, h, cfg, mask=None, radii=None):
                                ps["features_rest"], sc["camera_to_worlds"][:1].double(), sc["Ks"][:1].double(), w, h,
                                sc["background"].double(), rasterize_mode=cfg.rasterize_mode,
                                radii_override=radii, return_margin=True)
-    l_rgb = O.main_loss(out["rgb"], sc["gt_rgb"].double(), cfg.ssim_lambda)
+    l_rgb = O.main_loss(out["rgb"], sc["gt_rgb"].double(), cfg.ssim_lambda, mask)
     l_d = O.depth_l1_loss(out["depth"], sc["gt_depth"].double(), mask, cfg.depth_lambda)
     (l_rgb + l_d).backward()
     return out, l_rgb, l_d, ps
@@ -765,7 +765,7 @@ def test_adam_with_sh_gradients_rebuilt_for_models_with_fewer_coefficient_rows(c
     for fused in (False, True):
         ps = {k: sc[k].to(cuda) for k in PARAM_NAMES}
         ps["features_rest"] = ps["features_rest"][:, :rows].contiguous()
-        m = QEDSplatterModel(QEDSplatterModelConfig(sh_degree=cfg_degree, sh_degree_interval=1), **ps)
+        m = QEDSplatterModel(QEDSplatterModelConfig.synthetic(sh_degree=cfg_degree, sh_degree_interval=1), **ps)
         m.step = 100
         opt = FlatAdam(m)
         for _ in range(2):
@@ -923,8 +923,10 @@ def test_golden_fixtures(cuda, name):
     c = {k[len(name) + 1:]: gold[k] for k in gold.files if k.startswith(name + "/")}
     w, h = (int(v) for v in c["in_size"])
     deg = int(c["in_deg"])
-    cfg = QEDSplatterModelConfig(sh_degree=max(deg, 0) if deg >= 0 else 0, sh_degree_interval=1,
-                                 rasterize_mode=str(c["in_mode"]))
+    # the reference's exact lists: gsplat's 3-sigma squares, read back synchronously
+    cfg = QEDSplatterModelConfig.synthetic(sh_degree=max(deg, 0) if deg >= 0 else 0, sh_degree_interval=1,
+                                           rasterize_mode=str(c["in_mode"]), tight_tile_lists=False,
+                                           async_intersection_count=False)
     if deg > 0:
         cfg.sh_degree = deg
     m = QEDSplatterModel(cfg, **{k: torch.from_numpy(c[f"in_{k}"]).to(cuda) for k in PARAM_NAMES})

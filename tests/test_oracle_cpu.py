@@ -52,20 +52,55 @@ def test_depth_l1_matches_reference(kats):
     assert got == pytest.approx(float(kats["survey_loss"]), rel=1e-6)
 
 
-def test_product_get_loss_dict_matches_reference(kats):
-    """The product's host-side get_loss_dict mirror (pure torch) on the reference's vectors."""
+def test_product_get_loss_dict_has_no_cpu_path(kats):
+    """get_loss_dict runs fused HIP kernels (tests/test_api_path.py feeds the reference's vectors to them on the
+    GPU); handed CPU tensors it must fail loudly instead of quietly computing something else."""
+    from qed_splatter_amd._lib import QedSplatError
     from qed_splatter_amd.model import QEDSplatterModel, QEDSplatterModelConfig
     sc = scene(8, 16, 16, seed=1)
-    for i in kats["dl_cases"]:
-        cfg = QEDSplatterModelConfig(depth_lambda=float(kats[f"dl{i}_lambda"]), ssim_lambda=0.0)   # depth term only
-        m = QEDSplatterModel(cfg, **{k: sc[k] for k in PARAM_NAMES})
-        d_out = torch.from_numpy(kats[f"dl{i}_depth_out"])
-        d_gt = torch.from_numpy(kats[f"dl{i}_depth_gt"])
-        batch = {"depth_image": d_gt, "image": torch.zeros(*d_gt.shape[:2], 3)}
-        if kats[f"dl{i}_mask"].size:
-            batch["mask"] = torch.from_numpy(kats[f"dl{i}_mask"])
-        ld = m.get_loss_dict({"depth": d_out, "rgb": torch.zeros(*d_gt.shape[:2], 3)}, batch)
-        assert float(ld["depth_loss"]) == pytest.approx(float(kats[f"dl{i}_loss"]), rel=1e-6, abs=1e-9)
+    m = QEDSplatterModel(QEDSplatterModelConfig.synthetic(ssim_lambda=0.0), **{k: sc[k] for k in PARAM_NAMES})
+    d = torch.rand(16, 16, 1)
+    with pytest.raises(QedSplatError):
+        m.get_loss_dict({"depth": d, "rgb": torch.zeros(16, 16, 3), "background": torch.zeros(3)},
+                        {"depth_image": d, "image": torch.zeros(16, 16, 3)})
+
+
+def test_parent_class_helpers_on_the_host():
+    """The restated SplatfactoModel helpers that run on the host: resolution schedule, box-filter
+    downscaling of the ground truth (== oracle.resize_image), background colours, defaults."""
+    from qed_splatter_amd.model import QEDSplatterModel, QEDSplatterModelConfig
+    sc = scene(8, 16, 16, seed=1)
+    cfg = QEDSplatterModelConfig()
+    assert (cfg.num_downscales, cfg.resolution_schedule, cfg.background_color) == (2, 3000, "random")
+    assert (cfg.depth_lambda, cfg.output_depth_during_training) == (0.2, True)          # model.py:44,46
+    m = QEDSplatterModel(cfg, **{k: sc[k] for k in PARAM_NAMES})
+    for step, d in [(0, 4), (2999, 4), (3000, 2), (5999, 2), (6000, 1), (30000, 1)]:
+        m.step = step
+        assert m._get_downscale_factor() == d
+    m.step = 0
+    img = torch.rand(37, 50, 3)
+    assert torch.allclose(m.get_gt_img(img), O.resize_image(img, 4), atol=1e-6) and m.get_gt_img(img).shape == (9, 12, 3)
+    u8 = (img * 255).to(torch.uint8)
+    assert torch.allclose(m.get_gt_img(u8), O.resize_image(u8.float() / 255.0, 4), atol=1e-6)
+    m.eval()
+    assert m._get_downscale_factor() == 1 and m.get_gt_img(img).shape == img.shape
+    assert m._get_background_color().tolist() == pytest.approx([0.1490, 0.1647, 0.2157])
+    m.train()
+    assert m._get_background_color().shape == (3,)
+    with pytest.raises(NotImplementedError):
+        m._apply_bilateral_grid(img, 0, 37, 50)
+
+
+def test_oracle_masked_main_loss_and_scale_reg():
+    g = torch.Generator().manual_seed(0)
+    a, b = torch.rand(24, 30, 3, generator=g, dtype=torch.float64), torch.rand(24, 30, 3, generator=g, dtype=torch.float64)
+    mask = (torch.rand(24, 30, 1, generator=g) > 0.4).double()
+    # the parent multiplies both images by the mask, then takes plain L1 / SSIM of the products
+    assert float(O.main_loss(a, b, 0.2, mask)) == pytest.approx(float(O.main_loss(a * mask, b * mask, 0.2)), rel=1e-14)
+    assert float(O.main_loss(a, b, 0.0, mask)) == pytest.approx(float(((a - b).abs() * mask).mean()), rel=1e-12)
+    s = torch.log(torch.tensor([[1.0, 1.0, 1.0], [1.0, 2.0, 30.0], [0.1, 0.1, 5.0]], dtype=torch.float64))
+    assert float(O.scale_reg(s, 10, True, 10.0)) == pytest.approx(0.1 * (0.0 + 20.0 + 40.0) / 3, rel=1e-12)
+    assert float(O.scale_reg(s, 11, True, 10.0)) == 0.0 and float(O.scale_reg(s, 10, False)) == 0.0
 
 
 def test_depth_metrics_cross_check(kats):

@@ -45,6 +45,34 @@ def assert_close(a, b, tol=REL_TOL, what=""):
     return e
 
 
+def elem_stats(a: torch.Tensor, b: torch.Tensor, atol_frac: float = 1e-6):
+    """Element-wise comparison against the reference tensor b: the error of every element in units of its OWN
+    tolerance 1e-4 |b_i| + atol_frac max|b| (the north_star's "<= 1e-4 relative" with an absolute floor far below
+    anything that matters), plus the 99.9th percentile of the plain relative error where |b_i| is above the floor."""
+    a = a.detach().double().cpu().reshape(-1)
+    b = b.detach().double().cpu().reshape(-1)
+    if b.numel() == 0:
+        return dict(worst=0.0, p999_rel=0.0, n=0)
+    scale = float(b.abs().max()) + 1e-300
+    err = (a - b).abs()
+    worst = float((err / (REL_TOL * b.abs() + atol_frac * scale)).max())
+    big = b.abs() > 1e-3 * scale
+    rel = (err[big] / b.abs()[big]) if bool(big.any()) else torch.zeros(1, dtype=torch.float64)
+    k = max(int(math.ceil(0.999 * rel.numel())) - 1, 0)
+    return dict(worst=worst, p999_rel=float(rel.sort().values[k]), n=int(b.numel()))
+
+
+def assert_close_elem(a, b, what="", atol_frac: float = 1e-6):
+    """|a_i - b_i| <= 1e-4 |b_i| + atol_frac max|b| for EVERY element (a max-norm test lets a small-magnitude
+    element be 100 % wrong).  Prints the 99.9th-percentile relative error (visible with pytest -s / on failure)."""
+    st = elem_stats(a, b, atol_frac)
+    print(f"[parity] {what}: worst element at {st['worst']:.3f} of its tolerance, p99.9 relative error "
+          f"{st['p999_rel']:.2e} over {st['n']} elements")
+    assert st["worst"] <= 1.0, (f"{what}: an element is off by {st['worst']:.2f} x (1e-4 |b| + {atol_frac:.0e} max|b|); "
+                                f"p99.9 relative error {st['p999_rel']:.2e}")
+    return st
+
+
 def to_dev(d, dev, dtype=torch.float32):
     return {k: (v.to(dev, dtype) if torch.is_tensor(v) and v.is_floating_point() else
                 (v.to(dev) if torch.is_tensor(v) else v)) for k, v in d.items()}
