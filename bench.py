@@ -21,6 +21,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# committed rocprofv3 --pmc summaries the roofline objects quote (re-taken whenever the compositing kernels change)
+PMC_TRAFFIC = "r01_hbm_traffic_pmc.json"
+PMC_VALU = "r01_valu_issue_pmc.json"
 
 import torch  # noqa: E402
 
@@ -421,38 +424,42 @@ def main():
     if rank == 0:
         ms_step = dt2 / args.steps * 1e3
         P = w * h
-        # dominant kernel = compositing backward; algorithmic bytes: 92 B/intersection + 28 B/pixel
+        # dominant kernel = compositing backward; algorithmic bytes: 92 B per list entry the launch
+        # processed + 28 B per pixel.  The list shrinks as training proceeds (config.intersections ->
+        # intersections_after_timed_steps), so the mean of the two ends of the run is used.
         dom = "qed_composite_bwd"
         dom_ms = kern.get(dom, (0, float("nan")))[1]
-        alg_bytes = 92.0 * M_ref + 28.0 * P
+        M_proc = 0.5 * (M + M_end)
+        alg_bytes = 92.0 * M_proc + 28.0 * P
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
-        # HBM traffic of that kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
-        # cannot share a pass, and counters cannot be read from inside this process): per launch, with the
-        # guide's gfx950 correction (FETCH_SIZE doubled); null if the profile is not for this workload.
-        traffic = None
-        try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")))
-            kk = prof["kernels"]["qed::composite_bwd_kernel<4>"]
-            if (n, w, h) == (500_000, 1920, 1080):
-                traffic = (2.0 * kk["fetch_size_kb"] + kk["write_size_kb"]) * 1024.0
-        except (OSError, KeyError, ValueError):
-            pass
-        valu_frac = None
-        try:
-            vp = json.load(open(os.path.join(ROOT, "profiles", "r01_valu_issue_pmc.json")))
-            if (n, w, h) == (500_000, 1920, 1080):
+        # Counter-derived figures of that kernel come from COMMITTED rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
+        # cannot share a pass and counters cannot be read from inside this process): valid only for this workload and
+        # for the kernel version named in the profile; null otherwise.
+        traffic = valu_frac = prof_note = None
+        if (n, w, h) == (500_000, 1920, 1080):
+            try:
+                prof = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC)))
+                kk = prof["kernels"]["qed::composite_bwd_kernel<4>"]
+                traffic = (2.0 * kk["fetch_size_kb"] + kk["write_size_kb"]) * 1024.0    # gfx950: FETCH_SIZE counts half
+                vp = json.load(open(os.path.join(ROOT, "profiles", PMC_VALU)))
                 valu_frac = vp["kernels"]["qed::composite_bwd_kernel<4>"]["valu_issue_frac"]
-        except (OSError, KeyError, ValueError):
-            pass
+                prof_note = f"from committed profiles {PMC_TRAFFIC} / {PMC_VALU} (kernels {prof.get('kernels_version', '?')}), " \
+                            "not measured in this run"
+            except (OSError, KeyError, ValueError):
+                pass
         roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                "frac": achieved / 8000.0, "traffic": traffic, "valu_issue_frac_pmc": valu_frac,
-                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": dom_ms,
-                "note": "algorithmic bytes = 92 B x M + 28 B x P (SURVEY 8d) with M = the reference's list length "
-                        "(gsplat 3-sigma squares); this run lists only the tiles that can reach alpha >= 1/255 "
-                        "(config.intersections) and renders the same image.  The kernel is VALU-issue bound, not "
-                        "HBM bound: ~45 VALU instructions per pixel-Gaussian pair against 44 B per 256 pairs; "
-                        "measured traffic is BELOW the algorithmic bytes because culled / early-terminated list "
-                        "entries are never gathered.  See DESIGN.md section 4 ('Roofline honesty') for the VALU-side roofline."}
+                "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": prof_note,
+                "algorithmic_bytes_per_launch": alg_bytes, "list_entries_per_launch": M_proc,
+                "list_entries_reference": M_ref, "kernel_ms": dom_ms,
+                "note": "algorithmic bytes = 92 B x (list entries this launch processed) + 28 B x pixels (SURVEY 8d).  The "
+                        "reference (gsplat) would list list_entries_reference entries for the same image; this run lists "
+                        "only the tiles that can reach alpha >= 1/255.  The kernel is not HBM bound (see roofline_issue): "
+                        "measured traffic is BELOW the algorithmic bytes because culled / early-terminated entries are "
+                        "never gathered."}
+        roof_issue = {"bound": "valu_issue", "kernel": dom, "frac": valu_frac, "source": prof_note,
+                      "definition": "SQ_ACTIVE_INST_VALU / (SIMDs x GRBM_GUI_ACTIVE / 8 / 4) quad-cycles; a wave64 "
+                                    "cross-lane op (v_readlane 11.5, v_permlane*_swap 8.4, DPP 4.3 cycles) occupies the "
+                                    "pipe several times longer than a plain op (2.2-2.5): DESIGN.md section 4"}
         out = {
             "metric": "train iters/sec @ 1080p, 500k Gaussians (fwd + loss + bwd + Adam; camera-steps/s over all GPUs)",
             "value": world * args.steps / dt2, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
@@ -488,6 +495,7 @@ def main():
             "ms_per_step_percentiles": pct,
             "kernels_ms": {k: round(v[1], 4) for k, v in sorted(kern.items())},
             "roofline": roof,
+            "roofline_issue": roof_issue,
         }
         log(f"timed region: {ms_step:.3f} ms/step")
         if world == 1 and not args.no_api_path:

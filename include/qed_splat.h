@@ -11,8 +11,9 @@
  * Conventions
  *   - every pointer is a DEVICE pointer unless it is named h_*; all float data is fp32
  *   - the caller (PyTorch) owns every buffer: the library never allocates or frees device
- *     memory, never synchronises the stream and keeps no global mutable state besides a
- *     thread-local error string -> re-entrant per stream, safe to capture into a hipGraph
+ *     memory, never synchronises the stream, reads no environment variable and keeps no global
+ *     mutable state besides a thread-local error string -> re-entrant per stream, safe to capture
+ *     into a hipGraph
  *   - `stream` is a hipStream_t passed as void*
  *   - return value: 0 = ok, <0 = error (see QED_E_*); qed_last_error() describes it
  *   - C = cameras, N = Gaussians, M = tile/Gaussian intersections, T = tile_w * tile_h
@@ -171,11 +172,19 @@ int qed_tile_offsets(const uint64_t* sorted_keys, const int32_t* n_dev, int64_t 
  * sigma = .5(a dx^2 + c dy^2) + b dx dy, alpha = min(.999, o e^-sigma), skip if sigma < 0 or
  * alpha < 1/255, stop (Gaussian not applied) when T(1-alpha) <= 1e-4.
  * channels = 3 (RGB) or 4 (RGB+D).  backgrounds[C,channels] may be NULL (model.py:267-288 passes
- * none).  Outputs render[C,H,W,channels], alpha[C,H,W], last_ids[C,H,W] i32. */
+ * none).  Outputs render[C,H,W,channels], alpha[C,H,W], last_ids[C,H,W] i32.
+ * launch_flags: 0 in production.  One wave composites a whole tile, or one 8x8 quadrant of it for the
+ * last tiles of a launch (finer work items fill the end of the launch); QED_CL_TILE_WAVES / _QUADRANT_WAVES
+ * / _HALF_AND_HALF force one shape and QED_CL_NO_CULL turns the per-quadrant culling off -- results must
+ * not change (parity tests). */
+#define QED_CL_TILE_WAVES 1
+#define QED_CL_QUADRANT_WAVES 2
+#define QED_CL_HALF_AND_HALF 3
+#define QED_CL_NO_CULL 4
 int qed_composite_fwd(int32_t C, int32_t N, const float* splats, const int32_t* flatten_ids,
                       const int32_t* offsets, int32_t width, int32_t height, int32_t tile_w,
                       int32_t tile_h, int32_t channels, const float* backgrounds, float* render,
-                      float* alpha, int32_t* last_ids, void* stream);
+                      float* alpha, int32_t* last_ids, int32_t launch_flags, void* stream);
 
 /* ---- K7: alpha compositing backward ------------------------------------------------------------
  * Back-to-front replay from last_ids; per-pixel gradients are reduced across each 64-wide wave
@@ -186,7 +195,7 @@ int qed_composite_bwd(int32_t C, int32_t N, const float* splats, const int32_t* 
                       const int32_t* offsets, int32_t width, int32_t height, int32_t tile_w,
                       int32_t tile_h, int32_t channels, const float* backgrounds,
                       const float* render_alpha, const int32_t* last_ids, const float* v_render,
-                      const float* v_alpha, float* vsplat, void* stream);
+                      const float* v_alpha, float* vsplat, int32_t launch_flags, void* stream);
 
 /* ---- K8: fused image-space loss + gradient ------------------------------------------------------
  * Collapses model.py:295-297 (background composite + clamp), :304-306 (depth fix-up), :87-116

@@ -36,8 +36,8 @@ SIGNATURES = {
     "qed_tile_offsets": (C.c_int, [_P, _P, _L, _I, _I, _I, _P, _P]),
     "qed_bin_workspace_bytes": (_L, [_L, _L]),
     "qed_bin_tiles": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _L, _P, _P]),
-    "qed_composite_fwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
-    "qed_composite_bwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "qed_composite_fwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
+    "qed_composite_bwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "qed_loss_reduce": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qed_loss_grad": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _F, _F, _P]),
     "qed_sh_grad_from_views": (C.c_int, [_I, _I, _P, _P, _L, _P, _L, _I, _F, _P, _I, _P, _I, _P]),
@@ -77,6 +77,18 @@ SPLAT_FLOATS = 12
 VSPLAT_FLOATS = 16
 STATUS_WORDS = 4
 TILE = 16
+CL_TILE_WAVES, CL_QUADRANT_WAVES, CL_HALF_AND_HALF, CL_NO_CULL = 1, 2, 3, 4
+
+
+def composite_launch_flags() -> int:
+    """Test hooks (0 in production): QED_COMPOSITE_WAVES=tile|quadrant|half forces one launch shape of the
+    compositing kernels, QED_COMPOSITE_NOCULL=1 turns their quadrant culling off.  Read HERE, by the host layer; the
+    library itself reads no environment."""
+    f = {"t": CL_TILE_WAVES, "q": CL_QUADRANT_WAVES, "h": CL_HALF_AND_HALF}.get(
+        os.environ.get("QED_COMPOSITE_WAVES", "")[:1], 0)
+    if os.environ.get("QED_COMPOSITE_NOCULL", "")[:1] == "1":
+        f |= CL_NO_CULL
+    return f
 
 
 class QedSplatError(RuntimeError):

@@ -19,7 +19,7 @@
 //     Gaussian whose bound exceeds that (plus an fp32 rounding margin) cannot pass the alpha test at
 //     any pixel of the quadrant.  64-bit ballots give one survivor mask per quadrant; the loop walks
 //     the set bits with scalar instructions.  Results are identical to walking the whole list
-//     (QED_COMPOSITE_NOCULL=1 does that: tested bit-identical), at 1.5-1.65x the speed.
+//     (launch flag QED_CL_NO_CULL does that: tested bit-identical), at 1.5-1.65x the speed.
 //   * The inner loop is branch-free: 4 independent pixel chains per lane; every predicate ("done",
 //     "accepted", "valid") is a 64-bit scalar mask fed straight to v_cndmask.  The conic is
 //     pre-scaled by -log2(e) at staging so the exponent is a bare v_exp_f32 of a 5-instruction
@@ -28,7 +28,6 @@
 //     reduced over the 64 lanes with v_permlane32_swap / v_permlane16_swap (the number of live
 //     values halves per level) + one DPP row reduction, parked in LDS and flushed with ONE
 //     64-byte-row atomic request per (tile, Gaussian) that actually contributed.
-#include <stdlib.h>
 #include "qed_common.h"
 
 namespace qed {
@@ -37,6 +36,39 @@ typedef unsigned long long u64;
 
 constexpr int kBatch = 64;
 constexpr float kLog2e = 1.4426950408889634f;
+
+// How the current Gaussian's scalars reach all 64 lanes.  Measured on MI355X (scripts/ubench/xlane_cycles.hip): a
+// v_readlane_b32 costs 11-12 issue cycles of the SIMD's vector pipe (a plain VALU op 2.2-2.5), so ten of them per
+// Gaussian were 115 cycles -- more than the forward pass's arithmetic for that Gaussian.  Parking the batch's records
+// in LDS once (three 16-byte stores per lane) and fetching the current one with broadcast reads (every lane the same
+// address: two ds_read_b128 + one ds_read_b64) costs ~45 cycles of LDS time per Gaussian, which runs beside the
+// vector pipe instead of on it.  -DQED_READLANE_BCAST restores the v_readlane form (A/B builds).
+#ifndef QED_READLANE_BCAST
+#define QED_LDS_BCAST 1
+#endif
+constexpr int kRecFloats = 12;      // LDS record stride (floats): 10 used + the list id (backward) + 1 pad
+
+// Backward: how the 12 per-Gaussian gradient sums leave the wave.  Cross-lane instructions are the expensive ones
+// (v_permlane*_swap 8.4, DPP 4.3 issue cycles against 2.2-2.5 for a plain op), and a full in-wave reduction of 12 values
+// is 9 swaps + 9 adds + 12 DPP adds = ~150 cycles per (tile, Gaussian).  So only ONE halving level runs in the wave
+// (6 v_permlane16_swap + 6 adds: 32 partial sums per value); the partials of up to four Gaussians are parked in LDS
+// (stores are issued beside the vector pipe, not on it) and the flush -- one lane per (Gaussian, value) -- adds the 32
+// partials with plain adds before its atomic: ~87 cycles per Gaussian.  -DQED_K7_WAVE_REDUCE restores the in-wave
+// reduction (A/B builds).
+#if defined(QED_LDS_BCAST) && !defined(QED_K7_WAVE_REDUCE)
+#define QED_K7_LDS_REDUCE 1
+#endif
+#ifndef QED_PARK_SLOTS
+#define QED_PARK_SLOTS 3
+#endif
+#ifndef QED_PARK_SLOT_FLOATS
+#define QED_PARK_SLOT_FLOATS 448
+#endif
+constexpr int kParkSlots = QED_PARK_SLOTS;   // Gaussians parked per flush (16 lanes each)
+constexpr int kParkStride = 36;              // floats per (Gaussian, value): 32 partials + 4 pad, and
+constexpr int kParkSlot = QED_PARK_SLOT_FLOATS;   // floats per parked Gaussian (12 values, padded to a multiple of 64): the
+                                             // 16-byte reads of the flush (lane groups {0-3,12-15,20-27}, ...) then hit
+                                             // 16 different 4-bank groups
 
 // Diagnostic build only (-DQED_COMPOSITE_STATS; scripts/composite_stats.py): how much work each stage of the
 // compositing kernels really does.  Wave-uniform counts, added by lane 0.
@@ -182,7 +214,7 @@ __device__ __forceinline__ void fwd_quadrant(f2 pq, f2 XY, f2 AC, float B, float
 // One wave composites either a whole 16x16 tile (NQ = 4: four pixels per lane, one per 8x8 quadrant) or a
 // single quadrant q0 of it (NQ = 1: one pixel per lane).
 template <int CH, int NQ>
-__device__ __forceinline__ void fwd_tile(int tile, int qf, int C, const float4* __restrict__ splats,
+__device__ __forceinline__ void fwd_tile(int tile, int qf, float (*s_rec)[kRecFloats], int C, const float4* __restrict__ splats,
                                          const int* __restrict__ flatten_ids, const int* __restrict__ offsets, int width,
                                          int height, int tile_w, int tile_h, const float* __restrict__ backgrounds,
                                          float* __restrict__ render, float* __restrict__ alpha_out,
@@ -252,21 +284,21 @@ __device__ __forceinline__ void fwd_tile(int tile, int qf, int C, const float4* 
         const float gx = r0.x, gy = r0.y;
         const float gA = -0.5f * kLog2e * r0.z, gB = -kLog2e * r0.w, gC = -0.5f * kLog2e * r1.x;
         const float gop = r1.y, gr = r1.z, gg = r1.w, gb = r2.x, gd = r2.y;
+#ifdef QED_LDS_BCAST
+        if (km) {                                       // park this lane's (pre-scaled) Gaussian for the broadcast reads
+            *reinterpret_cast<float4*>(&s_rec[lane][0]) = make_float4(gx, gy, gA, gC);
+            *reinterpret_cast<float4*>(&s_rec[lane][4]) = make_float4(gB, gop, gr, gg);
+            *reinterpret_cast<float2*>(&s_rec[lane][8]) = make_float2(gb, gd);
+        }
+        __syncthreads();                                // single wave: orders the stores before the reads below
+#endif
         // issue the gather of the next batch (its ids arrived a batch ago) and the id load of the one after
         const size_t g_n = (size_t)rid_n;
         const float4 n0 = splats[3 * g_n], n1 = splats[3 * g_n + 1], n2 = splats[3 * g_n + 2];
         const int rid_nn = id_at(start + (b + 2) * kBatch + lane);
         const int batch_start = start + b * kBatch;
-        while (km) {
-            const int t = __builtin_ctzll(km);
-            const u64 bit = 1ull << t;
-            km &= ~bit;
-            // broadcast Gaussian t: ten v_readlane -> SGPRs
-            const f2 XY = {bcast(gx, t), bcast(gy, t)};
-            const f2 AC = {bcast(gA, t), bcast(gC, t)};
-            const float B = bcast(gB, t), op = bcast(gop, t);
-            const f2 col01 = {bcast(gr, t), bcast(gg, t)};
-            const f2 col23 = {bcast(gb, t), CH == 4 ? bcast(gd, t) : 0.f};
+        // composite Gaussian t (its scalars in XY .. col23): the quadrants whose mask holds it, in turn
+        auto visit = [&](int t, u64 bit, f2 XY, f2 AC, float B, float op, f2 col01, f2 col23) {
             QED_STAT(4, 1);
             int idx_v;                                  // one VGPR copy per Gaussian, not per quadrant
             asm volatile("v_mov_b32 %0, %1" : "=v"(idx_v) : "s"(batch_start + t));
@@ -280,11 +312,27 @@ __device__ __forceinline__ void fwd_tile(int tile, int qf, int C, const float4* 
                     km &= or_masks(mq);
                 }
             }
-            if (and_done() == ~0ull) {
-                all_done = true;
-                break;
-            }
+        };
+        // (A version that fetched the NEXT surviving record before compositing the current one -- two register sets,
+        // loop unrolled by two -- measured slower, 154 vs 150 us at 5 waves per SIMD and 146 vs 141 us at 6: the
+        // extra scalar bookkeeping costs more than the LDS latency the other resident waves already hide.)
+        while (km) {
+            const int t = __builtin_ctzll(km);
+            const u64 bit = 1ull << t;
+            km &= ~bit;
+#ifdef QED_LDS_BCAST
+            // broadcast Gaussian t: every lane reads the same LDS record
+            const float4 q0 = *reinterpret_cast<const float4*>(&s_rec[t][0]);
+            const float4 q1 = *reinterpret_cast<const float4*>(&s_rec[t][4]);
+            const float2 q2 = *reinterpret_cast<const float2*>(&s_rec[t][8]);
+            visit(t, bit, (f2){q0.x, q0.y}, (f2){q0.z, q0.w}, q1.x, q1.y, (f2){q1.z, q1.w}, (f2){q2.x, CH == 4 ? q2.y : 0.f});
+#else
+            // broadcast Gaussian t: ten v_readlane -> SGPRs
+            visit(t, bit, (f2){bcast(gx, t), bcast(gy, t)}, (f2){bcast(gA, t), bcast(gC, t)}, bcast(gB, t), bcast(gop, t),
+                  (f2){bcast(gr, t), bcast(gg, t)}, (f2){bcast(gb, t), CH == 4 ? bcast(gd, t) : 0.f});
+#endif
         }
+        all_done = and_done() == ~0ull;                 // (a finished quadrant empties its mask, so km ran out by itself)
         r0 = n0; r1 = n1; r2 = n2;                      // rotate the pipeline (the wave waits HERE, not above)
         rid_n = rid_nn;
         present = start + (b + 1) * kBatch + lane < end;
@@ -342,10 +390,17 @@ __device__ __forceinline__ void small_wave(int r, int n_small, int& t, int& q) {
 // quarter-size work items arrive last and fill the end of the launch, where whole-tile waves would leave most
 // wave slots idle (measured: 2.7 of 5 resident waves per SIMD on average with whole tiles only).
 #ifndef QED_K6_WAVES
-#define QED_K6_WAVES 5
+#define QED_K6_WAVES 6
 #endif
 #ifndef QED_K7_WAVES
 #define QED_K7_WAVES 4
+#endif
+// quadrant waves at the end of a launch, in units of the device's wave slots for the kernel (see big_tiles())
+#ifndef QED_K6_SMALL
+#define QED_K6_SMALL 2.5
+#endif
+#ifndef QED_K7_SMALL
+#define QED_K7_SMALL 1.2
 #endif
 template <int CH>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QED_K6_WAVES, QED_K6_WAVES)))
@@ -353,17 +408,18 @@ composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
                      const int* __restrict__ offsets, int width, int height, int tile_w, int tile_h,
                      const float* __restrict__ backgrounds, float* __restrict__ render, float* __restrict__ alpha_out,
                      int* __restrict__ last_ids, int n_big_flags) {
+    __shared__ __attribute__((aligned(16))) float s_rec[kBatch][kRecFloats];
     const int n_total = C * tile_w * tile_h;
     const int b = blockIdx.x;
     const int keep_all = (n_big_flags >> 30) << 2;      // test hook, see quadrant_masks
     const int n_big = n_big_flags & 0x3fffffff;
     if (b < n_big) {
-        fwd_tile<CH, 4>(xcd_remap(b, n_total), keep_all, C, splats, flatten_ids, offsets, width, height, tile_w, tile_h,
-                        backgrounds, render, alpha_out, last_ids);
+        fwd_tile<CH, 4>(xcd_remap(b, n_total), keep_all, s_rec, C, splats, flatten_ids, offsets, width, height, tile_w,
+                        tile_h, backgrounds, render, alpha_out, last_ids);
     } else {
         int t, q;
         small_wave(b - n_big, n_total - n_big, t, q);
-        fwd_tile<CH, 1>(xcd_remap(n_big + t, n_total), q | keep_all, C, splats, flatten_ids, offsets, width, height,
+        fwd_tile<CH, 1>(xcd_remap(n_big + t, n_total), q | keep_all, s_rec, C, splats, flatten_ids, offsets, width, height,
                         tile_w, tile_h, backgrounds, render, alpha_out, last_ids);
     }
 }
@@ -454,12 +510,41 @@ __device__ __forceinline__ void bwd_quadrant(f2 pq, f2 XY, f2 AC, float B, float
     g.s0 += vs;
 }
 
+// Flush of the parked Gaussians (QED_K7_LDS_REDUCE): one lane per (parked Gaussian, value) adds its 32 partials in a
+// fixed order, scales, and the wave issues one 64-byte row per Gaussian in a single atomic request.
+__device__ __forceinline__ void flush_parked(int n_parked, int pt0, int pt1, int pt2, int pt3,
+                                             const float* __restrict__ s_part, const float (*s_rec)[kRecFloats],
+                                             float* __restrict__ vsplat, int lane) {
+    QED_STAT(13, 1);
+    __syncthreads();                                    // single wave: orders the parking stores before these reads
+    const int grp = lane >> 4, k = lane & 15;
+    const int tg = grp == 0 ? pt0 : grp == 1 ? pt1 : grp == 2 ? pt2 : pt3;
+    if (grp < n_parked && k < 12) {
+        const float4* src = reinterpret_cast<const float4*>(s_part + grp * kParkSlot + k * kParkStride);
+        const float4 a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3], a4 = src[4], a5 = src[5], a6 = src[6], a7 = src[7];
+        const int id = __float_as_int(s_rec[tg][10]);
+        const float opac = s_rec[tg][5];
+        const float4 b0 = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+        const float4 b1 = make_float4(a2.x + a3.x, a2.y + a3.y, a2.z + a3.z, a2.w + a3.w);
+        const float4 b2 = make_float4(a4.x + a5.x, a4.y + a5.y, a4.z + a5.z, a4.w + a5.w);
+        const float4 b3 = make_float4(a6.x + a7.x, a6.y + a7.y, a6.z + a7.z, a6.w + a7.w);
+        const float4 c0 = make_float4(b0.x + b1.x, b0.y + b1.y, b0.z + b1.z, b0.w + b1.w);
+        const float4 c1 = make_float4(b2.x + b3.x, b2.y + b3.y, b2.z + b3.z, b2.w + b3.w);
+        float v = ((c0.x + c1.x) + (c0.y + c1.y)) + ((c0.z + c1.z) + (c0.w + c1.w));
+        if (k == 4 || k == 6) v *= 0.5f;
+        if (k == 7) v = -v * __builtin_amdgcn_rcpf(opac);   // (an IEEE division is 11 instructions for the whole wave)
+        if (v != 0.f) atomicAdd(&vsplat[(size_t)id * QED_VSPLAT_FLOATS + k], v);
+    }
+}
+
 // vsplat row layout (QED_VSPLAT_FLOATS = 16):
 //  0 v_x  1 v_y  2 |v_x|  3 |v_y|  4 v_conic_a  5 v_conic_b  6 v_conic_c  7 v_opacity  8 v_r  9 v_g  10 v_b  11 v_depth
 // Values 4, 6 and 7 are accumulated un-scaled (sum v_sigma dx^2, sum v_sigma dy^2, sum v_sigma) and
 // scaled by 0.5, 0.5 and -1/opacity once per (tile, Gaussian) at flush time.
 template <int CH, int NQ>
-__device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_acc)[12], int C, const float4* __restrict__ splats,
+__device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_acc)[12], float (*s_rec)[kRecFloats],
+                                         float* __restrict__ s_part, int C,
+                                         const float4* __restrict__ splats,
                                          const int* __restrict__ flatten_ids, const int* __restrict__ offsets, int width,
                                          int height, int tile_w, int tile_h, const float* __restrict__ backgrounds,
                                          const float* __restrict__ render_alpha, const int* __restrict__ last_ids,
@@ -555,21 +640,98 @@ __device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_acc)[12], i
         const float gx = r0.x, gy = r0.y, gca = r0.z, gcb = r0.w, gcc = r1.x;
         const float gop = r1.y, gr = r1.z, gg = r1.w, gb = r2.x, gd = r2.y;
         const int gid = rid;
+#ifdef QED_LDS_BCAST
+        if (km) {                                       // park this lane's Gaussian (+ its id, for the flush)
+            *reinterpret_cast<float4*>(&s_rec[lane][0]) = make_float4(gx, gy, gca, gcb);
+            *reinterpret_cast<float4*>(&s_rec[lane][4]) = make_float4(gcc, gop, gr, gg);
+            *reinterpret_cast<float4*>(&s_rec[lane][8]) = make_float4(gb, gd, __int_as_float(gid), 0.f);
+        }
+        __syncthreads();
+#endif
         const float4 n0 = splats[3 * (size_t)rid_n], n1 = splats[3 * (size_t)rid_n + 1],
                      n2 = splats[3 * (size_t)rid_n + 2];
         const int rid_nn = id_at(batch_hi - 2 * kBatch - lane);
+#ifdef QED_K7_LDS_REDUCE
+        int n_parked = 0, pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0;      // parked Gaussians (lane indices of this batch)
+        // this lane's slot in a parked Gaussian's partials: [value = 2 i + (row & 1)][half = row >> 1][lane & 15]
+        float* const park_lane = s_part + ((lane >> 4) & 1) * kParkStride + (lane >> 5) * 16 + (lane & 15);
+        while (km) {
+            const int t = __builtin_ctzll(km);
+            const u64 bit = 1ull << t;
+            km &= ~bit;
+#ifdef QED_LDS_BCAST
+            const float4 q0 = *reinterpret_cast<const float4*>(&s_rec[t][0]);
+            const float4 q1 = *reinterpret_cast<const float4*>(&s_rec[t][4]);
+            const float2 q2 = *reinterpret_cast<const float2*>(&s_rec[t][8]);
+            const f2 XY = {q0.x, q0.y};
+            const float ca = q0.z, cb = q0.w, cc = q1.x, op = q1.y;
+            const f2 col01 = {q1.z, q1.w};
+            const f2 col23 = {q2.x, CH == 4 ? q2.y : 0.f};
+#else
+            const f2 XY = {bcast(gx, t), bcast(gy, t)};
+            const float ca = bcast(gca, t), cb = bcast(gcb, t), cc = bcast(gcc, t), op = bcast(gop, t);
+            const f2 col01 = {bcast(gr, t), bcast(gg, t)};
+            const f2 col23 = {bcast(gb, t), CH == 4 ? bcast(gd, t) : 0.f};
+#endif
+            const f2 AC = {-0.5f * kLog2e * ca, -0.5f * kLog2e * cc};
+            const float B = -kLog2e * cb;
+            const f2 cab = {ca, cb}, cbc = {cb, cc};
+            const int idx = batch_hi - t;
+            GradAcc g;
+            g.vxy = g.c01 = g.rg = g.bd = (f2){0.f, 0.f};
+            g.ax = g.ay = g.c2 = g.s0 = 0.f;
+            u64 any_valid = 0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (!(mq[q] & bit)) continue;           // wave-uniform: this quadrant cannot see Gaussian t
+                QED_STAT(11, 1);
+                bwd_quadrant<CH>(pq[q], XY, AC, B, op, cab, cbc, col01, col23, idx, px[q], any_valid, g);
+            }
+            if (any_valid == 0) continue;
+            QED_STAT(12, 1);
+            {
+                float gv[12] = {g.vxy.x, g.vxy.y, g.ax, g.ay, g.c01.x, g.c01.y, g.c2, g.s0,
+                                g.rg.x, g.rg.y, g.bd.x, g.bd.y};
+                float* dst = park_lane + n_parked * kParkSlot;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    // a = [a.r0, b.r0, a.r2, b.r2], b = [a.r1, b.r1, a.r3, b.r3]: a + b holds, per 16-lane row, the sum of a
+                    // row pair of value 2 i (rows 0, 2) or 2 i + 1 (rows 1, 3)
+                    swap16(gv[2 * i], gv[2 * i + 1]);
+                    dst[i * 2 * kParkStride] = gv[2 * i] + gv[2 * i + 1];
+                }
+            }
+            if (n_parked == 0) pt0 = t; else if (n_parked == 1) pt1 = t; else if (n_parked == 2) pt2 = t; else pt3 = t;
+            if (++n_parked == kParkSlots) {
+                flush_parked(n_parked, pt0, pt1, pt2, pt3, s_part, s_rec, vsplat, lane);
+                n_parked = 0;
+            }
+        }
+        if (n_parked)                                   // before the next batch overwrites s_rec (ids, opacities)
+            flush_parked(n_parked, pt0, pt1, pt2, pt3, s_part, s_rec, vsplat, lane);
+#else
         u64 touched = 0;
         while (km) {
             const int t = __builtin_ctzll(km);
             const u64 bit = 1ull << t;
             km &= ~bit;
+#ifdef QED_LDS_BCAST
+            const float4 q0 = *reinterpret_cast<const float4*>(&s_rec[t][0]);
+            const float4 q1 = *reinterpret_cast<const float4*>(&s_rec[t][4]);
+            const float2 q2 = *reinterpret_cast<const float2*>(&s_rec[t][8]);
+            const f2 XY = {q0.x, q0.y};
+            const float ca = q0.z, cb = q0.w, cc = q1.x, op = q1.y;
+            const f2 col01 = {q1.z, q1.w};
+            const f2 col23 = {q2.x, CH == 4 ? q2.y : 0.f};
+#else
             const f2 XY = {bcast(gx, t), bcast(gy, t)};
             const float ca = bcast(gca, t), cb = bcast(gcb, t), cc = bcast(gcc, t), op = bcast(gop, t);
+            const f2 col01 = {bcast(gr, t), bcast(gg, t)};
+            const f2 col23 = {bcast(gb, t), CH == 4 ? bcast(gd, t) : 0.f};
+#endif
             const f2 AC = {-0.5f * kLog2e * ca, -0.5f * kLog2e * cc};
             const float B = -kLog2e * cb;
             const f2 cab = {ca, cb}, cbc = {cb, cc};
-            const f2 col01 = {bcast(gr, t), bcast(gg, t)};
-            const f2 col23 = {bcast(gb, t), CH == 4 ? bcast(gd, t) : 0.f};
             const int idx = batch_hi - t;
             GradAcc g;
             g.vxy = g.c01 = g.rg = g.bd = (f2){0.f, 0.f};
@@ -609,9 +771,14 @@ __device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_acc)[12], i
             }
             const int grp = lane >> 4, k = lane & 15;
             const int t = grp == 0 ? ts[0] : grp == 1 ? ts[1] : grp == 2 ? ts[2] : ts[3];
+#ifdef QED_LDS_BCAST
+            const int id = __float_as_int(s_rec[max(t, 0)][10]);
+            const float opac = s_rec[max(t, 0)][5];
+#else
             // all lanes take part in the shuffles (the source lane must be active)
             const int id = __shfl(gid, max(t, 0), 64);
             const float opac = __shfl(gop, max(t, 0), 64);
+#endif
             if (t >= 0 && k < 12) {
                 float v = s_acc[t][k];
                 if (k == 4 || k == 6) v *= 0.5f;
@@ -620,6 +787,7 @@ __device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_acc)[12], i
             }
         }
         __syncthreads();
+#endif
         r0 = n0; r1 = n1; r2 = n2;                      // rotate the pipeline
         rid = rid_n; rid_n = rid_nn;
         present = batch_hi - kBatch - lane >= start;
@@ -634,18 +802,25 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
                      const float* __restrict__ backgrounds, const float* __restrict__ render_alpha,
                      const int* __restrict__ last_ids, const float* __restrict__ v_render,
                      const float* __restrict__ v_alpha, float* __restrict__ vsplat, int n_big_flags) {
+#ifdef QED_K7_LDS_REDUCE
+    float (*s_acc)[12] = nullptr;
+    __shared__ __attribute__((aligned(16))) float s_part[kParkSlots * kParkSlot];
+#else
     __shared__ float s_acc[kBatch][12];
+    float* s_part = nullptr;
+#endif
+    __shared__ __attribute__((aligned(16))) float s_rec[kBatch][kRecFloats];
     const int n_total = C * tile_w * tile_h;
     const int b = blockIdx.x;
     const int keep_all = (n_big_flags >> 30) << 2;
     const int n_big = n_big_flags & 0x3fffffff;
     if (b < n_big) {
-        bwd_tile<CH, 4>(xcd_remap(b, n_total), keep_all, s_acc, C, splats, flatten_ids, offsets, width, height, tile_w, tile_h,
+        bwd_tile<CH, 4>(xcd_remap(b, n_total), keep_all, s_acc, s_rec, s_part, C, splats, flatten_ids, offsets, width, height, tile_w, tile_h,
                         backgrounds, render_alpha, last_ids, v_render, v_alpha, vsplat);
     } else {
         int t, q;
         small_wave(b - n_big, n_total - n_big, t, q);
-        bwd_tile<CH, 1>(xcd_remap(n_big + t, n_total), q | keep_all, s_acc, C, splats, flatten_ids, offsets, width, height,
+        bwd_tile<CH, 1>(xcd_remap(n_big + t, n_total), q | keep_all, s_acc, s_rec, s_part, C, splats, flatten_ids, offsets, width, height,
                         tile_w, tile_h, backgrounds, render_alpha, last_ids, v_render, v_alpha, vsplat);
     }
 }
@@ -672,35 +847,31 @@ extern "C" int qed_debug_composite_stats(unsigned long long* out, int reset) {
 // device's wave slots for the kernel (measured optimum at 1080p on MI355X: 1.9 x 5120 slots for the forward,
 // 1.2 x 4096 for the backward kernel), independent of the image size; an image with fewer tiles than that is
 // composited by quadrant waves only (it could not fill the device with whole-tile waves anyway).
-static long long big_tiles(long long n_tiles, double small_waves_per_slot, int waves_per_simd) {
-    // test hook (tests/test_gpu_parity.py): force one launch shape so that small images exercise all of them
-    if (const char* e = getenv("QED_COMPOSITE_WAVES")) {
-        if (e[0] == 't') return n_tiles;          // "tile": whole-tile waves only
-        if (e[0] == 'q') return 0;                // "quadrant": quadrant waves only
-        if (e[0] == 'h') return n_tiles / 2;      // "half": first half whole-tile, second half quadrant waves
+static long long big_tiles(long long n_tiles, double small_waves_per_slot, int waves_per_simd, int launch_flags) {
+    // QED_CL_* (include/qed_splat.h): tests force one launch shape so that small images exercise all of them
+    switch (launch_flags & 3) {
+        case QED_CL_TILE_WAVES: return n_tiles;
+        case QED_CL_QUADRANT_WAVES: return 0;
+        case QED_CL_HALF_AND_HALF: return n_tiles / 2;
+        default: break;
     }
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-                   ? prop.multiProcessorCount : 256;
-    }
+    // (asked of the runtime at every call: no state is kept in the library)
+    int dev = 0, n_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+        n_cu = 256;
     const long long slots = (long long)n_cu * 4 * waves_per_simd;
     const long long n_small = (long long)(small_waves_per_slot * (double)slots / 4.0);
     return n_tiles > n_small ? n_tiles - n_small : 0;
 }
 
-// test hook: QED_COMPOSITE_NOCULL=1 turns the quadrant culling off (bit 30 of the kernels' n_big argument)
-static int no_cull_flag() {
-    const char* e = getenv("QED_COMPOSITE_NOCULL");
-    return (e && e[0] == '1') ? (1 << 30) : 0;
-}
+// QED_CL_NO_CULL turns the quadrant culling off (bit 30 of the kernels' n_big argument)
+static int no_cull_flag(int launch_flags) { return (launch_flags & QED_CL_NO_CULL) ? (1 << 30) : 0; }
 
 extern "C" int qed_composite_fwd(int32_t C, int32_t N, const float* splats, const int32_t* flatten_ids,
                                  const int32_t* offsets, int32_t width, int32_t height, int32_t tile_w,
                                  int32_t tile_h, int32_t channels, const float* backgrounds, float* render,
-                                 float* alpha, int32_t* last_ids, void* stream) {
+                                 float* alpha, int32_t* last_ids, int32_t launch_flags, void* stream) {
     QED_REQUIRE(C >= 1 && N >= 0 && width > 0 && height > 0, "bad extents");
     QED_REQUIRE(channels == 3 || channels == 4, "channels must be 3 (RGB) or 4 (RGB+D)");
     QED_REQUIRE(tile_w == (width + QED_TILE - 1) / QED_TILE && tile_h == (height + QED_TILE - 1) / QED_TILE,
@@ -711,16 +882,16 @@ extern "C" int qed_composite_fwd(int32_t C, int32_t N, const float* splats, cons
     const long long grid = (long long)C * tile_w * tile_h;
     QED_REQUIRE(grid < (1ll << 31), "too many tiles");
     hipStream_t st = (hipStream_t)stream;
-    const long long n_big = big_tiles(grid, 1.9, QED_K6_WAVES);
+    const long long n_big = big_tiles(grid, QED_K6_SMALL, QED_K6_WAVES, launch_flags);
     const unsigned blocks = (unsigned)(n_big + 4 * (grid - n_big));
     if (channels == 4)
         hipLaunchKernelGGL(composite_fwd_kernel<4>, dim3(blocks), dim3(64), 0, st, C, (const float4*)splats,
                            flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render, alpha, last_ids,
-                           (int)n_big | no_cull_flag());
+                           (int)n_big | no_cull_flag(launch_flags));
     else
         hipLaunchKernelGGL(composite_fwd_kernel<3>, dim3(blocks), dim3(64), 0, st, C, (const float4*)splats,
                            flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render, alpha, last_ids,
-                           (int)n_big | no_cull_flag());
+                           (int)n_big | no_cull_flag(launch_flags));
     return check_launch("qed_composite_fwd");
 }
 
@@ -728,7 +899,7 @@ extern "C" int qed_composite_bwd(int32_t C, int32_t N, const float* splats, cons
                                  const int32_t* offsets, int32_t width, int32_t height, int32_t tile_w,
                                  int32_t tile_h, int32_t channels, const float* backgrounds,
                                  const float* render_alpha, const int32_t* last_ids, const float* v_render,
-                                 const float* v_alpha, float* vsplat, void* stream) {
+                                 const float* v_alpha, float* vsplat, int32_t launch_flags, void* stream) {
     QED_REQUIRE(C >= 1 && N >= 0 && width > 0 && height > 0, "bad extents");
     QED_REQUIRE(channels == 3 || channels == 4, "channels must be 3 (RGB) or 4 (RGB+D)");
     QED_REQUIRE(tile_w == (width + QED_TILE - 1) / QED_TILE && tile_h == (height + QED_TILE - 1) / QED_TILE,
@@ -739,15 +910,15 @@ extern "C" int qed_composite_bwd(int32_t C, int32_t N, const float* splats, cons
     const long long grid = (long long)C * tile_w * tile_h;
     QED_REQUIRE(grid < (1ll << 31), "too many tiles");
     hipStream_t st = (hipStream_t)stream;
-    const long long n_big = big_tiles(grid, 1.2, QED_K7_WAVES);
+    const long long n_big = big_tiles(grid, QED_K7_SMALL, QED_K7_WAVES, launch_flags);
     const unsigned blocks = (unsigned)(n_big + 4 * (grid - n_big));
     if (channels == 4)
         hipLaunchKernelGGL(composite_bwd_kernel<4>, dim3(blocks), dim3(64), 0, st, C, (const float4*)splats,
                            flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render_alpha, last_ids,
-                           v_render, v_alpha, vsplat, (int)n_big | no_cull_flag());
+                           v_render, v_alpha, vsplat, (int)n_big | no_cull_flag(launch_flags));
     else
         hipLaunchKernelGGL(composite_bwd_kernel<3>, dim3(blocks), dim3(64), 0, st, C, (const float4*)splats,
                            flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render_alpha, last_ids,
-                           v_render, v_alpha, vsplat, (int)n_big | no_cull_flag());
+                           v_render, v_alpha, vsplat, (int)n_big | no_cull_flag(launch_flags));
     return check_launch("qed_composite_bwd");
 }

@@ -779,11 +779,7 @@ extern "C" int qed_adam_step_sh(float* params, const float* grads, float* exp_av
     // 768 -> 121 us, 1024 -> 132 us).  Folding the leading groups into the same launch was slower in two
     // forms (their rows per pass: 139 us; grid-wide per-group passes + means rows per pass: 154 us): short spans
     // expose one memory latency each.
-    static const int grid_cap = [] {
-        const char* e = getenv("QED_ADAM_SH_GRID");
-        const int v = e ? atoi(e) : 0;
-        return v > 0 ? v : 768;
-    }();
+    constexpr int grid_cap = 768;
     const int n_chunks = (N + kShChunk - 1) / kShChunk;
     const unsigned grid = (unsigned)(n_chunks < grid_cap ? n_chunks : grid_cap);
     const size_t lds = ((size_t)kShChunk * RW + 4) * sizeof(float);

@@ -303,14 +303,14 @@ sort_global_hist_kernel(const KeyT* __restrict__ keys, const int* __restrict__ n
 
 // Measured on MI355X at M = 4.7e6 (round 1): the decoupled look-back pass takes 33 us against 28 us
 // for histogram + scan + scatter (its per-digit look-back walks predecessors one ~1.5 us global load
-// at a time), so the three-kernel pass is the default; QED_SORT_LOOKBACK=1 selects the look-back pass.
-static bool sort_use_lookback() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("QED_SORT_LOOKBACK");
-        v = (e != nullptr && e[0] == '1') ? 1 : 0;
-    }
-    return v == 1;
+// at a time), so the three-kernel pass is what the library runs; a build with -DQED_SORT_LOOKBACK selects the
+// look-back pass (a compile-time choice: the library reads no environment and keeps no state).
+static constexpr bool sort_use_lookback() {
+#ifdef QED_SORT_LOOKBACK
+    return true;
+#else
+    return false;
+#endif
 }
 
 template <typename KeyT>

@@ -301,7 +301,7 @@ class _Composite(torch.autograd.Function):
         bg = _f32c(backgrounds, "backgrounds") if backgrounds is not None else None
         L.check(lib.qed_composite_fwd(C, N, L.ptr(splats), L.ptr(flatten_ids), L.ptr(offsets), width, height, tile_w,
                                       tile_h, channels, L.ptr(bg), L.ptr(render), L.ptr(alpha), L.ptr(last_ids),
-                                      _stream()), "qed_composite_fwd")
+                                      L.composite_launch_flags(), _stream()), "qed_composite_fwd")
         ctx.save_for_backward(splats, flatten_ids, offsets, alpha, last_ids, bg)
         ctx.meta = (C, N, width, height, tile_w, tile_h, channels, absgrad)
         ctx.means2d_ref = means2d
@@ -322,7 +322,8 @@ class _Composite(torch.autograd.Function):
         vsplat = torch.zeros(C * N, R, dtype=torch.float32, device=dev)
         L.check(lib.qed_composite_bwd(C, N, L.ptr(splats), L.ptr(flatten_ids), L.ptr(offsets), width, height, tile_w,
                                       tile_h, channels, L.ptr(bg), L.ptr(alpha), L.ptr(last_ids), L.ptr(v_render),
-                                      L.ptr(v_alpha), L.ptr(vsplat), _stream()), "qed_composite_bwd")
+                                      L.ptr(v_alpha), L.ptr(vsplat), L.composite_launch_flags(), _stream()),
+                "qed_composite_bwd")
         v3 = vsplat.view(C, N, R)
         v_means2d = v3[..., 0:2]
         v_conics = v3[..., 4:7]

@@ -148,3 +148,101 @@ def test_intersection_buffer_overflow_is_detected_and_regrown(cuda):
     assert int(i["n_isects"]) == M and ws.capacity >= M
     assert torch.equal(r, r_ref) and torch.equal(a, a_ref)
     assert int(ws.status[0]) == 0
+
+
+# ---- oracle comparisons at the production density and on the production launch shape ----
+def test_cpu_baseline_sample_fused_step_matches_the_oracle(cuda):
+    """The workload bench.py times the CPU oracle on (config B / 16: 31 250 Gaussians @ 480 x 270, the same
+    Gaussians-per-pixel density as config B): one fused HIP training step against the fp64 oracle, losses and all
+    six gradients element by element.  Gaussians listed in a tile that holds a threshold pixel (an alpha / T
+    decision within fp32 rounding of its cut, which may legitimately flip) are excluded -- and counted."""
+    from oracle import splat_oracle as O
+    from qed_splatter_amd.model import PinholeCameras, QEDSplatterModel, QEDSplatterModelConfig
+    from tests.test_gpu_parity import MARGIN_E2E, _gaussians_in_tiles_of
+    from tests.util import elem_stats
+    n, w, h = 31_250, 480, 270
+    sc = _scene(n, w, h, 1235)
+    cfg = QEDSplatterModelConfig.synthetic(sh_degree_interval=1)
+    m = QEDSplatterModel(cfg, **{k: sc[k].to(cuda) for k in PARAM_NAMES})
+    m.step = 30000
+    K = sc["Ks"][0]
+    cam = PinholeCameras(sc["camera_to_worlds"].to(cuda), float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), w, h)
+    batch = {"image": sc["gt_rgb"].to(cuda), "depth_image": sc["gt_depth"].to(cuda)}
+    lf = m.fused_loss(cam, batch)
+    m.backward_fused(lf)
+    ps = {k: sc[k].double().requires_grad_(True) for k in PARAM_NAMES}
+    ref = O.splatfacto_outputs(ps["means"], ps["scales"], ps["quats"], ps["opacities"], ps["features_dc"],
+                               ps["features_rest"], sc["camera_to_worlds"][:1].double(), sc["Ks"][:1].double(), w, h,
+                               sc["background"].double(), radii_override=m.info["radii"].cpu(), return_margin=True)
+    l_rgb = O.main_loss(ref["rgb"], sc["gt_rgb"].double(), cfg.ssim_lambda)
+    l_d = O.depth_l1_loss(ref["depth"], sc["gt_depth"].double(), None, cfg.depth_lambda)
+    (l_rgb + l_d).backward()
+    assert float(lf["main_loss"]) == pytest.approx(float(l_rgb), rel=1e-4)
+    assert float(lf["depth_loss"]) == pytest.approx(float(l_d), rel=1e-4)
+    safe = ref["info"]["margin"][0] > MARGIN_E2E
+    keep = ~_gaussians_in_tiles_of(ref["info"], ~safe, n)
+    excluded = 1.0 - float(keep.float().mean())
+    print(f"[parity] threshold pixels {1.0 - float(safe.float().mean()):.2e}; Gaussians excluded {excluded:.3%}")
+    assert excluded < 0.25
+    for name in PARAM_NAMES:
+        st = elem_stats(m.gauss_params[name].grad.cpu()[keep], ps[name].grad[keep], atol_frac=1e-5)
+        print(f"[parity] grad {name}: worst element at {st['worst']:.2f} of (1e-4 |b| + 1e-5 max|b|), "
+              f"p99.9 relative error {st['p999_rel']:.2e}")
+        assert st["worst"] <= 1.0, (name, st)
+
+
+def test_config_b_launch_shapes_agree_and_random_tiles_match_the_oracle(cuda, monkeypatch):
+    """Config B at full size on the production (mixed whole-tile / quadrant) launch: (i) forcing whole-tile waves
+    only gives bit-identical images / alphas / last ids and gradients equal up to atomic summation order; (ii) 16
+    random tiles of the full-size render against oracle.composite_tiles run on exactly those tiles' lists (the
+    oracle cannot composite 8 160 tiles, but a tile only depends on its own run of the sorted list)."""
+    from oracle import splat_oracle as O
+    n, w, h = 500_000, 1920, 1080
+    sc = _scene(n, w, h, 1235)
+    g = torch.Generator().manual_seed(2)
+    wgt = torch.rand(1, h, w, 4, generator=g).to(cuda)
+
+    def run():
+        r, a, info, ps = _render(sc, cuda, w, h, need_grad=True)
+        grads = torch.autograd.grad((r * wgt).sum() + a.sum(), [ps[k] for k in PARAM_NAMES])
+        return r.detach(), a.detach(), info, grads
+
+    monkeypatch.delenv("QED_COMPOSITE_WAVES", raising=False)
+    r0, a0, i0, g0 = run()
+    monkeypatch.setenv("QED_COMPOSITE_WAVES", "tile")
+    r1, a1, i1, g1 = run()
+    monkeypatch.delenv("QED_COMPOSITE_WAVES", raising=False)
+    assert torch.equal(r0, r1) and torch.equal(a0, a1) and torch.equal(i0["last_ids"], i1["last_ids"])
+    for k, x, y in zip(PARAM_NAMES, g0, g1):
+        assert float((x - y).abs().max()) <= 2e-5 * (float(y.abs().max()) + 1e-30), k
+    # (ii) tiles: the GPU's own projected splats (fp32) feed the oracle in fp64, so only compositing is compared
+    tw, th = (w + 15) // 16, (h + 15) // 16
+    offs = i0["isect_offsets"].flatten().cpu().tolist() + [int(i0["n_isects"])]
+    fid = i0["flatten_ids"].cpu().long()
+    m2, con = i0["means2d"][0].cpu().double(), i0["conics"][0].cpu().double()
+    col = torch.cat([i0["colors"][0], i0["depths"][0][:, None]], dim=1).cpu().double()
+    opa = i0["opacities"][0].cpu().double()
+    lens = torch.tensor([offs[t + 1] - offs[t] for t in range(tw * th)])
+    pick = torch.randperm(tw * th, generator=g)[:12].tolist() + lens.topk(2).indices.tolist() + [tw * th - 1, tw * (th - 1)]
+    n_bad = n_pix = 0
+    for t in pick:                                                        # 12 random + the 2 longest + 2 cut by the border
+        ty, tx = divmod(t, tw)
+        ids = fid[offs[t]:offs[t + 1]]
+        if ids.numel() == 0:
+            continue
+        tile_w_px, tile_h_px = min(16, w - 16 * tx), min(16, h - 16 * ty)
+        shift = torch.tensor([16.0 * tx, 16.0 * ty], dtype=torch.float64)
+        rr, aa, ll, margin = O.composite_tiles((m2[ids] - shift)[None], con[ids][None], col[ids][None], opa[ids][None],
+                                               tile_w_px, tile_h_px, 16, torch.zeros(1, 1, 1, dtype=torch.int32),
+                                               torch.arange(ids.numel(), dtype=torch.int32), return_margin=True)
+        ys, xs = slice(16 * ty, 16 * ty + tile_h_px), slice(16 * tx, 16 * tx + tile_w_px)
+        safe = margin[0] > 1e-5
+        n_bad += int((~safe).sum())
+        n_pix += safe.numel()
+        got_r, got_a, got_l = r0[0, ys, xs].cpu().double(), a0[0, ys, xs, 0].cpu().double(), i0["last_ids"][0, ys, xs].cpu()
+        scale = float(rr.abs().amax()) + 1e-30
+        assert float((got_r - rr[0])[safe].abs().max()) <= 1e-4 * scale, t
+        assert float((got_a - aa[0, ..., 0])[safe].abs().max()) <= 1e-4, t
+        want_l = torch.where(aa[0, ..., 0] > 0, ll[0].long() + offs[t], torch.zeros_like(ll[0].long()))
+        assert torch.equal(got_l.long()[safe], want_l[safe]), t
+    assert n_bad <= 0.002 * n_pix
