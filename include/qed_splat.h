@@ -154,13 +154,22 @@ int qed_sort_pairs(uint64_t* keys, int32_t* vals, uint64_t* keys_alt, int32_t* v
  * Overflow (M > capacity) sets status[0] = M and leaves M = 0.  workspace: qed_bin_workspace_bytes.
  * splats (may be NULL): the records of qed_project_fwd; when given, each Gaussian's tile rectangle is
  * taken from record slot 11 (the rectangle project_fwd counted) instead of being recomputed from
- * means2d / radii -- REQUIRED when project_fwd ran with QED_F_TIGHT_TILES. */
+ * means2d / radii -- REQUIRED when project_fwd ran with QED_F_TIGHT_TILES.
+ * mode: QED_BIN_TWO_STAGE is the pipeline above.  QED_BIN_TILE_SORT gives the same list another way: entries
+ * are emitted in slot order and stably sorted on the tile bits, then one workgroup per tile sorts its run by
+ * the 32 depth bits (stable, in LDS for runs of <= 2048 entries, through global scratch beyond) -- no global
+ * sort of the C*N slots, 10 launches instead of 23, faster while the runs are short.  QED_BIN_AUTO picks by
+ * capacity per tile.  block_sums (may be NULL): qed_project_fwd's per-256-slot sums of tiles_per_gauss, which
+ * save the tile-sort pipeline one counting launch. */
+#define QED_BIN_AUTO 0
+#define QED_BIN_TWO_STAGE 1
+#define QED_BIN_TILE_SORT 2
 int64_t qed_bin_workspace_bytes(int64_t n_slots, int64_t capacity);
 int qed_bin_tiles(int32_t N, int32_t C, const float* means2d, const int32_t* radii, const float* depths,
-                  const int32_t* tiles_per_gauss, const float* splats, int32_t tile_w, int32_t tile_h,
-                  int64_t capacity, int32_t* flatten_ids, int32_t* offsets, int32_t* n_isect,
-                  uint64_t* isect_ids, void* workspace, int64_t workspace_bytes, int32_t* status,
-                  void* stream);
+                  const int32_t* tiles_per_gauss, const float* splats, const int32_t* block_sums,
+                  int32_t tile_w, int32_t tile_h, int64_t capacity, int32_t mode, int32_t* flatten_ids,
+                  int32_t* offsets, int32_t* n_isect, uint64_t* isect_ids, void* workspace,
+                  int64_t workspace_bytes, int32_t* status, void* stream);
 
 /* ---- K5: tile offsets --------------------------------------------------------------------------
  * offsets[C*T + 1]: offsets[t] = first sorted index whose (cam,tile) >= t; offsets[C*T] = M. */

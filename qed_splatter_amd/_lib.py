@@ -35,7 +35,7 @@ SIGNATURES = {
     "qed_sort_pairs": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P, _L, _P, _P]),
     "qed_tile_offsets": (C.c_int, [_P, _P, _L, _I, _I, _I, _P, _P]),
     "qed_bin_workspace_bytes": (_L, [_L, _L]),
-    "qed_bin_tiles": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _L, _P, _P]),
+    "qed_bin_tiles": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P, _P, _P, _P, _L, _P, _P]),
     "qed_composite_fwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
     "qed_composite_bwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "qed_loss_reduce": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -78,6 +78,12 @@ VSPLAT_FLOATS = 16
 STATUS_WORDS = 4
 TILE = 16
 CL_TILE_WAVES, CL_QUADRANT_WAVES, CL_HALF_AND_HALF, CL_NO_CULL = 1, 2, 3, 4
+BIN_AUTO, BIN_TWO_STAGE, BIN_TILE_SORT = 0, 1, 2
+
+
+def bin_mode() -> int:
+    """Test / measurement hook (auto in production): QED_BIN_MODE=two_stage|tile_sort forces one binning pipeline."""
+    return {"two": BIN_TWO_STAGE, "til": BIN_TILE_SORT}.get(os.environ.get("QED_BIN_MODE", "")[:3], BIN_AUTO)
 
 
 def composite_launch_flags() -> int:

@@ -655,14 +655,24 @@ __device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_acc)[12], f
         int n_parked = 0, pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0;      // parked Gaussians (lane indices of this batch)
         // this lane's slot in a parked Gaussian's partials: [value = 2 i + (row & 1)][half = row >> 1][lane & 15]
         float* const park_lane = s_part + ((lane >> 4) & 1) * kParkStride + (lane >> 5) * 16 + (lane & 15);
+#ifdef QED_LDS_BCAST
+        // The record of the NEXT surviving Gaussian is requested right after the current one's pixels are done, into
+        // the very registers they were read from: the LDS latency (~130 cycles) then runs beside the reduction of the
+        // current Gaussian instead of in front of the next one's arithmetic.
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
+        float2 q2 = make_float2(0.f, 0.f);
+        auto fetch = [&](int tt) {
+            q0 = *reinterpret_cast<const float4*>(&s_rec[tt][0]);
+            q1 = *reinterpret_cast<const float4*>(&s_rec[tt][4]);
+            q2 = *reinterpret_cast<const float2*>(&s_rec[tt][8]);
+        };
+        if (km) fetch(__builtin_ctzll(km));
+#endif
         while (km) {
             const int t = __builtin_ctzll(km);
             const u64 bit = 1ull << t;
             km &= ~bit;
 #ifdef QED_LDS_BCAST
-            const float4 q0 = *reinterpret_cast<const float4*>(&s_rec[t][0]);
-            const float4 q1 = *reinterpret_cast<const float4*>(&s_rec[t][4]);
-            const float2 q2 = *reinterpret_cast<const float2*>(&s_rec[t][8]);
             const f2 XY = {q0.x, q0.y};
             const float ca = q0.z, cb = q0.w, cc = q1.x, op = q1.y;
             const f2 col01 = {q1.z, q1.w};
@@ -687,6 +697,9 @@ __device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_acc)[12], f
                 QED_STAT(11, 1);
                 bwd_quadrant<CH>(pq[q], XY, AC, B, op, cab, cbc, col01, col23, idx, px[q], any_valid, g);
             }
+#ifdef QED_LDS_BCAST
+            if (km) fetch(__builtin_ctzll(km));
+#endif
             if (any_valid == 0) continue;
             QED_STAT(12, 1);
             {

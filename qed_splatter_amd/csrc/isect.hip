@@ -174,13 +174,284 @@ __global__ void __launch_bounds__(256)
 count_sorted_kernel(int n_slots, const int* __restrict__ order, const int* __restrict__ tiles_per_gauss,
                     int* __restrict__ block_sums) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    int v = i < n_slots ? tiles_per_gauss[order[i]] : 0;
+    int v = i < n_slots ? tiles_per_gauss[order ? order[i] : i] : 0;
     __shared__ int wsum[4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x == 0) block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+
+// ---- per-tile depth sort (qed_bin_tiles, mode QED_BIN_TILE_SORT) ------------------------------------------------
+// After a STABLE sort of the list on the (camera|tile) bits alone -- entries emitted in slot order -- every tile's run
+// holds its Gaussians in slot order.  One workgroup per tile then sorts its run by the 32 depth bits with a stable LSD
+// radix sort (ties stay in slot order): the same list as sorting 64-bit (tile, depth) keys, without ever sorting the
+// C N slots globally (12 launch-latency-bound launches at config B).  Runs of up to kTileSortItems entries are sorted
+// entirely in LDS with the ranking scheme of sort_scatter_kernel (wave-striped keys in registers, 64-bit ballot
+// match, per-wave counters); longer runs go through global scratch, 256 entries at a time -- slow, but any length is
+// handled.  A pass whose digit is the same for the whole run (typical of the high depth byte) is skipped.
+constexpr int kTileSortKpt = 8;
+constexpr int kTileSortItems = 256 * kTileSortKpt;
+
+// stable rank of `valid` lanes' digit d within the wave, on top of the wave's running counters cnt[256] (LDS)
+__device__ __forceinline__ int wave_digit_rank(bool valid, unsigned d, int* cnt, int lane) {
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const unsigned long long bal = __ballot(bit);
+        peers &= bit ? bal : ~bal;
+    }
+    int r = 0;
+    if (valid) {
+        r = cnt[d] + __popcll(peers & ((1ull << lane) - 1ull));
+        if ((peers >> lane) == 1ull) cnt[d] = r + 1;      // highest peer publishes (LDS ops of a wave complete in order)
+    }
+    return r;
+}
+
+
+// Short runs (<= kTileWaveItems entries: nearly every tile at config B): ONE WAVE per tile, four tiles per workgroup,
+// no workgroup barrier anywhere -- the keys stay in registers (8 rows of 64), ranks come from the same ballot match, the
+// 256 digit totals are scanned by the wave itself (four digits per lane), and a whole generation of tiles is resident
+// at once (32 waves per CU).  Longer runs are left to tile_depth_sort_kernel.
+constexpr int kTileWaveKpt = 8;
+constexpr int kTileWaveItems = 64 * kTileWaveKpt;
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ void __launch_bounds__(256)
+tile_depth_sort_wave_kernel(const int* __restrict__ offsets, const int* __restrict__ vals_in,
+                            const float* __restrict__ depths, int* __restrict__ vals_out, int n_tiles_total) {
+    __shared__ unsigned s_keys[4][kTileWaveItems];
+    __shared__ int s_vals[4][kTileWaveItems];
+    __shared__ __attribute__((aligned(16))) int s_cnt[4][256];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int tile = blockIdx.x * 4 + wid;
+    if (tile >= n_tiles_total) return;
+    const int start = offsets[tile], n = offsets[tile + 1] - start;
+    if (n <= 0 || n > kTileWaveItems) return;
+    if (n == 1) {
+        if (lane == 0) vals_out[start] = vals_in[start];
+        return;
+    }
+    const int rows = (n + 63) >> 6;                        // wave-uniform
+    unsigned key[kTileWaveKpt];
+    int val[kTileWaveKpt], rank[kTileWaveKpt];
+#pragma unroll
+    for (int k = 0; k < kTileWaveKpt; ++k) {
+        if (k >= rows) break;
+        const int li = k * 64 + lane;
+        val[k] = vals_in[start + (li < n ? li : n - 1)];
+    }
+#pragma unroll
+    for (int k = 0; k < kTileWaveKpt; ++k) {
+        if (k >= rows) break;
+        key[k] = __float_as_uint(depths[val[k]]);
+    }
+    int* cnt = s_cnt[wid];
+    unsigned* skeys = s_keys[wid];
+    int* svals = s_vals[wid];
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 8 * pass;
+        *reinterpret_cast<int4*>(&cnt[4 * lane]) = make_int4(0, 0, 0, 0);
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < kTileWaveKpt; ++k) {
+            if (k >= rows) break;
+            rank[k] = wave_digit_rank(k * 64 + lane < n, (key[k] >> shift) & 255u, cnt, lane);
+        }
+        wave_lds_fence();
+        // lane l owns digits 4 l .. 4 l + 3: totals -> exclusive bases
+        const int4 c = *reinterpret_cast<const int4*>(&cnt[4 * lane]);
+        const bool skip = __ballot(c.x == n || c.y == n || c.z == n || c.w == n) != 0ull;   // one digit holds the run
+        const bool last = pass == 3;
+        if (skip && !last) continue;
+        const int tot = c.x + c.y + c.z + c.w;
+        int x = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        const int b = x - tot;
+        *reinterpret_cast<int4*>(&cnt[4 * lane]) = make_int4(b, b + c.x, b + c.x + c.y, b + c.x + c.y + c.z);
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < kTileWaveKpt; ++k) {
+            if (k >= rows) break;
+            const int li = k * 64 + lane;
+            if (li < n) {
+                const int pos = skip ? li : cnt[(key[k] >> shift) & 255u] + rank[k];
+                if (last) vals_out[start + pos] = val[k];
+                else { skeys[pos] = key[k]; svals[pos] = val[k]; }
+            }
+        }
+        if (last) break;
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < kTileWaveKpt; ++k) {
+            if (k >= rows) break;
+            const int li = k * 64 + lane;
+            if (li < n) { key[k] = skeys[li]; val[k] = svals[li]; }
+        }
+        wave_lds_fence();
+    }
+}
+
+__global__ void __launch_bounds__(256)
+tile_depth_sort_kernel(const int* __restrict__ offsets, const int* __restrict__ vals_in, const float* __restrict__ depths,
+                       int* __restrict__ vals_out, unsigned* __restrict__ gk0, unsigned* __restrict__ gk1,
+                       int* __restrict__ gv0, int* __restrict__ gv1, int n_tiles_total) {
+    __shared__ unsigned s_keys[kTileSortItems];
+    __shared__ int s_vals[kTileSortItems];
+    __shared__ int s_cnt[4][256];
+    __shared__ int s_base[256];
+    __shared__ int s_wsum[4];
+    __shared__ int s_skip[4];                           // per pass: one digit holds the whole run
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  for (int tile = blockIdx.x; tile < n_tiles_total; tile += gridDim.x) {
+    const int start = offsets[tile], n = offsets[tile + 1] - start;
+    if (n <= kTileWaveItems) continue;                  // short runs: tile_depth_sort_wave_kernel
+    __syncthreads();                                    // (the previous tile's LDS reads are done)
+    // exclusive scan over the 256 digits of per-digit totals held one per thread; returns this digit's base
+    auto digit_scan = [&](int tot) {
+        int x = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) s_wsum[wid] = x;
+        __syncthreads();
+        int wb = 0;
+        for (int w = 0; w < wid; ++w) wb += s_wsum[w];
+        return wb + x - tot;
+    };
+    if (n <= kTileSortItems) {
+        // ---- LDS path: the run is dealt to the four waves as contiguous quarters of Q entries (a multiple of 64):
+        // wave w owns [w Q, (w + 1) Q), item k of lane l = w Q + 64 k + l; every wave works, whatever the run length ----
+        unsigned key[kTileSortKpt];
+        int val[kTileSortKpt], rank[kTileSortKpt];
+        const int Q = ((n + 255) >> 8) << 6;
+        const int rows = Q >> 6;                            // rows of 64 per wave (block-uniform, <= kTileSortKpt)
+        const int wbase = wid * Q;
+        auto mine = [&](int k) { return wbase + 64 * k + lane < n; };
+        if (tid < 4) s_skip[tid] = 0;
+#pragma unroll
+        for (int k = 0; k < kTileSortKpt; ++k) {
+            if (k >= rows) break;
+            const int li = wbase + k * 64 + lane;
+            val[k] = vals_in[start + (li < n ? li : n - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < kTileSortKpt; ++k) {
+            if (k >= rows) break;
+            key[k] = __float_as_uint(depths[val[k]]);
+        }
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 8 * pass;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) s_cnt[w][tid] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kTileSortKpt; ++k) {
+                if (k >= rows) break;
+                rank[k] = wave_digit_rank(mine(k), (key[k] >> shift) & 255u, s_cnt[wid], lane);
+            }
+            __syncthreads();
+            {   // thread tid owns digit tid: per-wave bases, run-local exclusive scan
+                int c[4], tot = 0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) c[w] = s_cnt[w][tid];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { s_cnt[w][tid] = tot; tot += c[w]; }
+                if (tot == n) s_skip[pass] = 1;            // one digit holds the whole run: this pass is the identity
+                s_base[tid] = digit_scan(tot);
+            }
+            __syncthreads();
+            const bool skip = s_skip[pass] != 0;           // (block-uniform)
+            const bool last = pass == 3;
+            if (skip && !last) continue;
+#pragma unroll
+            for (int k = 0; k < kTileSortKpt; ++k) {
+                if (k >= rows) break;
+                if (mine(k)) {
+                    const unsigned d = (key[k] >> shift) & 255u;
+                    const int pos = skip ? wbase + k * 64 + lane : s_base[d] + s_cnt[wid][d] + rank[k];
+                    if (last) vals_out[start + pos] = val[k];
+                    else { s_keys[pos] = key[k]; s_vals[pos] = val[k]; }
+                }
+            }
+            if (last) break;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kTileSortKpt; ++k) {
+                if (k >= rows) break;
+                if (mine(k)) { key[k] = s_keys[wbase + k * 64 + lane]; val[k] = s_vals[wbase + k * 64 + lane]; }
+            }
+        }
+        continue;
+    }
+    // ---- long runs: the same passes through global scratch, one row of 256 entries at a time ----
+    const unsigned* ksrc = nullptr;        // pass 0 gathers the depth bits
+    const int* vsrc = vals_in;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 8 * pass;
+        unsigned* kdst = (pass & 1) ? gk1 : gk0;
+        int* vdst = pass == 3 ? vals_out : ((pass & 1) ? gv1 : gv0);
+        s_base[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) {
+            const unsigned kk = ksrc ? ksrc[start + i] : __float_as_uint(depths[vsrc[start + i]]);
+            atomicAdd(&s_base[(kk >> shift) & 255u], 1);
+        }
+        __syncthreads();
+        const int tot = s_base[tid];
+        const int base = digit_scan(tot);
+        __syncthreads();
+        s_base[tid] = base;                                 // running cursor of digit tid
+        __syncthreads();
+        for (int row = 0; row < n; row += 256) {
+            const int i = row + tid;
+            const bool valid = i < n;
+            const int vv = valid ? vsrc[start + i] : 0;
+            const unsigned kk = valid ? (ksrc ? ksrc[start + i] : __float_as_uint(depths[vv])) : 0u;
+            const unsigned d = (kk >> shift) & 255u;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) s_cnt[w][tid] = 0;
+            __syncthreads();
+            const int r = wave_digit_rank(valid, d, s_cnt[wid], lane);
+            __syncthreads();
+            {   // digit tid: counts of the four waves -> exclusive per-wave bases; advance the cursor
+                int c[4], t2 = 0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) c[w] = s_cnt[w][tid];
+                const int cur = s_base[tid];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { s_cnt[w][tid] = cur + t2; t2 += c[w]; }
+                __syncthreads();
+                s_base[tid] = cur + t2;
+            }
+            __syncthreads();
+            if (valid) {
+                const int pos = s_cnt[wid][d] + r;
+                vdst[start + pos] = vv;
+                if (pass < 3) kdst[start + pos] = kk;
+            }
+            __syncthreads();
+        }
+        __threadfence_block();
+        __syncthreads();
+        ksrc = kdst;
+        vsrc = vdst;
+    }
+  }
 }
 
 // gsplat-style 64-bit keys of the sorted list (info["isect_ids"]), rebuilt on demand
@@ -200,7 +471,7 @@ static long long align256(long long x) { return (x + 255) & ~255ll; }
 
 struct BinLayout {
     long long n_slots_dev, keysA0, keysA1, valsA0, valsA1, block_sums, block_offsets, keysB0, keysB1, valsB, sort_ws,
-        total;
+        tk1, tv0, tv1, total;
     long long sort_ws_bytes;
 };
 
@@ -220,6 +491,10 @@ static BinLayout bin_layout(long long S, long long cap) {
     L.valsB = o; o += align256(4 * cap);
     L.sort_ws_bytes = sort32_workspace_bytes(S > cap ? S : cap);
     L.sort_ws = o; o += align256(L.sort_ws_bytes);
+    // tile-sort mode: scratch of the long-run path of tile_depth_sort_kernel (its other key buffer is keysB's spare)
+    L.tk1 = o; o += align256(4 * cap);
+    L.tv0 = o; o += align256(4 * cap);
+    L.tv1 = o; o += align256(4 * cap);
     L.total = o;
     return L;
 }
@@ -230,10 +505,10 @@ extern "C" int64_t qed_bin_workspace_bytes(int64_t n_slots, int64_t capacity) {
 }
 
 extern "C" int qed_bin_tiles(int32_t N, int32_t C, const float* means2d, const int32_t* radii, const float* depths,
-                             const int32_t* tiles_per_gauss, const float* splats, int32_t tile_w, int32_t tile_h,
-                             int64_t capacity, int32_t* flatten_ids, int32_t* offsets, int32_t* n_isect,
-                             uint64_t* isect_ids, void* workspace, int64_t workspace_bytes, int32_t* status,
-                             void* stream) {
+                             const int32_t* tiles_per_gauss, const float* splats, const int32_t* block_sums_in,
+                             int32_t tile_w, int32_t tile_h, int64_t capacity, int32_t mode, int32_t* flatten_ids,
+                             int32_t* offsets, int32_t* n_isect, uint64_t* isect_ids, void* workspace,
+                             int64_t workspace_bytes, int32_t* status, void* stream) {
     QED_REQUIRE(N >= 0 && C >= 1 && tile_w > 0 && tile_h > 0, "bad extents");
     QED_REQUIRE(splats == nullptr || (tile_w <= 1023 && tile_h <= 2047), "packed tile rectangles need tile_w <= 1023");
     QED_REQUIRE(capacity >= 0 && capacity < (1ll << 30), "capacity out of range");
@@ -267,7 +542,50 @@ extern "C" int qed_bin_tiles(int32_t N, int32_t C, const float* means2d, const i
         return QED_OK;
     }
     QED_REQUIRE(means2d && radii && depths && tiles_per_gauss && flatten_ids, "null buffers");
+    QED_REQUIRE(mode >= QED_BIN_AUTO && mode <= QED_BIN_TILE_SORT, "unknown binning mode");
     const unsigned gridS = (unsigned)((S + 255) / 256);
+    // Which pipeline: sorting every tile's run by depth costs time in proportion to the list and runs in LDS only
+    // for runs of <= 2048 entries; the global depth sort of the slots costs ~12 launch latencies whatever the list.
+    // The capacity (1.25 x the longest list seen) per tile decides: short lists per tile -> per-tile sort.
+    if (mode == QED_BIN_AUTO) mode = capacity <= 1024 * n_tot ? QED_BIN_TILE_SORT : QED_BIN_TWO_STAGE;
+    if (mode == QED_BIN_TILE_SORT) {
+        // (1) list positions in SLOT order: block sums of the tile counts (project_fwd's, or counted here) -> scan
+        const int* bsums = block_sums_in;
+        if (bsums == nullptr) {
+            hipLaunchKernelGGL(count_sorted_kernel, dim3(gridS), dim3(256), 0, st, (int)S, (const int*)nullptr,
+                               tiles_per_gauss, block_sums);
+            bsums = block_sums;
+        }
+        hipLaunchKernelGGL(isect_scan_kernel, dim3(1), dim3(1024), 0, st, bsums, (int)gridS, block_offsets, n_isect,
+                           (long long)capacity, status);
+        // (2) emit (cam|tile, slot) in slot order, STABLE sort on the tile bits: every tile's run is in slot order.
+        // The buffers are dealt so that the sorted values land in vB (the per-tile sort writes flatten_ids).
+        const int end_bit = tile_bits + cam_bits;
+        const int passes = (end_bit + 7) / 8;
+        int* v_first = (passes & 1) ? flatten_ids : vB;
+        int* v_alt = (passes & 1) ? vB : flatten_ids;
+        hipLaunchKernelGGL(isect_emit_kernel<unsigned>, dim3(gridS), dim3(256), 0, st, N, C, means2d, radii, depths,
+                           tiles_per_gauss, (const int*)block_offsets, tile_w, tile_h, tile_bits, (const int*)n_isect,
+                           (const int*)nullptr, kB0, v_first, splats);
+        const int which = sort_pairs_u32(kB0, v_first, kB1, v_alt, n_isect, capacity, end_bit, sort_ws, L.sort_ws_bytes,
+                                         status, st);
+        if (which < 0) return which;
+        const unsigned* tile_keys = which ? kB1 : kB0;
+        unsigned* k_spare = which ? kB0 : kB1;
+        const long long work = capacity > n_tot + 1 ? capacity : n_tot + 1;
+        hipLaunchKernelGGL(tile_offsets_kernel<unsigned>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, tile_keys,
+                           (const int*)n_isect, (int)n_tot, tile_w * tile_h, tile_bits, offsets);
+        // (3) every tile's run into depth order (stable: ties stay in slot order)
+        hipLaunchKernelGGL(tile_depth_sort_wave_kernel, dim3((unsigned)((n_tot + 3) / 4)), dim3(256), 0, st,
+                           (const int*)offsets, (const int*)vB, depths, flatten_ids, (int)n_tot);
+        hipLaunchKernelGGL(tile_depth_sort_kernel, dim3((unsigned)(n_tot < 2048 ? n_tot : 2048)), dim3(256), 0, st,
+                           (const int*)offsets, (const int*)vB, depths, flatten_ids, k_spare, (unsigned*)(w + L.tk1),
+                           (int*)(w + L.tv0), (int*)(w + L.tv1), (int)n_tot);
+        if (isect_ids != nullptr)
+            hipLaunchKernelGGL(isect_ids_kernel, dim3((unsigned)((capacity + 255) / 256)), dim3(256), 0, st, tile_keys,
+                               (const int*)flatten_ids, depths, (const int*)n_isect, (unsigned long long*)isect_ids);
+        return check_launch("qed_bin_tiles");
+    }
     // stage A: (camera, Gaussian) slots into depth order
     hipLaunchKernelGGL(depth_keys_kernel, dim3(gridS), dim3(256), 0, st, (int)S, radii, depths, kA0, vA0, n_slots_dev);
     int which = sort_pairs_u32(kA0, vA0, kA1, vA1, n_slots_dev, S, 32, sort_ws, L.sort_ws_bytes, status, st);

@@ -262,9 +262,10 @@ def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, til
         flatten_ids = torch.empty(cap, dtype=torch.int32, device=dev)
         isect_ids = torch.empty(cap, dtype=torch.int64, device=dev) if sync else None
         scratch = torch.empty(int(lib.qed_bin_workspace_bytes(C * N, cap)), dtype=torch.uint8, device=dev)
-        L.check(lib.qed_bin_tiles(N, C, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(tiles_per_gauss), L.ptr(splats), tile_w,
-                                  tile_h, cap, L.ptr(flatten_ids), L.ptr(offsets), L.ptr(n_isect), L.ptr(isect_ids),
-                                  L.ptr(scratch), scratch.numel(), L.ptr(ws.status), _stream()), "qed_bin_tiles")
+        L.check(lib.qed_bin_tiles(N, C, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(tiles_per_gauss), L.ptr(splats),
+                                  L.ptr(block_sums), tile_w, tile_h, cap, L.bin_mode(), L.ptr(flatten_ids), L.ptr(offsets),
+                                  L.ptr(n_isect), L.ptr(isect_ids), L.ptr(scratch), scratch.numel(), L.ptr(ws.status),
+                                  _stream()), "qed_bin_tiles")
         if capturing:
             ws.last_n_isect = n_isect                  # device tensor the replaying code polls
             return None, flatten_ids, offsets, None

@@ -82,8 +82,12 @@ def test_sh_degrees(cuda, deg):
 # --------------------------------------------------------------------------------------------------
 # K3/K4/K5: intersection, sort, offsets -- bit exact given the same projected inputs
 # --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("bin_mode", ["two_stage", "tile_sort"])
 @pytest.mark.parametrize("n,w,h,n_cam", [(5000, 200, 136, 1), (3000, 96, 64, 3), (50, 33, 17, 1)])
-def test_isect_sort_offsets_exact(cuda, n, w, h, n_cam):
+def test_isect_sort_offsets_exact(cuda, monkeypatch, n, w, h, n_cam, bin_mode):
+    """Both binning pipelines of qed_bin_tiles (global depth sort of the slots + tile sort; tile sort + per-tile depth
+    sort) give the reference's list bit for bit: keys, order (ties included), offsets."""
+    monkeypatch.setenv("QED_BIN_MODE", bin_mode)
     sc = scene(n, w, h, seed=3, n_cameras=n_cam)
     _, _, _, info = _raster_gpu(sc, cuda, w, h)
     tw, th = info["tile_width"], info["tile_height"]
@@ -93,6 +97,27 @@ def test_isect_sort_offsets_exact(cuda, n, w, h, n_cam):
     assert torch.equal(info["isect_ids"].cpu(), keys)
     assert torch.equal(info["flatten_ids"].cpu(), fids)
     offs = O.isect_offset_encode(keys, n_cam, tw, th)
+    assert torch.equal(info["isect_offsets"].cpu(), offs)
+
+
+@pytest.mark.parametrize("bin_mode", ["two_stage", "tile_sort"])
+def test_binning_long_runs_and_depth_ties(cuda, monkeypatch, bin_mode):
+    """Tile runs longer than the 2048 entries the per-tile sort holds in LDS (its global-scratch path), many bit-equal
+    depths (ties must stay in Gaussian order) and empty tiles: the list equals the oracle's stable 64-bit sort."""
+    monkeypatch.setenv("QED_BIN_MODE", bin_mode)
+    w, h, n = 64, 48, 40000                                               # 12 tiles, ~3-6 k entries each
+    sc = scene(n, w, h, seed=17)
+    sc["means"][:, 2] = -torch.round(sc["means"][:, 2].abs() * 2) / 2      # depths on a 0.5 grid: thousands of exact ties
+    sc["means"][: n // 3, 0] = sc["means"][: n // 3, 0].abs() + 0.2        # crowd a third of them into the right half
+    sc["scales"][:] = math.log(0.05)
+    _, _, _, info = _raster_gpu(sc, cuda, w, h)
+    tw, th = info["tile_width"], info["tile_height"]
+    tpg, keys, fids = O.isect_tiles(info["means2d"].cpu(), info["radii"].cpu(), info["depths"].cpu(), 16, tw, th)
+    offs = O.isect_offset_encode(keys, 1, tw, th)
+    runs = torch.diff(torch.cat([offs.flatten(), torch.tensor([keys.numel()])]))
+    assert int(runs.max()) > 2048 and int((torch.diff(keys) == 0).sum()) > 1000
+    assert torch.equal(info["isect_ids"].cpu(), keys)
+    assert torch.equal(info["flatten_ids"].cpu(), fids)
     assert torch.equal(info["isect_offsets"].cpu(), offs)
 
 
