@@ -53,20 +53,49 @@ isect_scan_kernel(const int* __restrict__ block_sums, int n_blocks, int* __restr
 // KeyT = u64: key = (cam|tile) << 32 | depth bits (one-stage sort).  KeyT = u32: key = cam|tile only;
 // then `order` lists the slots in depth order, so emission order already carries the depth order
 // (two-stage binning, qed_bin_tiles).
-template <typename KeyT>
+// SELF_SCAN (qed_bin_tiles): block_offsets holds the per-block SUMS and every workgroup adds up its predecessors'
+// itself (a few thousand L2-resident ints) -- one launch and one single-workgroup serial scan less; the last workgroup
+// publishes M (or the overflow) in n_isect / status, which only later kernels read.
+template <typename KeyT, bool SELF_SCAN>
 __global__ void __launch_bounds__(256)
 isect_emit_kernel(int N, int C, const float* __restrict__ means2d, const int* __restrict__ radii,
                   const float* __restrict__ depths, const int* __restrict__ tiles_per_gauss,
                   const int* __restrict__ block_offsets, int tile_w, int tile_h, int tile_bits,
-                  const int* __restrict__ n_isect, const int* __restrict__ order, KeyT* __restrict__ keys,
-                  int* __restrict__ vals, const float* __restrict__ splats) {
+                  int* __restrict__ n_isect, const int* __restrict__ order, KeyT* __restrict__ keys,
+                  int* __restrict__ vals, const float* __restrict__ splats, long long capacity,
+                  int* __restrict__ status) {
     __shared__ int s_pref[4][65];   // per wave: exclusive prefix of counts (+ total)
     __shared__ int s_x0[4][64], s_y0[4][64], s_w[4][64];
     __shared__ unsigned s_depth[4][64];
     __shared__ int s_slot[4][64];
     __shared__ int s_wave_tot[4];
-    if (n_isect[0] == 0) return;    // nothing to do (or capacity exceeded)
+    __shared__ long long s_scan[2][4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    int block_base = 0;
+    if constexpr (SELF_SCAN) {
+        long long before = 0, all = 0;
+        for (int i = tid; i < (int)gridDim.x; i += 256) {
+            const long long v = block_offsets[i];
+            all += v;
+            if (i < (int)blockIdx.x) before += v;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o, 64); all += __shfl_xor(all, o, 64); }
+        if (lane == 0) { s_scan[0][wid] = before; s_scan[1][wid] = all; }
+        __syncthreads();
+        before = s_scan[0][0] + s_scan[0][1] + s_scan[0][2] + s_scan[0][3];
+        all = s_scan[1][0] + s_scan[1][1] + s_scan[1][2] + s_scan[1][3];
+        const bool overflow = all > capacity || all > 0x7fffffffll;
+        if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+            if (overflow) { status[0] = (int)min(all, (long long)0x7fffffff); n_isect[0] = 0; }
+            else n_isect[0] = (int)all;
+        }
+        if (overflow || all == 0) return;
+        block_base = (int)before;
+    } else {
+        if (n_isect[0] == 0) return;    // nothing to do (or capacity exceeded)
+        block_base = block_offsets[blockIdx.x];
+    }
     const long long total = (long long)C * N;
     const long long pos = (long long)blockIdx.x * 256 + tid;
     long long slot = pos;
@@ -102,7 +131,7 @@ isect_emit_kernel(int N, int C, const float* __restrict__ means2d, const int* __
     s_x0[wid][lane] = x0; s_y0[wid][lane] = y0; s_w[wid][lane] = x1 - x0; s_depth[wid][lane] = dbits;
     s_slot[wid][lane] = (int)slot;
     __syncthreads();
-    int wave_base = block_offsets[blockIdx.x];
+    int wave_base = block_base;
     for (int w = 0; w < wid; ++w) wave_base += s_wave_tot[w];
     const int wtot = s_pref[wid][64];
     for (int j = lane; j < wtot; j += 64) {
@@ -214,23 +243,47 @@ __device__ __forceinline__ int wave_digit_rank(bool valid, unsigned d, int* cnt,
 
 
 // Short runs (<= kTileWaveItems entries: nearly every tile at config B): ONE WAVE per tile, four tiles per workgroup,
-// no workgroup barrier anywhere -- the keys stay in registers (8 rows of 64), ranks come from the same ballot match, the
-// 256 digit totals are scanned by the wave itself (four digits per lane), and a whole generation of tiles is resident
-// at once (32 waves per CU).  Longer runs are left to tile_depth_sort_kernel.
+// no workgroup barrier anywhere, a whole generation of tiles resident at once.  The keys stay in registers (8 rows of
+// 64).  A run is a few hundred depths, so a full 4-pass radix sort is overkill:
+//   (1) ONE stable counting pass on a 9-bit bucket  b = floor((key - kmin) * 511.99 / (kmax - kmin))  -- monotone in the
+//       key, ranks from the same ballot match, the 512 bucket totals scanned by the wave itself (8 per lane);
+//   (2) the run, now ordered by bucket, is finished by odd-even transposition with a strict compare (stable: equal
+//       depths keep their slot order).  Two keys can only be out of order inside one bucket, so it converges in
+//       (largest bucket) rounds -- one or two for a spread of depths.
+// Runs with a crowded bucket (> kTileBucketMax) take four stable 8-bit radix passes instead, like the long runs that
+// are left to tile_depth_sort_kernel.
 constexpr int kTileWaveKpt = 8;
 constexpr int kTileWaveItems = 64 * kTileWaveKpt;
+constexpr int kTileBuckets = 512;
+constexpr int kTileBucketMax = 12;
 
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 
+// as wave_digit_rank, for 9-bit digits
+__device__ __forceinline__ int wave_bucket_rank(bool valid, unsigned d, int* cnt, int lane) {
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 9; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const unsigned long long bal = __ballot(bit);
+        peers &= bit ? bal : ~bal;
+    }
+    int r = 0;
+    if (valid) {
+        r = cnt[d] + __popcll(peers & ((1ull << lane) - 1ull));
+        if ((peers >> lane) == 1ull) cnt[d] = r + 1;
+    }
+    return r;
+}
+
 __global__ void __launch_bounds__(256)
 tile_depth_sort_wave_kernel(const int* __restrict__ offsets, const int* __restrict__ vals_in,
                             const float* __restrict__ depths, int* __restrict__ vals_out, int n_tiles_total) {
-    __shared__ unsigned s_keys[4][kTileWaveItems];
-    __shared__ int s_vals[4][kTileWaveItems];
-    __shared__ __attribute__((aligned(16))) int s_cnt[4][256];
+    __shared__ __attribute__((aligned(16))) uint2 s_kv[4][kTileWaveItems];      // (key, value) pairs of a run
+    __shared__ __attribute__((aligned(16))) int s_cnt[4][kTileBuckets];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int tile = blockIdx.x * 4 + wid;
     if (tile >= n_tiles_total) return;
@@ -249,14 +302,98 @@ tile_depth_sort_wave_kernel(const int* __restrict__ offsets, const int* __restri
         const int li = k * 64 + lane;
         val[k] = vals_in[start + (li < n ? li : n - 1)];
     }
+    unsigned kmin = 0xFFFFFFFFu, kmax = 0u;
 #pragma unroll
     for (int k = 0; k < kTileWaveKpt; ++k) {
         if (k >= rows) break;
-        key[k] = __float_as_uint(depths[val[k]]);
+        key[k] = __float_as_uint(depths[val[k]]);          // (lanes past the end hold a copy of the last entry)
+        kmin = min(kmin, key[k]);
+        kmax = max(kmax, key[k]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, o, 64));
+        kmax = max(kmax, (unsigned)__shfl_xor((int)kmax, o, 64));
     }
     int* cnt = s_cnt[wid];
-    unsigned* skeys = s_keys[wid];
-    int* svals = s_vals[wid];
+    uint2* kv = s_kv[wid];
+    if (kmin == kmax) {                                    // one depth: the slot order is the answer
+#pragma unroll
+        for (int k = 0; k < kTileWaveKpt; ++k) {
+            if (k >= rows) break;
+            if (k * 64 + lane < n) vals_out[start + k * 64 + lane] = val[k];
+        }
+        return;
+    }
+    // ---- (1) stable counting pass on the bucket ----
+    const float scale = 511.99f / (float)(kmax - kmin);
+    unsigned bkt[kTileWaveKpt];
+    *reinterpret_cast<int4*>(&cnt[8 * lane]) = make_int4(0, 0, 0, 0);
+    *reinterpret_cast<int4*>(&cnt[8 * lane + 4]) = make_int4(0, 0, 0, 0);
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < kTileWaveKpt; ++k) {
+        if (k >= rows) break;
+        bkt[k] = min((unsigned)((float)(key[k] - kmin) * scale), (unsigned)(kTileBuckets - 1));
+        rank[k] = wave_bucket_rank(k * 64 + lane < n, bkt[k], cnt, lane);
+    }
+    wave_lds_fence();
+    int largest;
+    {   // lane l owns buckets 8 l .. 8 l + 7: totals -> exclusive bases
+        const int4 c0 = *reinterpret_cast<const int4*>(&cnt[8 * lane]);
+        const int4 c1 = *reinterpret_cast<const int4*>(&cnt[8 * lane + 4]);
+        largest = max(max(max(c0.x, c0.y), max(c0.z, c0.w)), max(max(c1.x, c1.y), max(c1.z, c1.w)));
+        const int tot = c0.x + c0.y + c0.z + c0.w + c1.x + c1.y + c1.z + c1.w;
+        int x = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) largest = max(largest, __shfl_xor(largest, o, 64));
+        int b = x - tot;
+        int4 e0, e1;
+        e0.x = b; b += c0.x; e0.y = b; b += c0.y; e0.z = b; b += c0.z; e0.w = b; b += c0.w;
+        e1.x = b; b += c1.x; e1.y = b; b += c1.y; e1.z = b; b += c1.z; e1.w = b;
+        *reinterpret_cast<int4*>(&cnt[8 * lane]) = e0;
+        *reinterpret_cast<int4*>(&cnt[8 * lane + 4]) = e1;
+    }
+    wave_lds_fence();
+    if (largest <= kTileBucketMax) {
+#pragma unroll
+        for (int k = 0; k < kTileWaveKpt; ++k) {
+            if (k >= rows) break;
+            if (k * 64 + lane < n) kv[cnt[bkt[k]] + rank[k]] = make_uint2(key[k], (unsigned)val[k]);
+        }
+        wave_lds_fence();
+        // ---- (2) odd-even transposition, strict compare; a round without a swap ends it ----
+        const int n_even = n >> 1, n_odd = (n - 1) >> 1;   // pairs (2 j, 2 j + 1) and (2 j + 1, 2 j + 2)
+        for (int round = 0; round <= kTileBucketMax; ++round) {
+            bool swapped = false;
+            for (int j = lane; j < n_even; j += 64) {
+                const uint4 p = *reinterpret_cast<const uint4*>(&kv[2 * j]);
+                if (p.x > p.z) { *reinterpret_cast<uint4*>(&kv[2 * j]) = make_uint4(p.z, p.w, p.x, p.y); swapped = true; }
+            }
+            wave_lds_fence();
+            for (int j = lane; j < n_odd; j += 64) {
+                const uint2 lo = kv[2 * j + 1], hi = kv[2 * j + 2];
+                if (lo.x > hi.x) { kv[2 * j + 1] = hi; kv[2 * j + 2] = lo; swapped = true; }
+            }
+            wave_lds_fence();
+            if (__ballot(swapped) == 0ull) break;
+        }
+#pragma unroll
+        for (int k = 0; k < kTileWaveKpt; ++k) {
+            if (k >= rows) break;
+            const int li = k * 64 + lane;
+            if (li < n) vals_out[start + li] = (int)kv[li].y;
+        }
+        return;
+    }
+    // ---- crowded bucket: four stable 8-bit radix passes (counters: the first 256 of cnt) ----
+    unsigned* skeys = reinterpret_cast<unsigned*>(kv);
+    int* svals = reinterpret_cast<int*>(kv) + kTileWaveItems;
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 8 * pass;
         *reinterpret_cast<int4*>(&cnt[4 * lane]) = make_int4(0, 0, 0, 0);
@@ -531,7 +668,7 @@ extern "C" int qed_bin_tiles(int32_t N, int32_t C, const float* means2d, const i
     int* n_slots_dev = (int*)(w + L.n_slots_dev);
     unsigned* kA0 = (unsigned*)(w + L.keysA0); unsigned* kA1 = (unsigned*)(w + L.keysA1);
     int* vA0 = (int*)(w + L.valsA0); int* vA1 = (int*)(w + L.valsA1);
-    int* block_sums = (int*)(w + L.block_sums); int* block_offsets = (int*)(w + L.block_offsets);
+    int* block_sums = (int*)(w + L.block_sums);
     unsigned* kB0 = (unsigned*)(w + L.keysB0); unsigned* kB1 = (unsigned*)(w + L.keysB1);
     int* vB = (int*)(w + L.valsB);
     void* sort_ws = w + L.sort_ws;
@@ -549,24 +686,23 @@ extern "C" int qed_bin_tiles(int32_t N, int32_t C, const float* means2d, const i
     // The capacity (1.25 x the longest list seen) per tile decides: short lists per tile -> per-tile sort.
     if (mode == QED_BIN_AUTO) mode = capacity <= 1024 * n_tot ? QED_BIN_TILE_SORT : QED_BIN_TWO_STAGE;
     if (mode == QED_BIN_TILE_SORT) {
-        // (1) list positions in SLOT order: block sums of the tile counts (project_fwd's, or counted here) -> scan
+        // (1) list positions in SLOT order: block sums of the tile counts (project_fwd's, or counted here), scanned
+        // by the emit kernel itself
         const int* bsums = block_sums_in;
         if (bsums == nullptr) {
             hipLaunchKernelGGL(count_sorted_kernel, dim3(gridS), dim3(256), 0, st, (int)S, (const int*)nullptr,
                                tiles_per_gauss, block_sums);
             bsums = block_sums;
         }
-        hipLaunchKernelGGL(isect_scan_kernel, dim3(1), dim3(1024), 0, st, bsums, (int)gridS, block_offsets, n_isect,
-                           (long long)capacity, status);
         // (2) emit (cam|tile, slot) in slot order, STABLE sort on the tile bits: every tile's run is in slot order.
         // The buffers are dealt so that the sorted values land in vB (the per-tile sort writes flatten_ids).
         const int end_bit = tile_bits + cam_bits;
         const int passes = (end_bit + 7) / 8;
         int* v_first = (passes & 1) ? flatten_ids : vB;
         int* v_alt = (passes & 1) ? vB : flatten_ids;
-        hipLaunchKernelGGL(isect_emit_kernel<unsigned>, dim3(gridS), dim3(256), 0, st, N, C, means2d, radii, depths,
-                           tiles_per_gauss, (const int*)block_offsets, tile_w, tile_h, tile_bits, (const int*)n_isect,
-                           (const int*)nullptr, kB0, v_first, splats);
+        hipLaunchKernelGGL((isect_emit_kernel<unsigned, true>), dim3(gridS), dim3(256), 0, st, N, C, means2d, radii, depths,
+                           tiles_per_gauss, bsums, tile_w, tile_h, tile_bits, n_isect, (const int*)nullptr, kB0, v_first,
+                           splats, (long long)capacity, status);
         const int which = sort_pairs_u32(kB0, v_first, kB1, v_alt, n_isect, capacity, end_bit, sort_ws, L.sort_ws_bytes,
                                          status, st);
         if (which < 0) return which;
@@ -593,17 +729,15 @@ extern "C" int qed_bin_tiles(int32_t N, int32_t C, const float* means2d, const i
     const int* order = which ? vA1 : vA0;
     // intersection counts in depth order -> offsets, M
     hipLaunchKernelGGL(count_sorted_kernel, dim3(gridS), dim3(256), 0, st, (int)S, order, tiles_per_gauss, block_sums);
-    hipLaunchKernelGGL(isect_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)block_sums, (int)gridS, block_offsets,
-                       n_isect, (long long)capacity, status);
     // stage B: emit (cam|tile, slot) in depth order, then a STABLE sort on the tile bits only.  The pass
     // count decides which buffer to emit into so that the sorted values land in `flatten_ids`.
     const int end_bit = tile_bits + cam_bits;
     const int passes = (end_bit + 7) / 8;
     int* v_first = (passes & 1) ? vB : flatten_ids;
     int* v_alt = (passes & 1) ? flatten_ids : vB;
-    hipLaunchKernelGGL(isect_emit_kernel<unsigned>, dim3(gridS), dim3(256), 0, st, N, C, means2d, radii, depths,
-                       tiles_per_gauss, (const int*)block_offsets, tile_w, tile_h, tile_bits, (const int*)n_isect, order,
-                       kB0, v_first, splats);
+    hipLaunchKernelGGL((isect_emit_kernel<unsigned, true>), dim3(gridS), dim3(256), 0, st, N, C, means2d, radii, depths,
+                       tiles_per_gauss, (const int*)block_sums, tile_w, tile_h, tile_bits, n_isect, order, kB0, v_first,
+                       splats, (long long)capacity, status);
     which = sort_pairs_u32(kB0, v_first, kB1, v_alt, n_isect, capacity, end_bit, sort_ws, L.sort_ws_bytes, status, st);
     if (which < 0) return which;
     const unsigned* tile_keys = which ? kB1 : kB0;
@@ -636,9 +770,10 @@ extern "C" int qed_isect_emit(int32_t N, int32_t C, const float* means2d, const 
                 "null buffers");
     const long long total = (long long)C * N;
     const unsigned grid = (unsigned)((total + 255) / 256);
-    hipLaunchKernelGGL(isect_emit_kernel<unsigned long long>, dim3(grid), dim3(256), 0, (hipStream_t)stream, N, C,
-                       means2d, radii, depths, tiles_per_gauss, block_offsets, tile_w, tile_h, tile_bits, n_isect,
-                       (const int*)nullptr, (unsigned long long*)keys, vals, (const float*)nullptr);
+    hipLaunchKernelGGL((isect_emit_kernel<unsigned long long, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, N, C,
+                       means2d, radii, depths, tiles_per_gauss, block_offsets, tile_w, tile_h, tile_bits,
+                       const_cast<int*>(n_isect), (const int*)nullptr, (unsigned long long*)keys, vals,
+                       (const float*)nullptr, 0ll, (int*)nullptr);
     return check_launch("qed_isect_emit");
 }
 

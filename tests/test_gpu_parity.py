@@ -101,13 +101,15 @@ def test_isect_sort_offsets_exact(cuda, monkeypatch, n, w, h, n_cam, bin_mode):
 
 
 @pytest.mark.parametrize("bin_mode", ["two_stage", "tile_sort"])
-def test_binning_long_runs_and_depth_ties(cuda, monkeypatch, bin_mode):
-    """Tile runs longer than the 2048 entries the per-tile sort holds in LDS (its global-scratch path), many bit-equal
-    depths (ties must stay in Gaussian order) and empty tiles: the list equals the oracle's stable 64-bit sort."""
+@pytest.mark.parametrize("n,grid,long_runs", [(40000, 0.5, True), (3000, 0.5, False), (3000, 0.01, False), (600, 2.0, False)])
+def test_binning_long_runs_and_depth_ties(cuda, monkeypatch, bin_mode, n, grid, long_runs):
+    """Every path of the per-tile depth sort -- runs longer than the 2048 entries held in LDS (global scratch), short
+    runs with crowded buckets (radix passes in the wave), short runs finished by odd-even transposition -- on depths
+    with many bit-equal values (ties must stay in Gaussian order): the list equals the oracle's stable 64-bit sort."""
     monkeypatch.setenv("QED_BIN_MODE", bin_mode)
-    w, h, n = 64, 48, 40000                                               # 12 tiles, ~3-6 k entries each
+    w, h = 64, 48                                                         # 12 tiles
     sc = scene(n, w, h, seed=17)
-    sc["means"][:, 2] = -torch.round(sc["means"][:, 2].abs() * 2) / 2      # depths on a 0.5 grid: thousands of exact ties
+    sc["means"][:, 2] = -torch.round(sc["means"][:, 2].abs() / grid).clamp(min=1) * grid     # depths on a grid: exact ties
     sc["means"][: n // 3, 0] = sc["means"][: n // 3, 0].abs() + 0.2        # crowd a third of them into the right half
     sc["scales"][:] = math.log(0.05)
     _, _, _, info = _raster_gpu(sc, cuda, w, h)
@@ -115,7 +117,7 @@ def test_binning_long_runs_and_depth_ties(cuda, monkeypatch, bin_mode):
     tpg, keys, fids = O.isect_tiles(info["means2d"].cpu(), info["radii"].cpu(), info["depths"].cpu(), 16, tw, th)
     offs = O.isect_offset_encode(keys, 1, tw, th)
     runs = torch.diff(torch.cat([offs.flatten(), torch.tensor([keys.numel()])]))
-    assert int(runs.max()) > 2048 and int((torch.diff(keys) == 0).sum()) > 1000
+    assert (int(runs.max()) > 2048) == long_runs and int((torch.diff(keys) == 0).sum()) > 50
     assert torch.equal(info["isect_ids"].cpu(), keys)
     assert torch.equal(info["flatten_ids"].cpu(), fids)
     assert torch.equal(info["isect_offsets"].cpu(), offs)
