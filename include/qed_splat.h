@@ -234,7 +234,8 @@ int qed_loss_grad(int32_t n_pix, int32_t channels, const float* render, const fl
  * pred is either a plain [H,W,3] image (alpha == NULL) or the compositor's render[H,W,channels]
  * together with alpha[H,W] and background[3], in which case the colour clamp(render + (1-alpha) bg)
  * of model.py:296-297 is formed on the fly.  qed_ssim_fwd writes ssim_sum[0] = sum of the SSIM map
- * (SSIM = ssim_sum / (3 (H-10)(W-10))) and the coefficient maps (qed_ssim_maps_floats floats) that
+ * (SSIM = ssim_sum / (3 (H-10)(W-10))) and, unless maps == NULL (value only: the rgb_ssim metric), the
+ * coefficient maps (qed_ssim_maps_floats floats) that
  * qed_ssim_bwd turns into v_pred[H,W,3] = scale * (scale_dev ? scale_dev[0] : 1) * d ssim_sum / d colour
  * (scale_dev: an upstream gradient that lives in device memory).  mask[H,W] (may be NULL) multiplies
  * both images before the SSIM, as the parent's loss does; v_pred is the gradient w.r.t. the colour
@@ -288,6 +289,9 @@ int qed_image_losses_bwd(int32_t n_pix, const float* rgb, const float* depth, co
  * rgb_ssim is qed_ssim_fwd's value; LPIPS (pretrained network) is not provided. */
 int qed_image_metrics(int32_t n_pix, const float* pred_rgb, const float* gt_rgb, const float* pred_depth,
                       const float* gt_depth, float tolerance, double* workspace, float* out, void* stream);
+/* out[0] = nanmean_i exp(x[i * stride]), i < n (NaN when nothing is left) -- the "avg_min_scale" entry of
+ * get_metrics_dict (model.py:192-194).  workspace: QED_METRICS_WS_DOUBLES doubles. */
+int qed_nanmean_exp(int32_t n, const float* x, int32_t stride, double* workspace, float* out, void* stream);
 
 /* ---- densification / culling ---------------------------------------------------
  * GPU side of the parent class's callbacks that consume model.py:249,289-292 (self.xys.absgrad,

@@ -50,6 +50,7 @@ SIGNATURES = {
     "qed_backproject_workspace_ints": (C.c_int64, [_I, _I, _I]),
     "qed_backproject_depth": (C.c_int, [_I, _I, _P, _F, _F, _F, _F, _P, _F, _I, _L, _P, _P, _P, _P, _P]),
     "qed_image_metrics": (C.c_int, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
+    "qed_nanmean_exp": (C.c_int, [_I, _P, _I, _P, _P, _P]),
     "qed_ssim_maps_floats": (C.c_int64, [_I, _I]),
     "qed_ssim_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qed_ssim_bwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P]),

@@ -110,9 +110,57 @@ metrics_finalize_kernel(int n_pix, int n_blocks, int has_rgb, int has_depth, con
     out[9] = (float)n;
 }
 
+// model.py:192-194 `torch.nanmean(torch.exp(self.scales[..., -1]))`: ~8 eager launches over N values per step in the
+// reference; here one pass + a one-workgroup fold.  partials: [2][kMetricMaxGrid] doubles (sum, count of non-NaN).
+__global__ void __launch_bounds__(256)
+nanmean_exp_kernel(int n, const float* __restrict__ x, int stride, double* __restrict__ partials) {
+    float sum = 0.f, cnt = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n; i += (size_t)gridDim.x * 256) {
+        const float e = expf(x[i * (size_t)stride]);
+        if (!isnan(e)) { sum += e; cnt += 1.f; }
+    }
+    __shared__ double s_tmp[2 * 4];
+    park_wave_sum(sum, s_tmp, 0);
+    park_wave_sum(cnt, s_tmp, 1);
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const int i = threadIdx.x;
+        partials[(size_t)i * kMetricMaxGrid + blockIdx.x] = s_tmp[4 * i] + s_tmp[4 * i + 1] + s_tmp[4 * i + 2] + s_tmp[4 * i + 3];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+nanmean_exp_finalize_kernel(int n_blocks, const double* __restrict__ partials, float* __restrict__ out) {
+    __shared__ double s_w[2][4];
+    for (int c = 0; c < 2; ++c) {
+        double v = 0.0;
+        for (int b = threadIdx.x; b < n_blocks; b += 256) v += partials[(size_t)c * kMetricMaxGrid + b];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) == 0) s_w[c][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double sum = s_w[0][0] + s_w[0][1] + s_w[0][2] + s_w[0][3], cnt = s_w[1][0] + s_w[1][1] + s_w[1][2] + s_w[1][3];
+        out[0] = cnt > 0.0 ? (float)(sum / cnt) : __builtin_nanf("");      // torch.nanmean of nothing is NaN
+    }
+}
+
 }  // namespace qed
 
 using namespace qed;
+
+extern "C" int qed_nanmean_exp(int32_t n, const float* x, int32_t stride, double* workspace, float* out, void* stream) {
+    QED_REQUIRE(n >= 0 && stride >= 1 && workspace && out, "bad arguments");
+    QED_REQUIRE(n == 0 || x, "null input");
+    hipStream_t st = (hipStream_t)stream;
+    long long g = ((long long)n + 255) / 256;
+    if (g > kMetricMaxGrid) g = kMetricMaxGrid;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(nanmean_exp_kernel, dim3((unsigned)g), dim3(256), 0, st, n, x, stride, workspace);
+    hipLaunchKernelGGL(nanmean_exp_finalize_kernel, dim3(1), dim3(256), 0, st, (int)g, (const double*)workspace, out);
+    return check_launch("qed_nanmean_exp");
+}
 
 extern "C" int qed_image_metrics(int32_t n_pix, const float* pred_rgb, const float* gt_rgb, const float* pred_depth,
                                  const float* gt_depth, float tolerance, double* workspace, float* out, void* stream) {

@@ -224,10 +224,12 @@ ssim_fwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
                 const float dS_dmu1 = cs * (2.f * mu2 * ib1 - a1 * ib1 * ib1 * 2.f * mu1);
                 const float dS_dvar1 = -lum * a2 * ib2 * ib2;
                 const float dS_dcov = lum * 2.f * ib2;
-                const size_t q = (size_t)qy * Wo + qx;
-                m[q] = dS_dmu1 - 2.f * mu1 * dS_dvar1 - mu2 * dS_dcov;       // A
-                m[n_out + q] = dS_dvar1;                                     // B
-                m[2 * n_out + q] = dS_dcov;                                  // C
+                if (maps != nullptr) {                                           // (NULL: value only)
+                    const size_t q = (size_t)qy * Wo + qx;
+                    m[q] = dS_dmu1 - 2.f * mu1 * dS_dvar1 - mu2 * dS_dcov;       // A
+                    m[n_out + q] = dS_dvar1;                                     // B
+                    m[2 * n_out + q] = dS_dcov;                                  // C
+                }
             }
         }
     }
@@ -358,7 +360,7 @@ extern "C" int qed_ssim_fwd(int32_t height, int32_t width, int32_t channels, con
                             const float* background, const float* gt_rgb, const float* mask, float* maps,
                             float* ssim_sum, void* stream) {
     QED_REQUIRE(height > kHalo && width > kHalo, "image smaller than the 11 x 11 SSIM window");
-    QED_REQUIRE(pred && gt_rgb && maps && ssim_sum, "null buffers");
+    QED_REQUIRE(pred && gt_rgb && ssim_sum, "null buffers");
     QED_REQUIRE(alpha == nullptr || (background && (channels == 3 || channels == 4)), "composite mode needs a background");
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(ssim_sum, 0, sizeof(float), st) != hipSuccess) { set_error("qed_ssim_fwd: memset failed"); return QED_E_LAUNCH; }

@@ -59,14 +59,24 @@ def ssim_value(pred_rgb: Tensor, gt_rgb: Tensor) -> Tensor:
     lib = L.load()
     H, W, _ = pred_rgb.shape
     p, g = pred_rgb.to(torch.float32).contiguous(), gt_rgb.to(torch.float32).contiguous()
-    n_maps = lib.qed_ssim_maps_floats(H, W)
-    if n_maps < 0:
+    if lib.qed_ssim_maps_floats(H, W) < 0:
         raise L.QedSplatError("image smaller than the 11 x 11 SSIM window")
-    maps = torch.empty(n_maps, dtype=torch.float32, device=p.device)
     ssum = torch.empty(1, dtype=torch.float32, device=p.device)
-    L.check(lib.qed_ssim_fwd(H, W, 3, L.ptr(p), None, None, L.ptr(g), None, L.ptr(maps), L.ptr(ssum), _stream()),
-            "qed_ssim_fwd")
+    # maps = NULL: the value only (no 75 MB of backward coefficient maps at 1080p)
+    L.check(lib.qed_ssim_fwd(H, W, 3, L.ptr(p), None, None, L.ptr(g), None, None, L.ptr(ssum), _stream()), "qed_ssim_fwd")
     return ssum.view(()) / (3.0 * (H - 10) * (W - 10))
+
+
+@torch.no_grad()
+def nanmean_exp(x: Tensor) -> Tensor:
+    """``torch.nanmean(torch.exp(x))`` of a (possibly strided) 1-D view as one pass + a fold (model.py:192-194 applies it
+    to ``self.scales[..., -1]`` every step: ~8 eager launches in the reference)."""
+    assert x.dim() == 1 and x.dtype == torch.float32
+    work = torch.empty(L.METRICS_WS_DOUBLES, dtype=torch.float64, device=x.device)
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    L.check(L.load().qed_nanmean_exp(x.numel(), L.ptr(x), x.stride(0) if x.numel() > 1 else 1, L.ptr(work), L.ptr(out),
+                                     _stream()), "qed_nanmean_exp")
+    return out.view(())
 
 
 def _to_hwc(img: Tensor) -> Tensor:

@@ -557,7 +557,8 @@ class QEDSplatterModel(nn.Module):
 
         BLOCK_WIDTH = 16                                                      # model.py:243
         camera_scale_fac = self._get_downscale_factor()
-        camera.rescale_output_resolution(1 / camera_scale_fac)
+        if camera_scale_fac != 1:                     # (x 1.0 and back is exact: eight tiny launches saved per step)
+            camera.rescale_output_resolution(1 / camera_scale_fac)
         intr = getattr(camera, "intrinsics_fxfycxcy", None)
         if intr is not None and optimized_camera_to_world.dtype == torch.float32 \
                 and not optimized_camera_to_world.requires_grad and optimized_camera_to_world.is_cuda:
@@ -572,7 +573,8 @@ class QEDSplatterModel(nn.Module):
             K = camera.get_intrinsics_matrices().to(self.device)
         W, H = int(camera.width.item()), int(camera.height.item())
         self.last_size = (H, W)
-        camera.rescale_output_resolution(camera_scale_fac)
+        if camera_scale_fac != 1:
+            camera.rescale_output_resolution(camera_scale_fac)
 
         if self.config.rasterize_mode not in ["antialiased", "classic"]:      # model.py:253-254
             raise ValueError("Unknown rasterize_mode: %s", self.config.rasterize_mode)
@@ -700,7 +702,7 @@ class QEDSplatterModel(nn.Module):
         ``gaussian_count``): the reference's ``float(...)``/``.item()`` per entry (model.py:160-182)
         is a device synchronisation each, which caps iterations/s regardless of kernel speed; the
         caller converts when (and if) it logs.  ``rgb_lpips`` is NaN (no pretrained weights here)."""
-        from .metrics import metrics_dict as _image_metrics
+        from .metrics import metrics_dict as _image_metrics, nanmean_exp
         d = self._get_downscale_factor()
 
         def resize(img):                                                       # model.py:131-147 (TF.resize, bilinear)
@@ -717,7 +719,7 @@ class QEDSplatterModel(nn.Module):
         with torch.no_grad():
             out = dict(_image_metrics(pred_rgb.detach(), gt_rgb, outputs["depth"].detach() if has_depth else None, gt_depth))
             out["gaussian_count"] = self.num_points
-            out["avg_min_scale"] = torch.nanmean(torch.exp(self.scales[..., -1]))      # model.py:192-194
+            out["avg_min_scale"] = nanmean_exp(self.scales[..., -1])                  # model.py:192-194
         return out
 
     def backward_fused(self, losses: Dict[str, Tensor]) -> None:

@@ -68,7 +68,11 @@ class _Workspace:
         host, ev = self.pending
         ev.synchronize()
         self.pending = None
-        M, overflow = int(host[0]), int(host[1])
+        M, overflow, watchdog = int(host[0]), int(host[1]), int(host[2])
+        if watchdog:
+            self.status.zero_()
+            raise L.QedSplatError("the radix-sort look-back watchdog fired in the previous asynchronous rasterization: "
+                                  "that frame's list was mis-sorted")
         if overflow:
             self.status.zero_()
             self.capacity = int(overflow * 1.5) + 4096
@@ -270,16 +274,19 @@ def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, til
             ws.last_n_isect = n_isect                  # device tensor the replaying code polls
             return None, flatten_ids, offsets, None
         if not sync:
-            host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            host = torch.empty(3, dtype=torch.int32, pin_memory=True)
             host[0:1].copy_(n_isect, non_blocking=True)
-            host[1:2].copy_(ws.status[:1], non_blocking=True)
+            host[1:3].copy_(ws.status[:2], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
             ws.pending = (host, ev)
             return None, flatten_ids, offsets, None
-        # one host read: M and the overflow word
-        host = torch.stack([n_isect[0], ws.status[0]]).tolist()
+        # one host read: M, the overflow word and the look-back watchdog word
+        host = torch.cat([n_isect, ws.status[:2]]).tolist()
         M, overflow = int(host[0]), int(host[1])
+        if host[2]:
+            ws.status.zero_()
+            raise L.QedSplatError("the radix-sort look-back watchdog fired: the list of this frame is mis-sorted")
         if overflow == 0:
             ws.capacity = max(ws.capacity, int(M * 1.25) + 4096)
             return isect_ids[:M], flatten_ids[:M], offsets, M

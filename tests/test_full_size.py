@@ -183,7 +183,7 @@ def test_cpu_baseline_sample_fused_step_matches_the_oracle(cuda):
     keep = ~_gaussians_in_tiles_of(ref["info"], ~safe, n)
     excluded = 1.0 - float(keep.float().mean())
     print(f"[parity] threshold pixels {1.0 - float(safe.float().mean()):.2e}; Gaussians excluded {excluded:.3%}")
-    assert excluded < 0.25
+    assert excluded < 0.18                                                # measured: 14.3 %
     for name in PARAM_NAMES:
         st = elem_stats(m.gauss_params[name].grad.cpu()[keep], ps[name].grad[keep], atol_frac=1e-5)
         print(f"[parity] grad {name}: worst element at {st['worst']:.2f} of (1e-4 |b| + 1e-5 max|b|), "

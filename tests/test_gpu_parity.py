@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from oracle import splat_oracle as O
-from tests.util import PARAM_NAMES, REL_TOL, activated, assert_close, scene, to_dev
+from tests.util import PARAM_NAMES, REL_TOL, activated, assert_close, assert_close_elem, scene, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -456,6 +456,11 @@ def _oracle_step(sc, w, h, cfg, mask=None, radii=None):
     return out, l_rgb, l_d, ps
 
 
+# measured fraction of Gaussians that share a tile with a threshold pixel, plus a margin (they are left out of the
+# gradient comparison; the print shows the current value)
+EXCLUDED_MAX = {(160, 112, 3000): 0.09, (256, 256, 10000): 0.06}       # measured: 7.1 %, 4.4 %
+
+
 @pytest.mark.parametrize("w,h,n", [(160, 112, 3000), (256, 256, 10000)])
 def test_end_to_end_api_path(cuda, w, h, n):
     """get_outputs + get_loss_dict (the reference's own call sequence) against the oracle."""
@@ -478,9 +483,15 @@ def test_end_to_end_api_path(cuda, w, h, n):
     # a flipped decision at a pixel changes the gradient of every Gaussian in that pixel's tile list:
     # those (few) Gaussians are left out of the gradient comparison
     keep = ~_gaussians_in_tiles_of(ref["info"], ~safe, n)
-    assert float(keep.float().mean()) > 0.8
+    excluded = 1.0 - float(keep.float().mean())
+    print(f"[parity] {w}x{h}, {n} Gaussians: threshold pixels {1.0 - float(safe.float().mean()):.2e}, "
+          f"Gaussians excluded {excluded:.2%}")
+    assert excluded < EXCLUDED_MAX[(w, h, n)]
     for name in PARAM_NAMES:
         assert_close(m.gauss_params[name].grad.cpu()[keep], ps[name].grad[keep], REL_TOL, f"grad {name}")
+        # ... and element by element: |a - b| <= 1e-4 |b| + 1e-5 max|b| (fp32 kernels against an fp64 oracle: the
+        # floor covers cancellation in small-magnitude elements; the 99.9th percentile relative error is printed)
+        assert_close_elem(m.gauss_params[name].grad.cpu()[keep], ps[name].grad[keep], f"grad {name}", atol_frac=1e-5)
     # side effects the densifier reads (model.py:249,289-292)
     assert m.last_size == (h, w) and m.xys.shape == (1, n, 2) and m.radii.shape == (n,)
     assert m.xys.grad is not None and m.xys.absgrad.shape == (1, n, 2)
@@ -562,6 +573,13 @@ def test_get_metrics_dict_keys_and_values(cuda):
     ref = O.depth_metrics(out["depth"].cpu().double(), sc["gt_depth"].double(), 0.1)
     assert float(md["depth_abs_rel"]) == pytest.approx(float(ref[0]), rel=1e-4)
     assert float(md["rgb_ssim"]) == pytest.approx(float(O.ssim(out["rgb"].cpu().double(), sc["gt_rgb"].double())), rel=1e-4)
+    # model.py:192-194: torch.nanmean(torch.exp(self.scales[..., -1])), NaNs skipped
+    want = torch.nanmean(torch.exp(sc["scales"][..., -1].double()))
+    assert float(md["avg_min_scale"]) == pytest.approx(float(want), rel=1e-5)
+    with torch.no_grad():
+        m.scales[7, -1] = float("nan")
+    assert float(m.get_metrics_dict(out, batch)["avg_min_scale"]) == pytest.approx(
+        float(torch.nanmean(torch.exp(m.scales[..., -1].detach().cpu().double()))), rel=1e-5)
 
 
 def test_tight_tile_lists_change_nothing_but_the_lists(cuda):
