@@ -968,6 +968,51 @@ class _SharedFlatState:
         self.t: Dict[int, int] = {}                    # flat offset -> steps taken
 
 
+class QedAdamSet:
+    """The per-group QedAdam instances of one model, seen as ONE optimiser over the flat buffer -- what
+    ``densify.Densifier`` needs (it rewrites parameters and both Adam moments in one pass when the number of Gaussians
+    changes, as the parent's dup_in_all_optim / remove_from_all_optim do group by group).
+
+        optimizers = {name: QedAdam([model.gauss_params[name]], lr=..., eps=1e-15) for name in model.group_names}
+        densifier = Densifier(model, QedAdamSet(model, optimizers), ...)
+    """
+
+    def __init__(self, model: "QEDSplatterModel", optimizers: Dict[str, "QedAdam"]):
+        assert set(optimizers) >= set(model.group_names), "one QedAdam per parameter group"
+        self.model, self.optimizers = model, optimizers
+
+    def _state(self) -> _SharedFlatState:
+        return self.optimizers[self.model.group_names[0]]._attach()
+
+    @property
+    def exp_avg(self) -> Tensor:
+        return self._state().exp_avg
+
+    @property
+    def exp_avg_sq(self) -> Tensor:
+        return self._state().exp_avg_sq
+
+    def rebind(self, exp_avg: Tensor, exp_avg_sq: Tensor) -> None:
+        """After ``model.rebind_flat``: point every instance at its new Parameter and adopt the new moments (the step
+        counts carry on, as torch.optim.Adam's per-parameter ``step`` does in the reference)."""
+        m = self.model
+        old = self._state_or_none()
+        steps = {}
+        for name, beg in zip(m.group_names, m.group_begin):
+            opt = self.optimizers[name]
+            old_off = opt._param().storage_offset()
+            steps[beg] = old.t.get(old_off, 0) if old is not None else 0
+            opt.param_groups[0]["params"] = [m.gauss_params[name]]
+            opt._shared = None
+        st = self._state()                                       # a fresh shared state over the new flat buffer
+        assert exp_avg.numel() == st.numel == exp_avg_sq.numel()
+        st.exp_avg, st.exp_avg_sq = exp_avg, exp_avg_sq
+        st.t.update(steps)
+
+    def _state_or_none(self) -> Optional[_SharedFlatState]:
+        return self.optimizers[self.model.group_names[0]]._shared
+
+
 _FLAT_STATES: "weakref.WeakValueDictionary[int, _SharedFlatState]" = weakref.WeakValueDictionary()
 _ALL_QED_ADAMS: "weakref.WeakSet[QedAdam]" = weakref.WeakSet()
 

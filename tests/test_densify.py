@@ -236,3 +236,99 @@ def test_graphed_step_recaptured_after_refinement(cuda):
         torch.cuda.synchronize()
     assert torch.isfinite(out["loss"]) and model.gauss_params["means"].grad.shape == (model.num_points, 3)
     assert opt.exp_avg.numel() == model.flat_params.numel()
+
+
+@pytest.mark.gpu
+def test_refinement_with_per_group_qed_adam_matches_flat_adam(cuda):
+    """The reference builds one optimiser per parameter group (config.py:44-68): six QedAdam instances behind a QedAdamSet
+    go through a refinement exactly as one FlatAdam does -- same parameters, same moments, step counts carried on -- and
+    keep training on the new Parameters."""
+    from qed_splatter_amd.densify import DensifyConfig, Densifier
+    from qed_splatter_amd.model import FlatAdam, QedAdam, QedAdamSet
+    from tests.test_gpu_parity import _model
+    from tests.util import scene
+    w, h, n = 160, 112, 3000
+    sc = scene(n, w, h, seed=21)
+    cfg = DensifyConfig(warmup_length=0, refine_every=2, densify_grad_thresh=1e-6)
+    lrs = FlatAdam.DEFAULT_LRS
+    results = []
+    for kind in ("flat", "qed"):
+        model, cam, batch = _model(sc, cuda)
+        if kind == "flat":
+            opts, opt = None, FlatAdam(model, lrs=lrs)
+        else:
+            opts = {k: QedAdam([model.gauss_params[k]], lr=lrs[k], eps=1e-15) for k in model.group_names}
+            opt = QedAdamSet(model, opts)
+        dz = Densifier(model, opt, cfg, num_train_data=0, seed=3)
+        grads = []
+        for step in range(1, 4):
+            for prm in model.parameters():
+                prm.grad = None
+            out = model.fused_loss(cam, batch)
+            out["loss"].backward()
+            if step == 1:                      # identical gradients for both kinds from here on would need identical
+                pass                           # atomics order; the statistics below are compared with a tolerance
+            if kind == "flat":
+                opt.step()
+            else:
+                for o in opts.values():
+                    o.step()
+            dz.after_train(step)
+        info = dz.refinement_after(3)
+        assert info["did_densify"] and model.num_points != n
+        for prm in model.parameters():
+            prm.grad = None
+        out = model.fused_loss(cam, batch)
+        out["loss"].backward()
+        if kind == "flat":
+            opt.step()
+        else:
+            assert all(o._param() is model.gauss_params[k] for k, o in opts.items())
+            for o in opts.values():
+                o.step()
+            assert float(opts["scales"].state_dict()["state"][0]["step"]) == 4.0
+        results.append((model, opt, info))
+    (m1, o1, i1), (m2, o2, i2) = results
+    # the decisions depend on accumulated |gradient| statistics that differ in the last bits between two runs
+    # (atomic summation order); the counts agree to a handful of borderline Gaussians
+    assert abs(i1["n_after"] - i2["n_after"]) <= 0.01 * i1["n_after"]
+    assert o2.exp_avg.numel() == m2.flat_params.numel() == o2.exp_avg_sq.numel()
+    assert bool(torch.isfinite(m2.flat_params).all()) and bool(torch.isfinite(o2.exp_avg).all())
+
+
+@pytest.mark.gpu
+def test_qed_adam_set_rebind_keeps_moments_and_steps(cuda):
+    """Deterministic check of the hand-over: after a refinement the moments the Densifier wrote are the ones the six
+    instances update, element for element the same as FlatAdam's."""
+    from qed_splatter_amd.densify import DensifyConfig, Densifier
+    from qed_splatter_amd.model import FlatAdam, QedAdam, QedAdamSet
+    p, m, v, st = _scenario(2000, seed=5, rest=15)
+    runs = []
+    for kind in ("flat", "qed"):
+        model, flat_opt = _gpu_model(p, m, v, cuda)
+        if kind == "qed":
+            opts = {k: QedAdam([model.gauss_params[k]], lr=FlatAdam.DEFAULT_LRS[k], eps=1e-15) for k in model.group_names}
+            opt = QedAdamSet(model, opts)
+            opt.exp_avg.copy_(flat_opt.exp_avg)
+            opt.exp_avg_sq.copy_(flat_opt.exp_avg_sq)
+        else:
+            opt = flat_opt
+        dz = Densifier(model, opt, DensifyConfig(), num_train_data=10, seed=1)
+        _, _, _, st2 = _scenario(2000, seed=5, rest=15)
+        dz.xys_grad_norm, dz.vis_counts, dz.max_2Dsize = (t.to(cuda) for t in (st2.xys_grad_norm, st2.vis_counts, st2.max_2Dsize))
+        info = dz.refinement_after(5000)
+        assert info["did_densify"]
+        # one Adam step on identical gradients
+        g = torch.Generator().manual_seed(2)
+        flat = (torch.randn(model.flat_params.numel(), generator=g) * 1e-3).to(cuda)
+        for k, b in zip(model.group_names, model.group_begin):
+            prm = model.gauss_params[k]
+            prm.grad = flat[b:b + prm.numel()].view(prm.shape)
+        if kind == "flat":
+            opt.step()
+        else:
+            for o in opts.values():
+                o.step()
+        runs.append((model.flat_params.detach().clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone()))
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
