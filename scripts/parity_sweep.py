@@ -67,7 +67,7 @@ for case in (range(n_cases) if only is None else [only]):
     out = O.splatfacto_outputs(ps["means"], ps["scales"], ps["quats"], ps["opacities"], ps["features_dc"], ps["features_rest"],
                                sc["camera_to_worlds"].double(), sc["Ks"].double(), w, h, sc["background"].double(),
                                sh_degree_to_use=deg, rasterize_mode=mode, radii_override=radii, return_margin=True)
-    l_rgb = O.main_loss(out["rgb"], sc["gt_rgb"].double(), cfg.ssim_lambda)
+    l_rgb = O.main_loss(out["rgb"], sc["gt_rgb"].double(), cfg.ssim_lambda, mask.double() if mask is not None else None)
     l_d = O.depth_l1_loss(out["depth"], sc["gt_depth"].double(), mask.double() if mask is not None else None, cfg.depth_lambda)
     (l_rgb + l_d).backward()
     safe = out["info"]["margin"][0] > 1e-4
