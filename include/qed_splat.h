@@ -218,7 +218,8 @@ int qed_composite_bwd(int32_t C, int32_t N, const float* splats, const int32_t* 
  * term, as the parent's get_loss_dict does behind model.py:83-85, and both depths (model.py:93-97).
  * An additional term on the same clamped colour (the SSIM part of the
  * parent's loss, qed_ssim_* below) enters through v_rgb_extra[H,W,3] = its gradient w.r.t. rgb and
- * extra_sum: losses[0] += extra_offset + extra_scale * extra_sum[0]; both pointers may be NULL. */
+ * extra_sum[extra_n] (qed_ssim_fwd's per-workgroup partials): losses[0] += extra_offset + extra_scale * sum(extra_sum);
+ * both pointers may be NULL. */
 int qed_loss_reduce(int32_t n_pix, int32_t channels, const float* render, const float* alpha,
                     const float* background, const float* gt_rgb, const float* gt_depth,
                     const float* mask, float* sums, void* stream);
@@ -226,21 +227,23 @@ int qed_loss_grad(int32_t n_pix, int32_t channels, const float* render, const fl
                   const float* background, const float* gt_rgb, const float* gt_depth,
                   const float* mask, const float* sums, float rgb_weight, float depth_lambda,
                   float* v_render, float* v_alpha, float* losses, const float* v_rgb_extra,
-                  const float* extra_sum, float extra_scale, float extra_offset, void* stream);
+                  const float* extra_sum, int32_t extra_n, float extra_scale, float extra_offset, void* stream);
 
 /* ---- SSIM term of the parent's RGB loss (reached from model.py:83-85) ----------
  * pytorch_msssim semantics: data_range 1, 11-tap Gaussian window (sigma 1.5) applied separably with
  * no padding, K = (0.01, 0.03), mean over the (H-10) x (W-10) map and 3 channels.
  * pred is either a plain [H,W,3] image (alpha == NULL) or the compositor's render[H,W,channels]
  * together with alpha[H,W] and background[3], in which case the colour clamp(render + (1-alpha) bg)
- * of model.py:296-297 is formed on the fly.  qed_ssim_fwd writes ssim_sum[0] = sum of the SSIM map
- * (SSIM = ssim_sum / (3 (H-10)(W-10))) and, unless maps == NULL (value only: the rgb_ssim metric), the
+ * of model.py:296-297 is formed on the fly.  qed_ssim_fwd writes one partial sum of the SSIM map per workgroup into
+ * ssim_sum[qed_ssim_sum_floats(H, W)] (SSIM = sum of them / (3 (H-10)(W-10)); nothing to zero, no same-address
+ * atomics) and, unless maps == NULL (value only: the rgb_ssim metric), the
  * coefficient maps (qed_ssim_maps_floats floats) that
  * qed_ssim_bwd turns into v_pred[H,W,3] = scale * (scale_dev ? scale_dev[0] : 1) * d ssim_sum / d colour
  * (scale_dev: an upstream gradient that lives in device memory).  mask[H,W] (may be NULL) multiplies
  * both images before the SSIM, as the parent's loss does; v_pred is the gradient w.r.t. the colour
  * BEFORE that multiply. */
 int64_t qed_ssim_maps_floats(int32_t height, int32_t width);
+int64_t qed_ssim_sum_floats(int32_t height, int32_t width);
 int qed_ssim_fwd(int32_t height, int32_t width, int32_t channels, const float* pred, const float* alpha,
                  const float* background, const float* gt_rgb, const float* mask, float* maps,
                  float* ssim_sum, void* stream);
@@ -258,7 +261,7 @@ int qed_ssim_bwd(int32_t height, int32_t width, int32_t channels, const float* p
  * workspace: QED_LOSS_SUMS_FLOATS floats.  bwd: v_rgb / v_depth (either may be NULL) -> v_render, v_alpha.
  *
  * qed_image_losses_fwd/bwd = the parent's main loss (behind model.py:83-85) + the depth term (:87-116):
- *   losses[0] = rgb_weight * mean|m rgb - m gt| + extra_offset + extra_scale * extra_sum[0]
+ *   losses[0] = rgb_weight * mean|m rgb - m gt| + extra_offset + extra_scale * sum(extra_sum[0 .. extra_n))
  *   losses[1] = depth_lambda * sum|m d - m dgt| / n_valid   (finite & dgt > 0; 0 when nothing is valid)
  * with extra_* the SSIM term (qed_ssim_fwd on the same images).  depth / gt_depth / mask may be NULL.
  * sums: QED_LOSS_SUMS_FLOATS floats, kept for the backward.  bwd: v_rgb = g_main[0] * d losses[0] / d rgb
@@ -271,8 +274,8 @@ int qed_post_process_bwd(int32_t n_pix, int32_t channels, const float* render, c
                          float* v_render, float* v_alpha, void* stream);
 int qed_image_losses_fwd(int32_t n_pix, const float* rgb, const float* depth, const float* gt_rgb,
                          const float* gt_depth, const float* mask, float rgb_weight, float depth_lambda,
-                         const float* extra_sum, float extra_scale, float extra_offset, float* sums,
-                         float* losses, void* stream);
+                         const float* extra_sum, int32_t extra_n, float extra_scale, float extra_offset,
+                         float* sums, float* losses, void* stream);
 int qed_image_losses_bwd(int32_t n_pix, const float* rgb, const float* depth, const float* gt_rgb,
                          const float* gt_depth, const float* mask, const float* sums, float rgb_weight,
                          float depth_lambda, const float* g_main, const float* g_depth, int32_t accumulate,

@@ -39,7 +39,7 @@ SIGNATURES = {
     "qed_composite_fwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
     "qed_composite_bwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "qed_loss_reduce": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "qed_loss_grad": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _F, _F, _P]),
+    "qed_loss_grad": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _I, _F, _F, _P]),
     "qed_sh_grad_from_views": (C.c_int, [_I, _I, _P, _P, _L, _P, _L, _I, _F, _P, _I, _P, _I, _P]),
     "qed_lr_exp_decay_dev": (C.c_int, [_P, _P, _F, _F, _I, _P]),
     "qed_densify_accumulate": (C.c_int, [_I, _P, _I, _P, _F, _P, _P, _P, _P]),
@@ -52,11 +52,12 @@ SIGNATURES = {
     "qed_image_metrics": (C.c_int, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
     "qed_nanmean_exp": (C.c_int, [_I, _P, _I, _P, _P, _P]),
     "qed_ssim_maps_floats": (C.c_int64, [_I, _I]),
+    "qed_ssim_sum_floats": (C.c_int64, [_I, _I]),
     "qed_ssim_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qed_ssim_bwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P]),
     "qed_post_process_fwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "qed_post_process_bwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "qed_image_losses_fwd": (C.c_int, [_I, _P, _P, _P, _P, _P, _F, _F, _P, _F, _F, _P, _P, _P]),
+    "qed_image_losses_fwd": (C.c_int, [_I, _P, _P, _P, _P, _P, _F, _F, _P, _I, _F, _F, _P, _P, _P]),
     "qed_image_losses_bwd": (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _I, _P, _P, _P]),
     "qed_adam_step": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _F, _F, _F, _I, _P]),
     "qed_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _F, _F, _F, _P, _P]),

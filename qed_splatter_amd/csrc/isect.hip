@@ -279,16 +279,10 @@ __device__ __forceinline__ int wave_bucket_rank(bool valid, unsigned d, int* cnt
     return r;
 }
 
-__global__ void __launch_bounds__(256)
-tile_depth_sort_wave_kernel(const int* __restrict__ offsets, const int* __restrict__ vals_in,
-                            const float* __restrict__ depths, int* __restrict__ vals_out, int n_tiles_total) {
-    __shared__ __attribute__((aligned(16))) uint2 s_kv[4][kTileWaveItems];      // (key, value) pairs of a run
-    __shared__ __attribute__((aligned(16))) int s_cnt[4][kTileBuckets];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int tile = blockIdx.x * 4 + wid;
-    if (tile >= n_tiles_total) return;
-    const int start = offsets[tile], n = offsets[tile + 1] - start;
-    if (n <= 0 || n > kTileWaveItems) return;
+// one wave sorts the run [start, start + n), 1 <= n <= kTileWaveItems; kv / cnt: this wave's LDS
+__device__ __forceinline__ void tile_sort_wave(int start, int n, int lane, uint2* __restrict__ kv, int* __restrict__ cnt,
+                                               const int* __restrict__ vals_in, const float* __restrict__ depths,
+                                               int* __restrict__ vals_out) {
     if (n == 1) {
         if (lane == 0) vals_out[start] = vals_in[start];
         return;
@@ -315,8 +309,6 @@ tile_depth_sort_wave_kernel(const int* __restrict__ offsets, const int* __restri
         kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, o, 64));
         kmax = max(kmax, (unsigned)__shfl_xor((int)kmax, o, 64));
     }
-    int* cnt = s_cnt[wid];
-    uint2* kv = s_kv[wid];
     if (kmin == kmax) {                                    // one depth: the slot order is the answer
 #pragma unroll
         for (int k = 0; k < kTileWaveKpt; ++k) {
@@ -441,21 +433,14 @@ tile_depth_sort_wave_kernel(const int* __restrict__ offsets, const int* __restri
     }
 }
 
-__global__ void __launch_bounds__(256)
-tile_depth_sort_kernel(const int* __restrict__ offsets, const int* __restrict__ vals_in, const float* __restrict__ depths,
-                       int* __restrict__ vals_out, unsigned* __restrict__ gk0, unsigned* __restrict__ gk1,
-                       int* __restrict__ gv0, int* __restrict__ gv1, int n_tiles_total) {
-    __shared__ unsigned s_keys[kTileSortItems];
-    __shared__ int s_vals[kTileSortItems];
-    __shared__ int s_cnt[4][256];
-    __shared__ int s_base[256];
-    __shared__ int s_wsum[4];
-    __shared__ int s_skip[4];                           // per pass: one digit holds the whole run
+// a 256-thread workgroup sorts the run [start, start + n), n > kTileWaveItems: in LDS up to kTileSortItems entries, through
+// global scratch beyond
+__device__ __forceinline__ void tile_sort_long_run(int start, int n, const int* __restrict__ vals_in,
+                                                   const float* __restrict__ depths, int* __restrict__ vals_out,
+                                                   unsigned* __restrict__ gk0, unsigned* __restrict__ gk1,
+                                                   int* __restrict__ gv0, int* __restrict__ gv1, unsigned* s_keys,
+                                                   int* s_vals, int (*s_cnt)[256], int* s_base, int* s_wsum, int* s_skip) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  for (int tile = blockIdx.x; tile < n_tiles_total; tile += gridDim.x) {
-    const int start = offsets[tile], n = offsets[tile + 1] - start;
-    if (n <= kTileWaveItems) continue;                  // short runs: tile_depth_sort_wave_kernel
-    __syncthreads();                                    // (the previous tile's LDS reads are done)
     // exclusive scan over the 256 digits of per-digit totals held one per thread; returns this digit's base
     auto digit_scan = [&](int tot) {
         int x = tot;
@@ -533,7 +518,7 @@ tile_depth_sort_kernel(const int* __restrict__ offsets, const int* __restrict__ 
                 if (mine(k)) { key[k] = s_keys[wbase + k * 64 + lane]; val[k] = s_vals[wbase + k * 64 + lane]; }
             }
         }
-        continue;
+        return;
     }
     // ---- long runs: the same passes through global scratch, one row of 256 entries at a time ----
     const unsigned* ksrc = nullptr;        // pass 0 gathers the depth bits
@@ -588,7 +573,36 @@ tile_depth_sort_kernel(const int* __restrict__ offsets, const int* __restrict__ 
         ksrc = kdst;
         vsrc = vdst;
     }
-  }
+}
+
+// One workgroup = four tiles.  Runs of <= kTileWaveItems entries (nearly all at config B): one wave each, no workgroup
+// barrier.  Longer runs among the four: afterwards, by all 256 threads together, in the same LDS.
+__global__ void __launch_bounds__(256)
+tile_depth_sort_kernel(const int* __restrict__ offsets, const int* __restrict__ vals_in, const float* __restrict__ depths,
+                       int* __restrict__ vals_out, unsigned* __restrict__ gk0, unsigned* __restrict__ gk1,
+                       int* __restrict__ gv0, int* __restrict__ gv1, int n_tiles_total) {
+    __shared__ __attribute__((aligned(16))) uint2 s_kv[4][kTileWaveItems];      // (key, value) pairs of a run
+    __shared__ __attribute__((aligned(16))) int s_cnt[4][kTileBuckets];
+    __shared__ int s_wsum[4], s_skip[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int tile = blockIdx.x * 4 + wid;
+    int start = 0, n = 0;
+    if (tile < n_tiles_total) { start = offsets[tile]; n = offsets[tile + 1] - start; }
+    if (n >= 1 && n <= kTileWaveItems) tile_sort_wave(start, n, lane, s_kv[wid], s_cnt[wid], vals_in, depths, vals_out);
+    if (!__syncthreads_or(n > kTileWaveItems)) return;
+    static_assert(sizeof(s_kv) >= kTileSortItems * 8 && sizeof(s_cnt) >= (4 * 256 + 256) * 4, "LDS aliasing");
+    unsigned* keys = reinterpret_cast<unsigned*>(&s_kv[0][0]);
+    int* vals = reinterpret_cast<int*>(keys + kTileSortItems);
+    int (*cnt)[256] = reinterpret_cast<int (*)[256]>(&s_cnt[0][0]);
+    int* base = &s_cnt[0][0] + 4 * 256;
+    for (int j = 0; j < 4; ++j) {
+        const int t = blockIdx.x * 4 + j;
+        if (t >= n_tiles_total) break;
+        const int s0 = offsets[t], m = offsets[t + 1] - s0;
+        if (m <= kTileWaveItems) continue;
+        __syncthreads();
+        tile_sort_long_run(s0, m, vals_in, depths, vals_out, gk0, gk1, gv0, gv1, keys, vals, cnt, base, s_wsum, s_skip);
+    }
 }
 
 // gsplat-style 64-bit keys of the sorted list (info["isect_ids"]), rebuilt on demand
@@ -712,9 +726,7 @@ extern "C" int qed_bin_tiles(int32_t N, int32_t C, const float* means2d, const i
         hipLaunchKernelGGL(tile_offsets_kernel<unsigned>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, tile_keys,
                            (const int*)n_isect, (int)n_tot, tile_w * tile_h, tile_bits, offsets);
         // (3) every tile's run into depth order (stable: ties stay in slot order)
-        hipLaunchKernelGGL(tile_depth_sort_wave_kernel, dim3((unsigned)((n_tot + 3) / 4)), dim3(256), 0, st,
-                           (const int*)offsets, (const int*)vB, depths, flatten_ids, (int)n_tot);
-        hipLaunchKernelGGL(tile_depth_sort_kernel, dim3((unsigned)(n_tot < 2048 ? n_tot : 2048)), dim3(256), 0, st,
+        hipLaunchKernelGGL(tile_depth_sort_kernel, dim3((unsigned)((n_tot + 3) / 4)), dim3(256), 0, st,
                            (const int*)offsets, (const int*)vB, depths, flatten_ids, k_spare, (unsigned*)(w + L.tk1),
                            (int*)(w + L.tv0), (int*)(w + L.tv1), (int)n_tot);
         if (isect_ids != nullptr)

@@ -178,20 +178,22 @@ loss_grad_kernel(int n_pix, const float* __restrict__ render, const float* __res
 // measured ~20 ns per workgroup, serialised.
 __global__ void __launch_bounds__(256)
 loss_finalize_kernel(int n_pix, int n_blocks, int has_depth, float* __restrict__ sums, float rgb_weight,
-                     float depth_lambda, float* __restrict__ losses, const float* __restrict__ extra_sum,
+                     float depth_lambda, float* __restrict__ losses, const float* __restrict__ extra_sum, int extra_n,
                      float extra_scale, float extra_offset) {
-    float nv = 0.f, dm = -3.0e38f, tl = 0.f, td = 0.f;
+    float nv = 0.f, dm = -3.0e38f, tl = 0.f, td = 0.f, ex = 0.f;
+    if (extra_sum != nullptr)                               // per-workgroup partials of the SSIM map sum (qed_ssim_fwd)
+        for (int b = threadIdx.x; b < extra_n; b += 256) ex += extra_sum[b];
     for (int b = threadIdx.x; b < n_blocks; b += 256) {
         if (has_depth) nv += loss_part(sums, 0)[b];                      // has_depth < 0: a valid count but no max row
         if (has_depth > 0) dm = fmaxf(dm, loss_part(sums, 1)[b]);
         tl += loss_part(sums, 2)[b];
         td += loss_part(sums, 3)[b];
     }
-    nv = wave_sum(nv); dm = wave_max(dm); tl = wave_sum(tl); td = wave_sum(td);
-    __shared__ float s[4][4];
+    nv = wave_sum(nv); dm = wave_max(dm); tl = wave_sum(tl); td = wave_sum(td); ex = wave_sum(ex);
+    __shared__ float s[5][4];
     if ((threadIdx.x & 63) == 0) {
         const int w = threadIdx.x >> 6;
-        s[0][w] = nv; s[1][w] = dm; s[2][w] = tl; s[3][w] = td;
+        s[0][w] = nv; s[1][w] = dm; s[2][w] = tl; s[3][w] = td; s[4][w] = ex;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -200,7 +202,7 @@ loss_finalize_kernel(int n_pix, int n_blocks, int has_depth, float* __restrict__
         const float tot_l1 = s[2][0] + s[2][1] + s[2][2] + s[2][3], tot_d = s[3][0] + s[3][1] + s[3][2] + s[3][3];
         sums[0] = tot_l1; sums[1] = tot_d; sums[2] = nvalid; sums[3] = has_depth > 0 ? dmax : 0.f;
         losses[0] = rgb_weight * tot_l1 / (3.f * (float)n_pix);
-        if (extra_sum != nullptr) losses[0] += extra_offset + extra_scale * extra_sum[0];
+        if (extra_sum != nullptr) losses[0] += extra_offset + extra_scale * (s[4][0] + s[4][1] + s[4][2] + s[4][3]);
         losses[1] = nvalid > 0.f ? depth_lambda * tot_d / nvalid : 0.f;       // empty -> 0.0 (model.py:111-114)
         losses[2] = losses[0] + losses[1];
     }
@@ -624,7 +626,7 @@ extern "C" int qed_loss_grad(int32_t n_pix, int32_t channels, const float* rende
                              const float* background, const float* gt_rgb, const float* gt_depth, const float* mask,
                              const float* sums, float rgb_weight, float depth_lambda, float* v_render,
                              float* v_alpha, float* losses, const float* v_rgb_extra, const float* extra_sum,
-                             float extra_scale, float extra_offset, void* stream) {
+                             int32_t extra_n, float extra_scale, float extra_offset, void* stream) {
     QED_REQUIRE(n_pix > 0 && (channels == 3 || channels == 4), "bad arguments");
     QED_REQUIRE(render && alpha && background && gt_rgb && sums && v_render && v_alpha && losses, "null buffers");
     QED_REQUIRE(channels == 3 || gt_depth, "gt_depth required with a depth channel");
@@ -638,7 +640,7 @@ extern "C" int qed_loss_grad(int32_t n_pix, int32_t channels, const float* rende
         hipLaunchKernelGGL(loss_grad_kernel<3>, dim3(grid), dim3(256), 0, st, n_pix, render, alpha, background, gt_rgb,
                            gt_depth, mask, sums_rw, rgb_weight, depth_lambda, v_render, v_alpha, v_rgb_extra);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, n_pix, (int)grid, channels == 4 ? 1 : 0, sums_rw,
-                       rgb_weight, depth_lambda, losses, extra_sum, extra_scale, extra_offset);
+                       rgb_weight, depth_lambda, losses, extra_sum, (int)extra_n, extra_scale, extra_offset);
     return check_launch("qed_loss_grad");
 }
 
@@ -679,8 +681,8 @@ extern "C" int qed_post_process_bwd(int32_t n_pix, int32_t channels, const float
 
 extern "C" int qed_image_losses_fwd(int32_t n_pix, const float* rgb, const float* depth, const float* gt_rgb,
                                     const float* gt_depth, const float* mask, float rgb_weight, float depth_lambda,
-                                    const float* extra_sum, float extra_scale, float extra_offset, float* sums,
-                                    float* losses, void* stream) {
+                                    const float* extra_sum, int32_t extra_n, float extra_scale, float extra_offset,
+                                    float* sums, float* losses, void* stream) {
     QED_REQUIRE(n_pix > 0, "bad arguments");
     QED_REQUIRE(rgb && gt_rgb && sums && losses, "null buffers");
     QED_REQUIRE(depth == nullptr || gt_depth, "gt_depth required with a depth image");
@@ -690,7 +692,7 @@ extern "C" int qed_image_losses_fwd(int32_t n_pix, const float* rgb, const float
                        sums);
     // has_depth = -1: fold row 0 (the valid count) but no row of maxima
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, n_pix, (int)grid, -1, sums, rgb_weight,
-                       depth_lambda, losses, extra_sum, extra_scale, extra_offset);
+                       depth_lambda, losses, extra_sum, (int)extra_n, extra_scale, extra_offset);
     return check_launch("qed_image_losses_fwd");
 }
 

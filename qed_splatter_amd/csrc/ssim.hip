@@ -236,7 +236,9 @@ ssim_fwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
     acc = wave_sum(acc);
     if ((tid & 63) == 0) s_red[tid >> 6] = acc;
     __syncthreads();
-    if (tid == 0) atomicAdd(ssim_sum, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+    // one partial per workgroup (folded by the consumer): no zeroing launch in front of the kernel and no 2 040
+    // same-address atomics behind it
+    if (tid == 0) ssim_sum[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
 }
 
 // v_pred[H,W,3] = scale * (scale_dev ? scale_dev[0] : 1) * d(sum of the SSIM map)/d pred, pred = the colour BEFORE the
@@ -351,6 +353,11 @@ using Tile = SsimTile<32, 32>;
 using namespace qed;
 
 
+extern "C" int64_t qed_ssim_sum_floats(int32_t height, int32_t width) {
+    if (height <= kHalo || width <= kHalo) return QED_E_INVALID_ARG;
+    return (int64_t)((width - kHalo + Tile::TW - 1) / Tile::TW) * ((height - kHalo + Tile::TH - 1) / Tile::TH);
+}
+
 extern "C" int64_t qed_ssim_maps_floats(int32_t height, int32_t width) {
     if (height <= kHalo || width <= kHalo) return QED_E_INVALID_ARG;
     return 9ll * (height - kHalo) * (width - kHalo);
@@ -363,7 +370,6 @@ extern "C" int qed_ssim_fwd(int32_t height, int32_t width, int32_t channels, con
     QED_REQUIRE(pred && gt_rgb && ssim_sum, "null buffers");
     QED_REQUIRE(alpha == nullptr || (background && (channels == 3 || channels == 4)), "composite mode needs a background");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(ssim_sum, 0, sizeof(float), st) != hipSuccess) { set_error("qed_ssim_fwd: memset failed"); return QED_E_LAUNCH; }
     const dim3 grid(((width - kHalo + Tile::TW - 1) / Tile::TW) * ((height - kHalo + Tile::TH - 1) / Tile::TH));
 #define QED_SSIM_FWD(COMP, MASK, CHN)                                                                               \
     hipLaunchKernelGGL((ssim_fwd_kernel<COMP, MASK, Tile>), grid, dim3(256), 0, st, height, width, CHN, pred, alpha,   \

@@ -61,10 +61,10 @@ def ssim_value(pred_rgb: Tensor, gt_rgb: Tensor) -> Tensor:
     p, g = pred_rgb.to(torch.float32).contiguous(), gt_rgb.to(torch.float32).contiguous()
     if lib.qed_ssim_maps_floats(H, W) < 0:
         raise L.QedSplatError("image smaller than the 11 x 11 SSIM window")
-    ssum = torch.empty(1, dtype=torch.float32, device=p.device)
+    ssum = torch.empty(lib.qed_ssim_sum_floats(H, W), dtype=torch.float32, device=p.device)
     # maps = NULL: the value only (no 75 MB of backward coefficient maps at 1080p)
     L.check(lib.qed_ssim_fwd(H, W, 3, L.ptr(p), None, None, L.ptr(g), None, None, L.ptr(ssum), _stream()), "qed_ssim_fwd")
-    return ssum.view(()) / (3.0 * (H - 10) * (W - 10))
+    return ssum.sum() / (3.0 * (H - 10) * (W - 10))
 
 
 @torch.no_grad()

@@ -167,11 +167,11 @@ class _SSIM(torch.autograd.Function):
         if n_maps < 0:
             raise L.QedSplatError("qed_ssim_maps_floats: image smaller than the 11 x 11 SSIM window")
         maps = torch.empty(n_maps, dtype=torch.float32, device=pred.device)
-        ssum = torch.empty(1, dtype=torch.float32, device=pred.device)
+        ssum = torch.empty(lib.qed_ssim_sum_floats(H, W), dtype=torch.float32, device=pred.device)
         L.check(lib.qed_ssim_fwd(H, W, 3, L.ptr(pred), None, None, L.ptr(gt), None, L.ptr(maps), L.ptr(ssum),
                                  _stream()), "qed_ssim_fwd")
         ctx.save_for_backward(pred, gt, maps)
-        return ssum.view(()) / (3.0 * (H - 10) * (W - 10))
+        return ssum.sum() / (3.0 * (H - 10) * (W - 10))
 
     @staticmethod
     def backward(ctx, v):
@@ -263,17 +263,17 @@ class _ImageLosses(torch.autograd.Function):
         sums = torch.empty(L.LOSS_SUMS_FLOATS, dtype=torch.float32, device=dev)
         losses = torch.empty(3, dtype=torch.float32, device=dev)
         maps = None
-        extra = (None, 0.0, 0.0)
+        extra = (None, 0, 0.0, 0.0)
         if ssim_lambda > 0.0:
             n_out = 3.0 * (H - 10) * (W - 10)
             n_maps = lib.qed_ssim_maps_floats(H, W)
             if n_maps < 0:
                 raise L.QedSplatError("image smaller than the 11 x 11 SSIM window")
             maps = torch.empty(n_maps, dtype=torch.float32, device=dev)
-            ssum = torch.empty(1, dtype=torch.float32, device=dev)
+            ssum = torch.empty(lib.qed_ssim_sum_floats(H, W), dtype=torch.float32, device=dev)
             L.check(lib.qed_ssim_fwd(H, W, 3, L.ptr(rgb), None, None, L.ptr(gt_rgb), L.ptr(mask), L.ptr(maps),
                                      L.ptr(ssum), st), "qed_ssim_fwd")
-            extra = (L.ptr(ssum), -ssim_lambda / n_out, ssim_lambda)
+            extra = (L.ptr(ssum), ssum.numel(), -ssim_lambda / n_out, ssim_lambda)
         L.check(lib.qed_image_losses_fwd(n_pix, L.ptr(rgb), L.ptr(depth), L.ptr(gt_rgb), L.ptr(gt_depth), L.ptr(mask),
                                          1.0 - ssim_lambda, depth_lambda, *extra, L.ptr(sums), L.ptr(losses), st),
                 "qed_image_losses_fwd")
@@ -324,20 +324,20 @@ class _FusedImageLoss(torch.autograd.Function):
         v_render = torch.empty_like(render)
         v_alpha = torch.empty_like(alpha)
         st = _stream()
-        extra = (None, None, 0.0, 0.0)
+        extra = (None, None, 0, 0.0, 0.0)
         if ssim_lambda > 0.0:
             # main = (1 - l) L1 + l (1 - SSIM): the SSIM gradient w.r.t. the clamped colour is formed
             # first and pass 2 below pushes it through the clamp / background composite with the L1 part
             n_out = 3.0 * (H - 10) * (W - 10)
             maps = torch.empty(lib.qed_ssim_maps_floats(H, W), dtype=torch.float32, device=dev)
             v_rgb = torch.empty(H, W, 3, dtype=torch.float32, device=dev)
-            ssum = torch.empty(1, dtype=torch.float32, device=dev)
+            ssum = torch.empty(lib.qed_ssim_sum_floats(H, W), dtype=torch.float32, device=dev)
             L.check(lib.qed_ssim_fwd(H, W, CH, L.ptr(render), L.ptr(alpha), L.ptr(background), L.ptr(gt_rgb),
                                      L.ptr(mask), L.ptr(maps), L.ptr(ssum), st), "qed_ssim_fwd")
             L.check(lib.qed_ssim_bwd(H, W, CH, L.ptr(render), L.ptr(alpha), L.ptr(background), L.ptr(gt_rgb),
                                      L.ptr(mask), L.ptr(maps), -ssim_lambda / n_out, None, L.ptr(v_rgb), st),
                     "qed_ssim_bwd")
-            extra = (L.ptr(v_rgb), L.ptr(ssum), -ssim_lambda / n_out, ssim_lambda)
+            extra = (L.ptr(v_rgb), L.ptr(ssum), ssum.numel(), -ssim_lambda / n_out, ssim_lambda)
         args = (n_pix, CH, L.ptr(render), L.ptr(alpha), L.ptr(background), L.ptr(gt_rgb), L.ptr(gt_depth), L.ptr(mask))
         L.check(lib.qed_loss_reduce(*args, L.ptr(sums), st), "qed_loss_reduce")
         L.check(lib.qed_loss_grad(*args, L.ptr(sums), 1.0 - ssim_lambda, depth_lambda, L.ptr(v_render),

@@ -18,7 +18,7 @@ alpha = torch.rand(H, W, 1, device=dev)
 bg = torch.rand(3, device=dev)
 gt = torch.rand(H, W, 3, device=dev)
 maps = torch.empty(lib.qed_ssim_maps_floats(H, W), device=dev)
-ssum = torch.empty(1, device=dev)
+ssum = torch.empty(lib.qed_ssim_sum_floats(H, W), device=dev)
 v = torch.empty(H, W, 3, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]

@@ -141,7 +141,7 @@ def test_reference_depth_l1_kats_through_both_kernel_paths(cuda, lib):
         v_r, v_a = torch.empty_like(render), torch.empty_like(alpha)
         args = (H * W, 4, L.ptr(render), L.ptr(alpha), L.ptr(bg), L.ptr(rgb), L.ptr(g), L.ptr(mask))
         L.check(lib.qed_loss_reduce(*args, L.ptr(sums), st), "reduce")
-        L.check(lib.qed_loss_grad(*args, L.ptr(sums), 1.0, lam, L.ptr(v_r), L.ptr(v_a), L.ptr(losses), None, None, 0.0,
+        L.check(lib.qed_loss_grad(*args, L.ptr(sums), 1.0, lam, L.ptr(v_r), L.ptr(v_a), L.ptr(losses), None, None, 0, 0.0,
                                   0.0, st), "grad")
         assert float(losses[1]) == pytest.approx(want, rel=1e-6, abs=1e-9)
         # NaN renders must not poison the gradient of the other pixels
