@@ -247,9 +247,9 @@ __device__ __forceinline__ int wave_digit_rank(bool valid, unsigned d, int* cnt,
 // 64).  A run is a few hundred depths, so a full 4-pass radix sort is overkill:
 //   (1) ONE stable counting pass on a 9-bit bucket  b = floor((key - kmin) * 511.99 / (kmax - kmin))  -- monotone in the
 //       key, ranks from the same ballot match, the 512 bucket totals scanned by the wave itself (8 per lane);
-//   (2) the run, now ordered by bucket, is finished by odd-even transposition with a strict compare (stable: equal
-//       depths keep their slot order).  Two keys can only be out of order inside one bucket, so it converges in
-//       (largest bucket) rounds -- one or two for a spread of depths.
+//   (2) the run is now ordered by bucket and two keys can only be out of order inside one bucket, so every entry
+//       counts the members of its own bucket that sort before it (smaller depth, or equal depth and earlier slot:
+//       stable) and that count is its place -- a few LDS reads per entry for a spread of depths.
 // Runs with a crowded bucket (> kTileBucketMax) take four stable 8-bit radix passes instead, like the long runs that
 // are left to tile_depth_sort_kernel.
 constexpr int kTileWaveKpt = 8;
@@ -359,27 +359,24 @@ __device__ __forceinline__ void tile_sort_wave(int start, int n, int lane, uint2
             if (k * 64 + lane < n) kv[cnt[bkt[k]] + rank[k]] = make_uint2(key[k], (unsigned)val[k]);
         }
         wave_lds_fence();
-        // ---- (2) odd-even transposition, strict compare; a round without a swap ends it ----
-        const int n_even = n >> 1, n_odd = (n - 1) >> 1;   // pairs (2 j, 2 j + 1) and (2 j + 1, 2 j + 2)
-        for (int round = 0; round <= kTileBucketMax; ++round) {
-            bool swapped = false;
-            for (int j = lane; j < n_even; j += 64) {
-                const uint4 p = *reinterpret_cast<const uint4*>(&kv[2 * j]);
-                if (p.x > p.z) { *reinterpret_cast<uint4*>(&kv[2 * j]) = make_uint4(p.z, p.w, p.x, p.y); swapped = true; }
-            }
-            wave_lds_fence();
-            for (int j = lane; j < n_odd; j += 64) {
-                const uint2 lo = kv[2 * j + 1], hi = kv[2 * j + 2];
-                if (lo.x > hi.x) { kv[2 * j + 1] = hi; kv[2 * j + 2] = lo; swapped = true; }
-            }
-            wave_lds_fence();
-            if (__ballot(swapped) == 0ull) break;
-        }
+        // ---- (2) place every entry inside its bucket: its offset there is the number of bucket members that sort
+        // before it (smaller depth, or the same depth and earlier in slot order = smaller rank).  Buckets hold a handful
+        // of entries, so this is a few LDS reads per entry and ONE pass (an odd-even transposition took 3-5 rounds of
+        // two fenced phases each) ----
 #pragma unroll
         for (int k = 0; k < kTileWaveKpt; ++k) {
             if (k >= rows) break;
             const int li = k * 64 + lane;
-            if (li < n) vals_out[start + li] = (int)kv[li].y;
+            if (li < n) {
+                const int b0 = cnt[bkt[k]];
+                const int b1 = bkt[k] + 1 < kTileBuckets ? cnt[bkt[k] + 1] : n;
+                int before = 0;
+                for (int j = b0; j < b1; ++j) {
+                    const unsigned other = kv[j].x;
+                    before += (other < key[k]) | ((other == key[k]) & (j - b0 < rank[k]));
+                }
+                vals_out[start + b0 + before] = val[k];
+            }
         }
         return;
     }
