@@ -210,7 +210,7 @@ def main():
 
     from qed_splatter_amd import _lib as L
     from qed_splatter_amd.model import FlatAdam, PinholeCameras, QEDSplatterModel, QEDSplatterModelConfig
-    from qed_splatter_amd.parallel import allreduce_flat_grad, exchange_grads_compact
+    from qed_splatter_amd.parallel import allreduce_flat_grad, exchange_grads_compact_begin
     L.load()
 
     n, w, h = args.gaussians, args.width, args.height
@@ -244,11 +244,19 @@ def main():
     dp_compact = not args.dp_plain and not args.plain_adam
     fused_sh = dp_compact
 
-    def exchange():
+    def exchange_and_step(adam_sh, adam_leading, adam_all):
+        """N > 1.  Compact exchange: the all-gather of the colour gradients is issued first and the SH part of the
+        optimiser (two thirds of its time) runs behind it while the geometry all-reduce is still on the links; the
+        leading groups follow that all-reduce.  --dp-plain: one all-reduce of the flat gradient, then the step."""
         if dp_compact:
-            exchange_grads_compact(model, world, rebuild=False)
+            ex = exchange_grads_compact_begin(model, world)
+            ex.wait_views()
+            adam_sh()
+            ex.wait_geometry()
+            adam_leading()
         else:
             allreduce_flat_grad(model, world)
+            adam_all()
 
     def step(sync):
         for p in model.parameters():
@@ -256,8 +264,10 @@ def main():
         losses = model.fused_loss(cam, batch, background=bg, sync=sync, compact_sh_grad=dp_compact)
         model.backward_fused(losses)
         if world > 1:
-            exchange()
-        opt.step(fused_sh=fused_sh)
+            exchange_and_step(lambda: opt.step(fused_sh=True, part=1), lambda: opt.step(fused_sh=True, part=2),
+                              lambda: opt.step(fused_sh=fused_sh))
+        else:
+            opt.step(fused_sh=fused_sh)
         return losses
 
     def log(msg):
@@ -333,6 +343,14 @@ def main():
             opt.step(device_state=True, fused_sh=fused_sh)
             return {}
 
+        def adam_sh_part():
+            opt.step(device_state=True, fused_sh=True, part=1)
+            return {}
+
+        def adam_leading_part():
+            opt.step(device_state=True, fused_sh=True, part=2)
+            return {}
+
         def graph_step():
             losses = fwd_bwd()
             adam_only()
@@ -343,17 +361,30 @@ def main():
             if split:
                 g_fb = GraphedTrainStep(fwd_bwd, dev, warmup=3, check_every=0)
                 g_fb.replay()                          # fills the captured (static) .grad buffers before Adam's
-                if world > 1:                          # warm-up run reads them; keep the replicas identical
-                    exchange()
-                g_adam = GraphedTrainStep(adam_only, dev, warmup=1, check_every=0)
-                graphed = g_fb
+                graphed = g_fb                         # warm-up run reads them; keep the replicas identical
+                if world > 1 and dp_compact:
+                    ex = exchange_grads_compact_begin(model, world)
+                    ex.wait_views()
+                    ex.wait_geometry()
+                    g_sh = GraphedTrainStep(adam_sh_part, dev, warmup=1, check_every=0)
+                    g_lead = GraphedTrainStep(adam_leading_part, dev, warmup=1, check_every=0)
 
-                def run():
-                    g_fb.replay()
+                    def run():
+                        g_fb.replay()
+                        exchange_and_step(g_sh.replay, g_lead.replay, None)
+                    dispatch = ("three hipGraphs (fwd+bwd | Adam SH groups | Adam leading groups): all-gather, SH groups "
+                                "behind it while the geometry all-reduce is on the links, leading groups")
+                else:
                     if world > 1:
-                        exchange()
-                    g_adam.replay()
-                dispatch = "two hipGraphs (fwd+bwd | Adam) around the gradient all-reduce"
+                        allreduce_flat_grad(model, world)
+                    g_adam = GraphedTrainStep(adam_only, dev, warmup=1, check_every=0)
+
+                    def run():
+                        g_fb.replay()
+                        if world > 1:
+                            allreduce_flat_grad(model, world)
+                        g_adam.replay()
+                    dispatch = "two hipGraphs (fwd+bwd | Adam) around the gradient all-reduce"
             else:
                 graphed = GraphedTrainStep(graph_step, dev, warmup=3, check_every=0)
                 run = graphed.replay

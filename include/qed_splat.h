@@ -372,14 +372,20 @@ int qed_adam_step_dev(float* params, const float* grads, float* exp_avg, float* 
  * sched_group >= 0 the same tick launch first sets dev_lr[sched_group] to the exponential decay of
  * qed_lr_exp_decay_dev for the step about to be taken) or host (h_lr + 1-based step; dev_* NULL,
  * sched_group < 0).  Saves, for one camera per step at 500 k Gaussians, 96 MB written + 96 MB read; for
- * data-parallel steps also the rebuild pass. */
+ * data-parallel steps also the rebuild pass.
+ * `parts`: QED_ADAM_PART_SH (the tick + the two SH groups: needs the gathered views only), QED_ADAM_PART_LEADING
+ * (the other groups: needs `grads`), or both (3).  A data-parallel step issues the SH part while the all-reduce of
+ * the leading groups' gradients is still on the wire, then the leading part -- in that order (see `means`), with the
+ * same `step`; with device state only the SH part advances it. */
+#define QED_ADAM_PART_SH 1
+#define QED_ADAM_PART_LEADING 2
 int qed_adam_step_sh(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                      int32_t n_groups, const int64_t* h_group_begin, const float* h_lr, float* dev_lr,
                      float beta1, float beta2, float eps, int32_t step, float* dev_state,
                      int32_t sched_group, float sched_lr_init, float sched_lr_final,
                      int32_t sched_max_steps, int32_t N, int32_t sh_degree, const float* means,
                      int32_t n_views, const float* viewmats, int64_t viewmat_stride,
-                     const float* v_views, int64_t view_stride, float scale, void* stream);
+                     const float* v_views, int64_t view_stride, float scale, int32_t parts, void* stream);
 
 /* ExponentialDecayScheduler of one group (the reference schedules "means": 1.6e-4 -> 1.6e-6 over
  * 30000 steps, config.py:46-51) from the device step counter, for graph replay: dev_lr_slot[0] =

@@ -62,7 +62,7 @@ SIGNATURES = {
     "qed_adam_step": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _F, _F, _F, _I, _P]),
     "qed_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _F, _F, _F, _P, _P]),
     "qed_adam_step_sh": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _P, _F, _F, _F, _I, _P, _I, _F, _F, _I, _I, _I, _P, _I,
-                                   _P, _L, _P, _L, _F, _P]),
+                                   _P, _L, _P, _L, _F, _I, _P]),
 }
 
 # flags (include/qed_splat.h)

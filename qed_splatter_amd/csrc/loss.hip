@@ -739,13 +739,14 @@ extern "C" int qed_adam_step_sh(float* params, const float* grads, float* exp_av
                                 float sched_lr_init, float sched_lr_final, int32_t sched_max_steps, int32_t N,
                                 int32_t sh_degree, const float* means, int32_t n_views, const float* viewmats,
                                 int64_t viewmat_stride, const float* v_views, int64_t view_stride, float scale,
-                                void* stream) {
+                                int32_t parts, void* stream) {
     QED_REQUIRE(n_groups >= 2 && n_groups <= 8 && h_group_begin, "2..8 groups, the last two features_dc, features_rest");
     QED_REQUIRE((dev_state != nullptr) == (dev_lr != nullptr), "device state and device rates go together");
     QED_REQUIRE(dev_state || (h_lr && step >= 1), "host rates and a 1-based step, or device state");
     QED_REQUIRE(params && exp_avg && exp_avg_sq && N > 0 && means && n_views >= 1 && viewmats && v_views,
                 "bad arguments");
-    QED_REQUIRE(grads || n_groups == 2, "gradients of the leading groups required");
+    QED_REQUIRE(parts >= 1 && parts <= 3, "parts: QED_ADAM_PART_SH | QED_ADAM_PART_LEADING");
+    QED_REQUIRE(grads || n_groups == 2 || !(parts & QED_ADAM_PART_LEADING), "gradients of the leading groups required");
     QED_REQUIRE((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
                 "buffers must be 16-byte aligned");
     QED_REQUIRE(sched_group < n_groups && (sched_group < 0 || (dev_state && sched_lr_init > 0.f && sched_lr_final > 0.f &&
@@ -768,6 +769,11 @@ extern "C" int qed_adam_step_sh(float* params, const float* grads, float* exp_av
                 "sh_degree 0..3 within the stored coefficient rows");
     hipStream_t st = (hipStream_t)stream;
     AdamCoef co{beta1, beta2, eps, 1.f, 1.f};
+    if (!(parts & QED_ADAM_PART_SH)) {                 // the leading groups only: the SH part of this step has ticked
+        if (n_groups == 2) return QED_OK;
+        return adam_launch(params, grads, exp_avg, exp_avg_sq, n_groups - 2, h_group_begin, h_lr, beta1, beta2, eps,
+                           dev_state ? 1 : step, dev_state, dev_lr, stream);
+    }
     if (dev_state != nullptr) {
         const bool sched = sched_group >= 0;
         hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, st, dev_state, beta1, beta2,
@@ -799,7 +805,7 @@ extern "C" int qed_adam_step_sh(float* params, const float* grads, float* exp_av
         default: QED_LAUNCH_ASH(3); break;
     }
 #undef QED_LAUNCH_ASH
-    if (n_groups == 2) return check_launch("qed_adam_step_sh");
+    if (n_groups == 2 || !(parts & QED_ADAM_PART_LEADING)) return check_launch("qed_adam_step_sh");
     return adam_launch(params, grads, exp_avg, exp_avg_sq, n_groups - 2, h_group_begin, h_lr, beta1, beta2, eps,
                        dev_state ? 1 : step, dev_state, dev_lr, stream);
 }

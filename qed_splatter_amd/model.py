@@ -897,15 +897,20 @@ class FlatAdam:
                                        _stream()), "qed_adam_step")
 
     @torch.no_grad()
-    def step(self, device_state: bool = False, fused_sh: bool = False) -> None:
+    def step(self, device_state: bool = False, fused_sh: bool = False, part: int = 3) -> None:
         """One Adam step.  ``device_state=True`` keeps the step counter / bias corrections in device
         memory (qed_adam_step_dev), which is what makes the step replayable from a hipGraph.
 
         ``fused_sh=True`` (after ``fused_loss(..., compact_sh_grad=True)`` + backward): the 48 N SH-coefficient
         gradients are never written or read -- qed_adam_step_sh evaluates b_k(dir) x colour gradient while it
         updates features_dc / features_rest (one view: this rank's; data parallel: the views gathered by
-        ``parallel.exchange_grads_compact(..., rebuild=False)``).  Same update as the plain step."""
+        ``parallel.exchange_grads_compact(..., rebuild=False)``).  Same update as the plain step.
+
+        ``part`` (fused_sh only): 1 = the step counter / schedule + the two SH groups (needs the gathered views, not the
+        reduced geometry gradients), 2 = the leading groups, 3 = both.  A data-parallel step calls 1 then 2 around the
+        wait for the geometry all-reduce (``parallel.exchange_grads_compact_begin``)."""
         import ctypes as C
+        assert part in (1, 2, 3) and (fused_sh or part == 3)
         p = self.model.flat_params
         g = self.model.flat_grad()
         if g is None:
@@ -913,7 +918,7 @@ class FlatAdam:
         self._check("step", compact_ok=fused_sh)
         lib = L.load()
         sched = (-1, 0.0, 0.0, 0)
-        if self.means_schedule is not None:                      # the rate of the step about to be taken
+        if self.means_schedule is not None and (part & 1):      # the rate of the step about to be taken
             lr_final, max_steps = self.means_schedule
             i = self.model.group_names.index("means")
             if device_state and fused_sh:                        # evaluated by qed_adam_step_sh's own tick launch
@@ -924,7 +929,8 @@ class FlatAdam:
             else:
                 self.lr[i] = exponential_decay_lr(self.t, self._means_lr_init, lr_final, max_steps)
                 self._lr[i] = self.lr[i]
-        self.t += 1
+        if part & 1:
+            self.t += 1
         if fused_sh:
             m = self.model
             if not getattr(m, "last_compact", False):
@@ -941,7 +947,7 @@ class FlatAdam:
                 L.ptr(self.dev_lr) if device_state else None, self.betas[0], self.betas[1], self.eps, self.t,
                 L.ptr(self.dev_state) if device_state else None, *sched, m.num_points, int(m.last_sh_degree or 0),
                 L.ptr(m.means), n_views, L.ptr(viewmats), vm_stride, L.ptr(v_views), view_stride, float(scale),
-                _stream()), "qed_adam_step_sh")
+                int(part), _stream()), "qed_adam_step_sh")
             return
         if device_state:
             L.check(lib.qed_adam_step_dev(L.ptr(p), L.ptr(g), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),

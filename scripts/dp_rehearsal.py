@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Two-rank rehearsal of the data-parallel step on ONE GPU (gloo, both ranks on cuda:0):
 allreduce_and_step (chunked, pipelined) and exchange_grads_compact (geometry all-reduce + gathered colour
-gradients, rebuilt either before the optimiser or inside it) must leave the same parameters as
+gradients, rebuilt either before the optimiser or inside it, or with both collectives left in flight and the optimiser
+run in two parts behind them) must leave the same parameters as
 allreduce_flat_grad + step.
 
     QED_BENCH_REHEARSE=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \\
@@ -16,7 +17,8 @@ import torch.distributed as dist  # noqa: E402
 
 from qed_splatter_amd import _lib as L  # noqa: E402
 from qed_splatter_amd.model import FlatAdam, PinholeCameras, QEDSplatterModel, QEDSplatterModelConfig  # noqa: E402
-from qed_splatter_amd.parallel import allreduce_and_step, allreduce_flat_grad, exchange_grads_compact  # noqa: E402
+from qed_splatter_amd.parallel import (allreduce_and_step, allreduce_flat_grad, exchange_grads_compact,  # noqa: E402
+                                       exchange_grads_compact_begin)
 from qed_splatter_amd.scene import synthetic_scene  # noqa: E402
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -30,7 +32,7 @@ names = ("means", "scales", "quats", "opacities", "features_dc", "features_rest"
 K = sc["Ks"][0]
 cam = PinholeCameras(sc["camera_to_worlds"][rank:rank + 1].to(dev), float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), w, h)
 batch = {"image": sc["gt_rgb"].to(dev), "depth_image": sc["gt_depth"].to(dev)}
-models = [QEDSplatterModel(QEDSplatterModelConfig.synthetic(sh_degree_interval=1), **{k: sc[k].to(dev) for k in names}) for _ in range(4)]
+models = [QEDSplatterModel(QEDSplatterModelConfig.synthetic(sh_degree_interval=1), **{k: sc[k].to(dev) for k in names}) for _ in range(5)]
 opts = [FlatAdam(m, means_schedule=FlatAdam.MEANS_SCHEDULE) for m in models]
 for m in models:
     m.step = 30000
@@ -47,9 +49,15 @@ for step in range(4):
         elif i == 2:
             exchange_grads_compact(m, world)
             o.step()
-        else:                                   # gathered views feed the optimiser directly (qed_adam_step_sh)
+        elif i == 3:                            # gathered views feed the optimiser directly (qed_adam_step_sh)
             exchange_grads_compact(m, world, rebuild=False)
             o.step(fused_sh=True)
+        else:                                   # both collectives in flight, optimiser in two parts behind them
+            ex = exchange_grads_compact_begin(m, world)
+            ex.wait_views()
+            o.step(fused_sh=True, part=1)
+            ex.wait_geometry()
+            o.step(fused_sh=True, part=2)
 torch.cuda.synchronize()
 # the two models see gradients that differ in the last bits (atomic summation order in the compositing
 # backward), so "same" is up to that noise amplified by four Adam steps
@@ -64,6 +72,13 @@ dist.all_gather(gathered3, models[3].flat_params.detach())
 replicas = replicas and all(torch.equal(gathered3[0], t) for t in gathered3)
 print(f"rank {rank}: chunked == plain: {same}; compact exchange == plain: {same2}; views -> optimiser == plain: {same3}; "
       f"replicas identical: {replicas}", flush=True)
-same = same and same2 and same3
+same4 = bool(((models[0].flat_params - models[4].flat_params).abs() <= 1e-5 + 1e-4 * models[0].flat_params.abs()).all())
+gathered4 = [torch.empty_like(models[4].flat_params) for _ in range(world)]
+dist.all_gather(gathered4, models[4].flat_params.detach())
+replicas4 = all(torch.equal(gathered4[0], t) for t in gathered4)
+print(f"rank {rank}: overlapped exchange (gather | SH part | all-reduce | leading part) == plain: {same4}; "
+      f"replicas identical: {replicas4}", flush=True)
+same = same and same2 and same3 and same4
+replicas = replicas and replicas4
 dist.destroy_process_group()
 sys.exit(0 if same and replicas else 1)

@@ -861,6 +861,50 @@ def test_adam_with_sh_gradients_from_several_views_equals_rebuild_then_step(cuda
         assert_close(x1[:b[4]], x0[:b[4]], 1e-5, f"geometry groups: {name}")
 
 
+@pytest.mark.parametrize("device_state", [False, True])
+def test_adam_sh_part_then_leading_part_equals_one_step(cuda, device_state):
+    """The data-parallel order -- exchange_grads_compact_begin, SH part of the step behind the gather, leading groups
+    behind the all-reduce -- is bit for bit the one-call step (same kernels, same inputs), schedule and step counter
+    included, over several steps."""
+    from qed_splatter_amd.model import FlatAdam, PinholeCameras
+    from qed_splatter_amd.parallel import exchange_grads_compact, exchange_grads_compact_begin
+    w, h, n = 96, 64, 1003
+    sc = scene(n, w, h, seed=29)
+    K = sc["Ks"][0]
+    cam = PinholeCameras(sc["camera_to_worlds"][:1].to(cuda), K[0, 0], K[1, 1], K[0, 2], K[1, 2], w, h)
+    runs = []
+    for parts in (False, True):
+        m, _, batch = _model(sc, cuda)
+        opt = FlatAdam(m, means_schedule=(1.6e-6, 50))
+        g_fixed = None
+        for it in range(3):
+            for p in m.parameters():
+                p.grad = None
+            m.backward_fused(m.fused_loss(cam, batch, compact_sh_grad=True))
+            # identical gradients in both runs (the backward's atomics are not order-deterministic)
+            if parts:
+                m.flat_grad().copy_(runs[0][2][it])
+            else:
+                g_fixed = (g_fixed or []) + [m.flat_grad().clone()]
+            if parts:
+                ex = exchange_grads_compact_begin(m, 1)
+                ex.wait_views()
+                opt.step(device_state=device_state, fused_sh=True, part=1)
+                ex.wait_geometry()
+                opt.step(device_state=device_state, fused_sh=True, part=2)
+            else:
+                exchange_grads_compact(m, 1, rebuild=False)
+                opt.step(device_state=device_state, fused_sh=True)
+        torch.cuda.synchronize()
+        runs.append((m, opt, g_fixed))
+    (m0, o0, _), (m1, o1, _) = runs
+    assert o0.t == o1.t == 3
+    assert torch.equal(m1.flat_params, m0.flat_params)
+    assert torch.equal(o1.exp_avg, o0.exp_avg) and torch.equal(o1.exp_avg_sq, o0.exp_avg_sq)
+    if device_state:
+        assert torch.equal(o1.dev_state, o0.dev_state) and torch.equal(o1.dev_lr, o0.dev_lr)
+
+
 def test_adam_step_in_ranges_equals_one_step(cuda):
     """FlatAdam.begin_step + step_range pieces (what parallel.allreduce_and_step interleaves with the chunked
     all-reduce) == FlatAdam.step, schedule included."""
