@@ -244,7 +244,10 @@ ssim_fwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
 // v_pred[H,W,3] = scale * (scale_dev ? scale_dev[0] : 1) * d(sum of the SSIM map)/d pred, pred = the colour BEFORE the
 // mask multiply (MASKED: x = m pred, y = m gt entered the SSIM, so the chain rule adds one factor m)
 template <bool COMPOSITE, bool MASKED, class T>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+#ifndef QED_SSIM_BWD_WAVES
+#define QED_SSIM_BWD_WAVES 4
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QED_SSIM_BWD_WAVES, QED_SSIM_BWD_WAVES)))
 ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, const float* __restrict__ alpha,
                 const float* __restrict__ bg, const float* __restrict__ gt, const float* __restrict__ mask,
                 const float* __restrict__ maps, float scale, const float* __restrict__ scale_dev,
@@ -346,7 +349,16 @@ ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
     }
 }
 
-using Tile = SsimTile<32, 32>;
+#ifndef QED_SSIM_FWD_TW
+#define QED_SSIM_FWD_TW 32
+#define QED_SSIM_FWD_TH 32
+#endif
+#ifndef QED_SSIM_BWD_TW
+#define QED_SSIM_BWD_TW 32
+#define QED_SSIM_BWD_TH 32
+#endif
+using Tile = SsimTile<QED_SSIM_FWD_TW, QED_SSIM_FWD_TH>;
+using TileB = SsimTile<QED_SSIM_BWD_TW, QED_SSIM_BWD_TH>;
 
 }  // namespace qed
 
@@ -387,9 +399,9 @@ extern "C" int qed_ssim_bwd(int32_t height, int32_t width, int32_t channels, con
     QED_REQUIRE(pred && gt_rgb && maps && v_pred, "null buffers");
     QED_REQUIRE(alpha == nullptr || (background && (channels == 3 || channels == 4)), "composite mode needs a background");
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(((width + Tile::TW - 1) / Tile::TW) * ((height + Tile::TH - 1) / Tile::TH));
+    const dim3 grid(((width + TileB::TW - 1) / TileB::TW) * ((height + TileB::TH - 1) / TileB::TH));
 #define QED_SSIM_BWD(COMP, MASK, CHN)                                                                               \
-    hipLaunchKernelGGL((ssim_bwd_kernel<COMP, MASK, Tile>), grid, dim3(256), 0, st, height, width, CHN, pred, alpha,   \
+    hipLaunchKernelGGL((ssim_bwd_kernel<COMP, MASK, TileB>), grid, dim3(256), 0, st, height, width, CHN, pred, alpha,   \
                        background, gt_rgb, mask, maps, scale, scale_dev, v_pred)
     if (alpha != nullptr) { if (mask) QED_SSIM_BWD(true, true, channels); else QED_SSIM_BWD(true, false, channels); }
     else { if (mask) QED_SSIM_BWD(false, true, 3); else QED_SSIM_BWD(false, false, 3); }
