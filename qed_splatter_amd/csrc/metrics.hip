@@ -35,29 +35,51 @@ metrics_kernel(int n_pix, const float* __restrict__ pred_rgb, const float* __res
     float acc[kMetricCols];
 #pragma unroll
     for (int i = 0; i < kMetricCols; ++i) acc[i] = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n_pix; i += (size_t)gridDim.x * 256) {
-        if (pred_rgb != nullptr) {
+    // kU pixels per trip, every load of the trip issued before the first use (clamped index, contribution switched off
+    // by `in`): one memory round trip per kU pixels instead of one per pixel -- with at most 1024 workgroups a thread
+    // walks ~8 pixels at 1080p and the pass was bound by those serial round trips (25 us for 66 MB)
+    constexpr int kU = 4;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x; i0 < (size_t)n_pix; i0 += kU * stride) {
+        float pr[kU][3], gr[kU][3], pd[kU], gd[kU];
+        bool in[kU];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float d = pred_rgb[3 * i + k] - gt_rgb[3 * i + k];
-                acc[0] += d * d;
+        for (int u = 0; u < kU; ++u) {
+            const size_t iu = i0 + u * stride;
+            in[u] = iu < (size_t)n_pix;
+            const size_t i = in[u] ? iu : i0;
+            if (pred_rgb != nullptr) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { pr[u][k] = pred_rgb[3 * i + k]; gr[u][k] = gt_rgb[3 * i + k]; }
             }
+            if (pred_depth != nullptr) { pd[u] = pred_depth[i]; gd[u] = gt_depth[i]; }
         }
-        if (pred_depth != nullptr) {
-            const float p = pred_depth[i], g = gt_depth[i];
-            if (isfinite(p) && isfinite(g) && g > tolerance) {
-                const float d = g - p;
-                acc[1] += 1.f;
-                acc[2] += fabsf(d) / g;
-                acc[3] += d * d / g;
-                acc[4] += d * d;
-                const float l = logf(g) - logf(p);          // NaN for p < 0, +-inf for p == 0 (kept, like nanmean)
-                const float l2 = l * l;
-                if (!isnan(l2)) { acc[5] += l2; acc[6] += 1.f; }
-                const float t = fmaxf(g / p, p / g);
-                acc[7] += t < 1.25f ? 1.f : 0.f;
-                acc[8] += t < 1.25f * 1.25f ? 1.f : 0.f;
-                acc[9] += t < 1.25f * 1.25f * 1.25f ? 1.f : 0.f;
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            if (!in[u]) continue;
+            if (pred_rgb != nullptr) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float d = pr[u][k] - gr[u][k];
+                    acc[0] += d * d;
+                }
+            }
+            if (pred_depth != nullptr) {
+                const float p = pd[u], g = gd[u];
+                if (isfinite(p) && isfinite(g) && g > tolerance) {
+                    const float d = g - p;
+                    acc[1] += 1.f;
+                    acc[2] += fabsf(d) / g;
+                    acc[3] += d * d / g;
+                    acc[4] += d * d;
+                    const float l = logf(g) - logf(p);          // NaN for p < 0, +-inf for p == 0 (kept, like nanmean)
+                    const float l2 = l * l;
+                    if (!isnan(l2)) { acc[5] += l2; acc[6] += 1.f; }
+                    const float t = fmaxf(g / p, p / g);
+                    acc[7] += t < 1.25f ? 1.f : 0.f;
+                    acc[8] += t < 1.25f * 1.25f ? 1.f : 0.f;
+                    acc[9] += t < 1.25f * 1.25f * 1.25f ? 1.f : 0.f;
+                }
             }
         }
     }
@@ -76,12 +98,20 @@ metrics_finalize_kernel(int n_pix, int n_blocks, int has_rgb, int has_depth, con
                         float* __restrict__ out) {
     __shared__ double s_w[kMetricCols][4];
     __shared__ double s[kMetricCols];
-    for (int c = 0; c < kMetricCols; ++c) {
-        double v = 0.0;
-        for (int b = threadIdx.x; b < n_blocks; b += 256) v += partials[(size_t)c * kMetricMaxGrid + b];
+    double v[kMetricCols];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if ((threadIdx.x & 63) == 0) s_w[c][threadIdx.x >> 6] = v;
+    for (int c = 0; c < kMetricCols; ++c) v[c] = 0.0;
+    // (all ten columns of a row of partials are requested together: ten dependent load / reduce rounds made this
+    // one-workgroup launch 15 us)
+    for (int b = threadIdx.x; b < n_blocks; b += 256) {
+#pragma unroll
+        for (int c = 0; c < kMetricCols; ++c) v[c] += partials[(size_t)c * kMetricMaxGrid + b];
+    }
+#pragma unroll
+    for (int c = 0; c < kMetricCols; ++c) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[c] += __shfl_xor(v[c], o, 64);
+        if ((threadIdx.x & 63) == 0) s_w[c][threadIdx.x >> 6] = v[c];
     }
     __syncthreads();
     if (threadIdx.x < kMetricCols) s[threadIdx.x] = s_w[threadIdx.x][0] + s_w[threadIdx.x][1] + s_w[threadIdx.x][2] + s_w[threadIdx.x][3];

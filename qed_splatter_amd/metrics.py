@@ -52,19 +52,30 @@ def image_metrics(pred_rgb: Optional[Tensor], gt_rgb: Optional[Tensor], pred_dep
     return out
 
 
-def ssim_value(pred_rgb: Tensor, gt_rgb: Tensor) -> Tensor:
+def ssim_value(pred_rgb: Tensor, gt_rgb: Tensor, keep_maps: bool = False):
     """StructuralSimilarityIndexMeasure(data_range=1, kernel_size=11) of two [H,W,3] images: torchmetrics
     reflect-pads by 5 and crops the same 5 pixels again, i.e. the mean of the unpadded valid-window SSIM
-    map, which is what ssim.hip computes."""
+    map, which is what ssim.hip computes.
+
+    ``keep_maps``: also return what a loss on the same two images needs from this forward pass -- {"key": identity of
+    the inputs, "maps_sum": (coefficient maps of the backward pass, per-workgroup map sums), "inputs": the two tensors,
+    held so that their addresses stay theirs} -- as a second value."""
     lib = L.load()
     H, W, _ = pred_rgb.shape
     p, g = pred_rgb.to(torch.float32).contiguous(), gt_rgb.to(torch.float32).contiguous()
-    if lib.qed_ssim_maps_floats(H, W) < 0:
+    n_maps = lib.qed_ssim_maps_floats(H, W)
+    if n_maps < 0:
         raise L.QedSplatError("image smaller than the 11 x 11 SSIM window")
     ssum = torch.empty(lib.qed_ssim_sum_floats(H, W), dtype=torch.float32, device=p.device)
     # maps = NULL: the value only (no 75 MB of backward coefficient maps at 1080p)
-    L.check(lib.qed_ssim_fwd(H, W, 3, L.ptr(p), None, None, L.ptr(g), None, None, L.ptr(ssum), _stream()), "qed_ssim_fwd")
-    return ssum.sum() / (3.0 * (H - 10) * (W - 10))
+    maps = torch.empty(n_maps, dtype=torch.float32, device=p.device) if keep_maps else None
+    L.check(lib.qed_ssim_fwd(H, W, 3, L.ptr(p), None, None, L.ptr(g), None, L.ptr(maps), L.ptr(ssum), _stream()),
+            "qed_ssim_fwd")
+    value = ssum.sum() / (3.0 * (H - 10) * (W - 10))
+    if not keep_maps:
+        return value
+    key = (p.data_ptr(), p._version, tuple(p.shape), g.data_ptr(), g._version, tuple(g.shape))
+    return value, {"key": key, "maps_sum": (maps, ssum), "inputs": (p, g)}
 
 
 @torch.no_grad()
@@ -117,11 +128,15 @@ class DepthMetrics(torch.nn.Module):
 
 @torch.no_grad()
 def metrics_dict(pred_rgb: Tensor, gt_rgb: Tensor, pred_depth: Optional[Tensor], gt_depth: Optional[Tensor],
-                 tolerance: float = 0.1) -> Dict[str, Tensor]:
-    """The image part of get_metrics_dict (model.py:152-182) in two launches, values left on the device."""
+                 tolerance: float = 0.1, keep_ssim_maps: bool = False) -> Dict[str, Tensor]:
+    """The image part of get_metrics_dict (model.py:152-182) in two launches, values left on the device.
+    ``keep_ssim_maps``: the entry "_ssim_shared" carries the SSIM forward for a loss on the same images (ssim_value)."""
     m = image_metrics(pred_rgb, gt_rgb, pred_depth, gt_depth, tolerance)
-    out = {"rgb_mse": m[0], "rgb_psnr": m[1], "rgb_ssim": ssim_value(pred_rgb, gt_rgb),
+    ssim = ssim_value(pred_rgb, gt_rgb, keep_maps=keep_ssim_maps)
+    out = {"rgb_mse": m[0], "rgb_psnr": m[1], "rgb_ssim": ssim[0] if keep_ssim_maps else ssim,
            "rgb_lpips": torch.full((), float("nan"), device=m.device)}
+    if keep_ssim_maps:
+        out["_ssim_shared"] = ssim[1]
     if pred_depth is not None:
         out.update({n: m[i] for i, n in enumerate(METRIC_NAMES) if n.startswith("depth_") and n != "depth_n_valid"})
     return out

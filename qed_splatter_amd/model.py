@@ -202,6 +202,11 @@ def _f32_image(t: Tensor, numel: int, what: str, dev) -> Tensor:
     return t
 
 
+def _ssim_key(pred: Tensor, gt: Tensor):
+    """What identifies the inputs of an SSIM forward: address, version and shape of both images."""
+    return (pred.data_ptr(), pred._version, tuple(pred.shape), gt.data_ptr(), gt._version, tuple(gt.shape))
+
+
 class _PostProcess(torch.autograd.Function):
     """model.py:295-297 + 304-306 as ONE node: rgb = clamp(render[..., :3] + (1 - alpha) background, 0, 1) and
     depth = where(alpha > 0, render[..., 3:4], render[..., 3:4].detach().max())."""
@@ -249,7 +254,7 @@ class _ImageLosses(torch.autograd.Function):
     multiplies each term's gradient by its upstream gradient, read from device memory."""
 
     @staticmethod
-    def forward(ctx, rgb, depth, gt_rgb, gt_depth, mask, ssim_lambda, depth_lambda):
+    def forward(ctx, rgb, depth, gt_rgb, gt_depth, mask, ssim_lambda, depth_lambda, ssim_shared=None):
         lib = L.load()
         ctx.set_materialize_grads(False)
         if not rgb.is_cuda:
@@ -269,10 +274,15 @@ class _ImageLosses(torch.autograd.Function):
             n_maps = lib.qed_ssim_maps_floats(H, W)
             if n_maps < 0:
                 raise L.QedSplatError("image smaller than the 11 x 11 SSIM window")
-            maps = torch.empty(n_maps, dtype=torch.float32, device=dev)
-            ssum = torch.empty(lib.qed_ssim_sum_floats(H, W), dtype=torch.float32, device=dev)
-            L.check(lib.qed_ssim_fwd(H, W, 3, L.ptr(rgb), None, None, L.ptr(gt_rgb), L.ptr(mask), L.ptr(maps),
-                                     L.ptr(ssum), st), "qed_ssim_fwd")
+            if ssim_shared is not None:
+                # get_metrics_dict ran qed_ssim_fwd on these very images a moment ago (rgb_ssim, model.py:157-166) and
+                # kept the coefficient maps: the loss needs the same map sum and the same maps
+                maps, ssum = ssim_shared
+            else:
+                maps = torch.empty(n_maps, dtype=torch.float32, device=dev)
+                ssum = torch.empty(lib.qed_ssim_sum_floats(H, W), dtype=torch.float32, device=dev)
+                L.check(lib.qed_ssim_fwd(H, W, 3, L.ptr(rgb), None, None, L.ptr(gt_rgb), L.ptr(mask), L.ptr(maps),
+                                         L.ptr(ssum), st), "qed_ssim_fwd")
             extra = (L.ptr(ssum), ssum.numel(), -ssim_lambda / n_out, ssim_lambda)
         L.check(lib.qed_image_losses_fwd(n_pix, L.ptr(rgb), L.ptr(depth), L.ptr(gt_rgb), L.ptr(gt_depth), L.ptr(mask),
                                          1.0 - ssim_lambda, depth_lambda, *extra, L.ptr(sums), L.ptr(losses), st),
@@ -304,7 +314,7 @@ class _ImageLosses(torch.autograd.Function):
         L.check(lib.qed_image_losses_bwd(H * W, L.ptr(rgb), L.ptr(depth), L.ptr(gt_rgb), L.ptr(gt_depth), L.ptr(mask),
                                          L.ptr(sums), 1.0 - ssim_lambda, depth_lambda, L.ptr(g_main), L.ptr(g_depth), acc,
                                          L.ptr(v_rgb), L.ptr(v_depth), st), "qed_image_losses_bwd")
-        return v_rgb, v_depth, None, None, None, None, None
+        return v_rgb, v_depth, None, None, None, None, None, None
 
 
 class _FusedImageLoss(torch.autograd.Function):
@@ -498,9 +508,16 @@ class QEDSplatterModel(nn.Module):
     def get_gt_img(self, image: Tensor) -> Tensor:
         """uint8 -> float / 255, downscaled by the current factor, on the model's device (the parent's get_gt_img,
         called at model.py:88,91,94)."""
-        if image.dtype == torch.uint8:
-            image = image.float() / 255.0
-        return self._downscale_if_required(image).to(self.device)
+        # get_metrics_dict and get_loss_dict prepare the SAME batch image within one step: the last conversion is kept
+        # (together with its source object, so that the address cannot be recycled under the key) and handed out again
+        d = self._get_downscale_factor()
+        memo = getattr(self, "_gt_memo", None)
+        if memo is not None and memo[0] is image and memo[1] == (image._version, d):
+            return memo[2]
+        out = image.float() / 255.0 if image.dtype == torch.uint8 else image
+        out = self._downscale_if_required(out).to(self.device)
+        self._gt_memo = (image, (image._version, d), out) if out is not image else None
+        return out
 
     def composite_with_background(self, image: Tensor, background: Tensor) -> Tensor:
         """RGBA ground truth composited onto the step's background (the parent does this to the GT image)."""
@@ -692,8 +709,14 @@ class QEDSplatterModel(nn.Module):
         mask = self._loss_mask(batch, pred_img.shape)
         gt_img = _f32_image(gt_img[..., :3] if gt_img.shape[-1] > 3 else gt_img, H * W * 3, "batch['image']", self.device)
         depth_batch = _f32_image(self.get_gt_img(batch["depth_image"]), H * W, "batch['depth_image']", self.device)
+        # the SSIM forward get_metrics_dict ran on the same two images (same storage, same version; the cache holds the
+        # tensors, so neither address can have been recycled), no mask: not computed a second time
+        shared, self._ssim_shared = getattr(self, "_ssim_shared", None), None
+        if shared is not None and (mask is not None or cfg.ssim_lambda <= 0.0 or
+                                   shared["key"] != _ssim_key(pred_img.contiguous(), gt_img)):
+            shared = None
         main, depth = _ImageLosses.apply(pred_img, depth_out, gt_img, depth_batch, mask, float(cfg.ssim_lambda),
-                                         float(cfg.depth_lambda))
+                                         float(cfg.depth_lambda), shared["maps_sum"] if shared else None)
         return {"main_loss": main, "scale_reg": self._scale_reg(), "depth_loss": depth}
 
     # ---- get_metrics_dict (model.py:120-197) ----
@@ -716,8 +739,15 @@ class QEDSplatterModel(nn.Module):
         pred_rgb = outputs["rgb"][0] if outputs["rgb"].dim() == 4 else outputs["rgb"]
         has_depth = "depth_image" in batch and outputs.get("depth") is not None
         gt_depth = resize(batch["depth_image"]).to(self.device) if has_depth else None
+        # In training the loss that follows needs the SSIM of the same two images WITH the coefficient maps of its
+        # backward pass: compute that form once here and leave it for get_loss_dict (which checks that it is handed the
+        # same tensors before using it)
+        keep = (self.training and torch.is_grad_enabled() and self.config.ssim_lambda > 0.0 and d <= 1
+                and pred_rgb.is_cuda and pred_rgb.dtype == torch.float32)
         with torch.no_grad():
-            out = dict(_image_metrics(pred_rgb.detach(), gt_rgb, outputs["depth"].detach() if has_depth else None, gt_depth))
+            out = dict(_image_metrics(pred_rgb.detach(), gt_rgb, outputs["depth"].detach() if has_depth else None, gt_depth,
+                                      keep_ssim_maps=keep))
+            self._ssim_shared = out.pop("_ssim_shared", None)
             out["gaussian_count"] = self.num_points
             out["avg_min_scale"] = nanmean_exp(self.scales[..., -1])                  # model.py:192-194
         return out

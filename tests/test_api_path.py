@@ -400,3 +400,63 @@ def test_flat_adam_refuses_stale_buffers_and_compact_gradients(cuda):
     m.backward_fused(m.fused_loss(cam, batch))
     with pytest.raises(RuntimeError, match="new flat parameter buffer"):
         opt.step()
+
+
+@pytest.mark.parametrize("uint8_image", [False, True])
+def test_ssim_forward_shared_between_metrics_and_loss(cuda, uint8_image):
+    """get_metrics_dict computes rgb_ssim of (rgb, gt) and get_loss_dict needs the SSIM of the same two images: in training
+    the second forward pass is not run (one qed_ssim_fwd per step instead of two), with identical loss values and rgb
+    gradients; a mask, another image, eval mode or an in-place change of the render all fall back to the full computation."""
+    from qed_splatter_amd import _lib as L
+    w, h, n = 160, 112, 3000
+    sc = scene(n, w, h, seed=9)
+
+    def run(with_metrics, tweak=None):
+        m, cam, batch = _model(sc, cuda)
+        m.train()
+        if uint8_image:
+            batch["image"] = (batch["image"] * 255).round().to(torch.uint8)
+        out = m.get_outputs(cam)
+        out["rgb"].retain_grad()
+        L.TIMER.reset()
+        L.TIMER.active = True
+        try:
+            md = m.get_metrics_dict(out, batch) if with_metrics else None
+            if tweak is not None:
+                tweak(m, out, batch)
+            ld = m.get_loss_dict(out, batch, md)
+            torch.cuda.synchronize()
+        finally:
+            L.TIMER.active = False
+        n_fwd = len(L.TIMER.events.get("qed_ssim_fwd", []))
+        sum(ld.values()).backward()
+        assert getattr(m, "_ssim_shared", None) is None              # consumed (or never made)
+        return md, ld, out["rgb"].grad.clone(), n_fwd
+
+    _, ld0, g0, n0 = run(False)
+    md1, ld1, g1, n1 = run(True)
+    assert n0 == 1 and n1 == 1, (n0, n1)                              # metrics + loss: still ONE SSIM forward
+    assert torch.equal(ld1["main_loss"], ld0["main_loss"]) and torch.equal(ld1["depth_loss"], ld0["depth_loss"])
+    assert torch.equal(g1, g0)
+    # rgb_ssim is the value the loss used: main = 0.8 L1 + 0.2 (1 - ssim)
+    assert 0.0 < float(md1["rgb_ssim"]) < 1.0
+
+    def add_mask(m, out, batch):
+        batch["mask"] = torch.ones(h, w, 1, device=cuda)
+    assert run(True, add_mask)[3] == 2                                # masked loss: SSIM of other images
+
+    def touch(m, out, batch):
+        with torch.no_grad():
+            out["rgb"].mul_(1.0)                                      # same values, new version: not trusted
+    assert run(True, touch)[3] == 2
+
+    def other_image(m, out, batch):
+        batch["image"] = batch["image"].clone()
+    assert run(True, other_image)[3] == 2
+
+    m, cam, batch = _model(sc, cuda)
+    m.eval()
+    with torch.no_grad():
+        out = m.get_outputs(cam)
+        m.get_metrics_dict(out, batch)
+    assert getattr(m, "_ssim_shared", None) is None                   # nothing kept outside training
