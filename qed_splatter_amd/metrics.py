@@ -52,6 +52,17 @@ def image_metrics(pred_rgb: Optional[Tensor], gt_rgb: Optional[Tensor], pred_dep
     return out
 
 
+_NANS: Dict[torch.device, Tensor] = {}
+
+
+def _nan(device) -> Tensor:
+    """LPIPS needs pretrained weights that are not here: one cached NaN scalar per device instead of a fill per step."""
+    t = _NANS.get(device)
+    if t is None:
+        t = _NANS[device] = torch.full((), float("nan"), device=device)
+    return t
+
+
 def ssim_value(pred_rgb: Tensor, gt_rgb: Tensor, keep_maps: bool = False):
     """StructuralSimilarityIndexMeasure(data_range=1, kernel_size=11) of two [H,W,3] images: torchmetrics
     reflect-pads by 5 and crops the same 5 pixels again, i.e. the mean of the unpadded valid-window SSIM
@@ -108,7 +119,7 @@ class RGBMetrics(torch.nn.Module):
     def forward(self, pred: Tensor, gt: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
         p, g = _to_hwc(pred), _to_hwc(gt)
         m = image_metrics(p, g)
-        return m[1], ssim_value(p, g), torch.full((), float("nan"), device=p.device)
+        return m[1], ssim_value(p, g), _nan(p.device)
 
 
 class DepthMetrics(torch.nn.Module):
@@ -134,7 +145,7 @@ def metrics_dict(pred_rgb: Tensor, gt_rgb: Tensor, pred_depth: Optional[Tensor],
     m = image_metrics(pred_rgb, gt_rgb, pred_depth, gt_depth, tolerance)
     ssim = ssim_value(pred_rgb, gt_rgb, keep_maps=keep_ssim_maps)
     out = {"rgb_mse": m[0], "rgb_psnr": m[1], "rgb_ssim": ssim[0] if keep_ssim_maps else ssim,
-           "rgb_lpips": torch.full((), float("nan"), device=m.device)}
+           "rgb_lpips": _nan(m.device)}
     if keep_ssim_maps:
         out["_ssim_shared"] = ssim[1]
     if pred_depth is not None:

@@ -496,14 +496,21 @@ class QEDSplatterModel(nn.Module):
 
     def _get_background_color(self) -> Tensor:
         dev = self.device
+        if self.config.background_color == "random" and self.training:
+            return torch.rand(3, device=dev)
+        # the fixed colours are made once per device (a fill launch per step otherwise); nothing writes into them
         if self.config.background_color == "random":
-            if self.training:
-                return torch.rand(3, device=dev)
             # the parent's eval colour under "random" (populate_modules: self.background_color)
-            return torch.tensor([0.1490, 0.1647, 0.2157], device=dev)
-        if self.config.background_color == "white":
-            return torch.ones(3, device=dev)
-        return torch.zeros(3, device=dev)
+            key, rgb = "eval", [0.1490, 0.1647, 0.2157]
+        elif self.config.background_color == "white":
+            key, rgb = "white", [1.0, 1.0, 1.0]
+        else:
+            key, rgb = "black", [0.0, 0.0, 0.0]
+        cache = self.__dict__.setdefault("_bg_consts", {})
+        c = cache.get((key, dev))
+        if c is None:
+            c = cache[(key, dev)] = torch.tensor(rgb, dtype=torch.float32, device=dev)
+        return c
 
     def get_gt_img(self, image: Tensor) -> Tensor:
         """uint8 -> float / 255, downscaled by the current factor, on the model's device (the parent's get_gt_img,

@@ -59,7 +59,10 @@ class _Workspace:
     def __init__(self, device):
         self.device = device
         self.capacity = 0
-        self.status = torch.zeros(L.STATUS_WORDS, dtype=torch.int32, device=device)
+        # [M of the last binning call | status words]: adjacent, so that an asynchronous call reads them back in ONE copy
+        self.words = torch.zeros(1 + L.STATUS_WORDS, dtype=torch.int32, device=device)
+        self.n_isect = self.words[:1]
+        self.status = self.words[1:]
         self.pending = None          # (pinned host copy of [M, overflow], event) of an async call
 
     def poll_pending(self):
@@ -247,7 +250,7 @@ def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, til
     dev = means2d.device
     ws = _workspace(dev)
     n_tiles = tile_w * tile_h
-    n_isect = torch.empty(1, dtype=torch.int32, device=dev)
+    n_isect = ws.n_isect               # (read by the kernels of this call only; launches are stream-ordered)
     offsets = torch.empty(C * n_tiles + 1, dtype=torch.int32, device=dev)
     capturing = torch.cuda.is_current_stream_capturing()
     if capturing:
@@ -275,14 +278,13 @@ def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, til
             return None, flatten_ids, offsets, None
         if not sync:
             host = torch.empty(3, dtype=torch.int32, pin_memory=True)
-            host[0:1].copy_(n_isect, non_blocking=True)
-            host[1:3].copy_(ws.status[:2], non_blocking=True)
+            host.copy_(ws.words[:3], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
             ws.pending = (host, ev)
             return None, flatten_ids, offsets, None
         # one host read: M, the overflow word and the look-back watchdog word
-        host = torch.cat([n_isect, ws.status[:2]]).tolist()
+        host = ws.words[:3].tolist()
         M, overflow = int(host[0]), int(host[1])
         if host[2]:
             ws.status.zero_()
