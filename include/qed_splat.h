@@ -251,6 +251,19 @@ int qed_ssim_bwd(int32_t height, int32_t width, int32_t channels, const float* p
                  const float* background, const float* gt_rgb, const float* mask, const float* maps,
                  float scale, const float* scale_dev, float* v_pred, void* stream);
 
+/* qed_ssim_bwd and qed_loss_grad in ONE launch (the fused training step), after qed_ssim_fwd and qed_loss_reduce on
+ * the same buffers: every thread of the SSIM backward pass finishes its pixels on the spot -- SSIM gradient (scale
+ * ssim_scale = -ssim_lambda / (3 (H-10)(W-10))) + L1 gradient through the clamp and the background composite
+ * (model.py:296-297) -> v_render[H,W,channels] / v_alpha[H,W], depth-L1 gradient (model.py:87-116, :304-306) into channel
+ * 3 -- instead of handing v_pred to a second pass that re-reads render, alpha and the ground truth (116 MB at 1080p).
+ * losses[0..2] as qed_loss_grad with extra_sum = ssim_sum, extra_scale = ssim_scale, extra_offset = ssim_offset (=
+ * ssim_lambda); sums is qed_loss_reduce's workspace (which also zeroes the slots this pass adds its loss sums to). */
+int qed_loss_grad_ssim(int32_t height, int32_t width, int32_t channels, const float* render, const float* alpha,
+                       const float* background, const float* gt_rgb, const float* gt_depth, const float* mask,
+                       const float* maps, float* sums, float rgb_weight, float depth_lambda, float ssim_scale,
+                       float* v_render, float* v_alpha, float* losses, const float* ssim_sum,
+                       int32_t ssim_sum_n, float ssim_offset, void* stream);
+
 /* ---- the same arithmetic behind the reference's OWN call sequence --------------------------------
  * get_outputs() returns images and get_loss_dict() turns them into a dict of scalar losses that the
  * trainer sums and differentiates; each half is one autograd node on the host side.

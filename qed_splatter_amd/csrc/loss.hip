@@ -68,14 +68,17 @@ __device__ __forceinline__ PixelEval eval_pixel(const float* __restrict__ render
 // pixels (its reciprocal scales every depth gradient) and the largest rendered depth (the value
 // alpha == 0 pixels take, model.py:306).  It reads the depth channel, the ground-truth depth and the
 // mask -- not the colours.
-constexpr int kLossMaxGrid = (QED_LOSS_SUMS_FLOATS - 8) / 4;
-__device__ __forceinline__ float* loss_part(float* sums, int row) { return sums + 8 + row * kLossMaxGrid; }
+// (kLossMaxGrid / loss_part: qed_common.h -- the fused SSIM-backward + loss-gradient pass of ssim.hip uses them too)
 
 template <int CH>
 __global__ void __launch_bounds__(256)
 loss_reduce_kernel(int n_pix, const float* __restrict__ render, const float* __restrict__ alpha,
                    const float* __restrict__ bg, const float* __restrict__ gt_rgb, const float* __restrict__ gt_depth,
                    const float* __restrict__ mask, float* __restrict__ sums) {
+    // rows 2 and 3 (the loss sums of pass 2): zeroed here for the fused SSIM-backward + gradient pass (ssim.hip), whose
+    // workgroups -- more than kLossMaxGrid at 1080p -- ADD their partials to slot (index mod this grid); the plain pass 2
+    // overwrites its slots
+    if (threadIdx.x == 0) { loss_part(sums, 2)[blockIdx.x] = 0.f; loss_part(sums, 3)[blockIdx.x] = 0.f; }
     if constexpr (CH != 4) return;
     float nv = 0.f;
     float dmax = -3.0e38f;

@@ -151,4 +151,21 @@ __device__ __forceinline__ int wave_max_i(int v) {
     return v;
 }
 
+// ---- shared between loss.hip and ssim.hip: the sums workspace of the loss passes -------------------------------
+// sums (QED_LOSS_SUMS_FLOATS floats): from [8] on four rows of kLossMaxGrid per-workgroup partials: n_valid, max depth
+// (pass 1), sum |rgb - gt|, sum |depth - gt| (pass 2); loss_finalize_kernel folds them into sums[0..3] and the losses.
+constexpr int kLossMaxGrid = (QED_LOSS_SUMS_FLOATS - 8) / 4;
+__device__ __forceinline__ float* loss_part(float* sums, int row) { return sums + 8 + row * kLossMaxGrid; }
+
+__global__ void loss_finalize_kernel(int n_pix, int n_blocks, int has_depth, float* __restrict__ sums, float rgb_weight,
+                                     float depth_lambda, float* __restrict__ losses, const float* __restrict__ extra_sum,
+                                     int extra_n, float extra_scale, float extra_offset);
+
+// grid of the two streaming loss passes (pass 2 reads pass 1's per-workgroup partials by index)
+inline unsigned loss_reduce_grid(long long n_pix) {
+    long long g = (n_pix + 255) / 256;
+    if (g > kLossMaxGrid) g = kLossMaxGrid;
+    return (unsigned)(g < 1 ? 1 : g);
+}
+
 }  // namespace qed

@@ -243,18 +243,40 @@ ssim_fwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
 
 // v_pred[H,W,3] = scale * (scale_dev ? scale_dev[0] : 1) * d(sum of the SSIM map)/d pred, pred = the colour BEFORE the
 // mask multiply (MASKED: x = m pred, y = m gt entered the SSIM, so the chain rule adds one factor m)
-template <bool COMPOSITE, bool MASKED, class T>
+// FUSE_CH = 3 / 4 (COMPOSITE only): the pass also does the work of loss.hip's gradient pass for a render of that many
+// channels -- instead of storing the SSIM gradient v_pred for qed_loss_grad to read back together with render, alpha and
+// the ground truth (116 MB of re-reads and one launch at 1080p), every thread finishes its four pixels on the spot:
+// L1 gradient + SSIM gradient through the clamp and the background composite -> v_render / v_alpha, depth-L1 gradient
+// into channel 3, and the workgroup's partial loss sums added to the slots qed_loss_reduce zeroed.
+struct LossFuse {
+    const float* gt_depth;
+    float* sums;            // the loss passes' workspace (pass 1 = qed_loss_reduce has run: n_valid, max depth partials)
+    int n_loss_blocks;      // pass 1's grid
+    float w_rgb;            // rgb_weight / (3 n_pix)
+    float depth_lambda;
+    float* v_render;
+    float* v_alpha;
+};
+
+template <bool COMPOSITE, bool MASKED, class T, int FUSE_CH = 0>
 #ifndef QED_SSIM_BWD_WAVES
 #define QED_SSIM_BWD_WAVES 4
 #endif
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QED_SSIM_BWD_WAVES, QED_SSIM_BWD_WAVES)))
+#ifndef QED_SSIM_FUSED_WAVES
+#define QED_SSIM_FUSED_WAVES 3      // the fused form holds its four pixels' inputs across the channel passes: 170 VGPRs
+#endif
+__global__ void __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(FUSE_CH ? QED_SSIM_FUSED_WAVES : QED_SSIM_BWD_WAVES,
+                                   FUSE_CH ? QED_SSIM_FUSED_WAVES : QED_SSIM_BWD_WAVES)))
 ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, const float* __restrict__ alpha,
                 const float* __restrict__ bg, const float* __restrict__ gt, const float* __restrict__ mask,
                 const float* __restrict__ maps, float scale, const float* __restrict__ scale_dev,
-                float* __restrict__ v_pred) {
+                float* __restrict__ v_pred, LossFuse lf) {
+    static_assert(FUSE_CH == 0 || COMPOSITE, "the fused loss gradient works on the rendered buffers");
     constexpr int TW = T::TW, PW = T::PW, PH = T::PH, SP = T::SP, SH = T::SH, CB = T::CB;
     __shared__ __attribute__((aligned(16))) float s_m[3][PH * SP];
     __shared__ __attribute__((aligned(16))) float s_h[3][PH * SH];
+    __shared__ float s_red[2][4];
     const int Ho = H - kHalo, Wo = W - kHalo;
     const int nbx = (W + TW - 1) / TW;
     const int blk = xcd_remap(blockIdx.x, gridDim.x);                   // halo sharing: see ssim_fwd_kernel
@@ -270,6 +292,55 @@ ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
     const int tx = tid % TW, ty0 = (tid / TW) * CB;
     const int ix = ox + tx;
     if (scale_dev != nullptr) scale *= scale_dev[0];
+    // FUSE: everything the epilogue needs is REQUESTED here, ahead of the three channel passes, and used after them --
+    // pass 1's per-workgroup partials (n_valid, largest rendered depth: folded as loss_grad_kernel does) and the four
+    // pixels' render / alpha / ground truth.  Requested at the end instead, their latency was exposed once per workgroup
+    // generation and the fused pass took 100 us against 50 + 29 for the two it replaces.
+    float l1 = 0.f, dsum = 0.f;
+    float ep_nv[4] = {0.f, 0.f, 0.f, 0.f}, ep_dm[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+    float4 ep_c[CB];
+    float ep_a[CB], ep_gd[CB];
+    Float3 ep_g[CB];
+    if constexpr (FUSE_CH != 0) {
+        static_assert(kLossMaxGrid <= 4 * 256, "four partials per thread cover pass 1's grid");
+        if constexpr (FUSE_CH == 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int b = tid + 256 * j;
+                const int bc = b < lf.n_loss_blocks ? b : 0;
+                const float nv = loss_part(lf.sums, 0)[bc], dm = loss_part(lf.sums, 1)[bc];
+                ep_nv[j] = b < lf.n_loss_blocks ? nv : 0.f;
+                ep_dm[j] = b < lf.n_loss_blocks ? dm : -3.0e38f;
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < CB; ++o) {
+            const size_t pix = (size_t)min(oy + ty0 + o, H - 1) * W + min(ix, W - 1);
+            if constexpr (FUSE_CH == 4) {
+                ep_c[o] = *reinterpret_cast<const float4*>(pred + 4 * pix);
+                ep_gd[o] = lf.gt_depth[pix];
+            } else {
+                const Float3 t = *reinterpret_cast<const Float3*>(pred + 3 * pix);
+                ep_c[o] = make_float4(t.a, t.b, t.c, 0.f);
+                ep_gd[o] = 0.f;
+            }
+            ep_a[o] = alpha[pix];
+            ep_g[o] = *reinterpret_cast<const Float3*>(gt + pix * 3);
+        }
+    }
+    float w_d = 0.f, dmax = 0.f;
+    if constexpr (FUSE_CH == 4) {
+        float nv = (ep_nv[0] + ep_nv[1]) + (ep_nv[2] + ep_nv[3]);
+        float dm = fmaxf(fmaxf(ep_dm[0], ep_dm[1]), fmaxf(ep_dm[2], ep_dm[3]));
+        nv = wave_sum(nv);
+        dm = wave_max(dm);
+        if ((tid & 63) == 0) { s_red[0][tid >> 6] = nv; s_red[1][tid >> 6] = dm; }
+        __syncthreads();
+        const float nvalid = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+        dmax = fmaxf(fmaxf(s_red[1][0], s_red[1][1]), fmaxf(s_red[1][2], s_red[1][3]));
+        w_d = nvalid > 0.f ? lf.depth_lambda / nvalid : 0.f;
+        // (s_red is written again only after the channel passes, each of which starts with a barrier)
+    }
     float r0[CB], r1[CB];            // channels 0 and 1 wait for channel 2: one 12-byte store per pixel
     float mo[CB];
 #pragma unroll
@@ -341,10 +412,63 @@ ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
             else {
                 const int iy = oy + ty0 + o;
                 if (ix < W && iy < H) {
-                    Float3 v; v.a = r0[o]; v.b = r1[o]; v.c = r;
-                    *reinterpret_cast<Float3*>(v_pred + ((size_t)iy * W + ix) * 3) = v;
+                    const size_t pix = (size_t)iy * W + ix;
+                    if constexpr (FUSE_CH == 0) {
+                        Float3 v; v.a = r0[o]; v.b = r1[o]; v.c = r;
+                        *reinterpret_cast<Float3*>(v_pred + pix * 3) = v;
+                    } else {
+                        // loss_grad_kernel's pixel (loss.hip), with the SSIM gradient straight from registers
+                        const float c[4] = {ep_c[o].x, ep_c[o].y, ep_c[o].z, ep_c[o].w};
+                        const float a = ep_a[o];
+                        const Float3 g3 = ep_g[o];
+                        const float gk[3] = {g3.a, g3.b, g3.c};
+                        const float vs[3] = {r0[o], r1[o], r};
+                        const float m = MASKED ? mo[o] : 1.f;
+                        float vr[4] = {0.f, 0.f, 0.f, 0.f};
+                        float va = 0.f;
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) {
+                            const float pre = c[q] + (1.f - a) * bg[q];
+                            const float col = fminf(fmaxf(pre, 0.f), 1.f);
+                            const float diff = col * m - gk[q] * m;
+                            l1 += fabsf(diff);
+                            const float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+                            const bool pass = pre >= 0.f && pre <= 1.f;           // torch.clamp backward (inclusive)
+                            const float g_in = lf.w_rgb * sg * m + vs[q];
+                            const float g = pass ? g_in : 0.f;
+                            vr[q] = g;
+                            va -= g * bg[q];
+                        }
+                        if constexpr (FUSE_CH == 4) {
+                            const float dg = ep_gd[o] * m;
+                            const float dsel = a > 0.f ? c[3] : dmax;             // model.py:306
+                            const float dp = dsel * m;
+                            if (isfinite(dp) && isfinite(dg) && dg > 0.f) {
+                                const float diff = dp - dg;
+                                dsum += fabsf(diff);
+                                const float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+                                if (a > 0.f) vr[3] = w_d * sg * m;
+                            }
+                            *reinterpret_cast<float4*>(lf.v_render + 4 * pix) = make_float4(vr[0], vr[1], vr[2], vr[3]);
+                        } else {
+                            lf.v_render[3 * pix] = vr[0]; lf.v_render[3 * pix + 1] = vr[1]; lf.v_render[3 * pix + 2] = vr[2];
+                        }
+                        lf.v_alpha[pix] = va;
+                    }
                 }
             }
+        }
+    }
+    if constexpr (FUSE_CH != 0) {
+        l1 = wave_sum(l1);
+        dsum = wave_sum(dsum);
+        __syncthreads();
+        if ((tid & 63) == 0) { s_red[0][tid >> 6] = l1; s_red[1][tid >> 6] = dsum; }
+        __syncthreads();
+        if (tid == 0) {
+            const int slot = (int)(blockIdx.x % (unsigned)lf.n_loss_blocks);
+            atomicAdd(&loss_part(lf.sums, 2)[slot], s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3]);
+            atomicAdd(&loss_part(lf.sums, 3)[slot], s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3]);
         }
     }
 }
@@ -402,9 +526,36 @@ extern "C" int qed_ssim_bwd(int32_t height, int32_t width, int32_t channels, con
     const dim3 grid(((width + TileB::TW - 1) / TileB::TW) * ((height + TileB::TH - 1) / TileB::TH));
 #define QED_SSIM_BWD(COMP, MASK, CHN)                                                                               \
     hipLaunchKernelGGL((ssim_bwd_kernel<COMP, MASK, TileB>), grid, dim3(256), 0, st, height, width, CHN, pred, alpha,   \
-                       background, gt_rgb, mask, maps, scale, scale_dev, v_pred)
+                       background, gt_rgb, mask, maps, scale, scale_dev, v_pred, LossFuse{})
     if (alpha != nullptr) { if (mask) QED_SSIM_BWD(true, true, channels); else QED_SSIM_BWD(true, false, channels); }
     else { if (mask) QED_SSIM_BWD(false, true, 3); else QED_SSIM_BWD(false, false, 3); }
 #undef QED_SSIM_BWD
     return check_launch("qed_ssim_bwd");
+}
+
+// SSIM backward + the loss-gradient pass in ONE launch (fused training step): after qed_ssim_fwd and qed_loss_reduce.
+extern "C" int qed_loss_grad_ssim(int32_t height, int32_t width, int32_t channels, const float* render, const float* alpha,
+                                  const float* background, const float* gt_rgb, const float* gt_depth, const float* mask,
+                                  const float* maps, float* sums, float rgb_weight, float depth_lambda, float ssim_scale,
+                                  float* v_render, float* v_alpha, float* losses, const float* ssim_sum,
+                                  int32_t ssim_sum_n, float ssim_offset, void* stream) {
+    QED_REQUIRE(height > kHalo && width > kHalo, "image smaller than the 11 x 11 SSIM window");
+    QED_REQUIRE(channels == 3 || channels == 4, "channels must be 3 (RGB) or 4 (RGB+D)");
+    QED_REQUIRE(render && alpha && background && gt_rgb && maps && sums && v_render && v_alpha && losses && ssim_sum,
+                "null buffers");
+    QED_REQUIRE(channels == 3 || gt_depth, "gt_depth required with a depth channel");
+    hipStream_t st = (hipStream_t)stream;
+    const int n_pix = height * width;
+    const unsigned n_loss = loss_reduce_grid(n_pix);
+    const LossFuse lf{gt_depth, sums, (int)n_loss, rgb_weight / (3.f * (float)n_pix), depth_lambda, v_render, v_alpha};
+    const dim3 grid(((width + TileB::TW - 1) / TileB::TW) * ((height + TileB::TH - 1) / TileB::TH));
+#define QED_SSIM_BWD_FUSED(MASK, CHN)                                                                                \
+    hipLaunchKernelGGL((ssim_bwd_kernel<true, MASK, TileB, CHN>), grid, dim3(256), 0, st, height, width, CHN, render, \
+                       alpha, background, gt_rgb, mask, maps, ssim_scale, (const float*)nullptr, (float*)nullptr, lf)
+    if (channels == 4) { if (mask) QED_SSIM_BWD_FUSED(true, 4); else QED_SSIM_BWD_FUSED(false, 4); }
+    else { if (mask) QED_SSIM_BWD_FUSED(true, 3); else QED_SSIM_BWD_FUSED(false, 3); }
+#undef QED_SSIM_BWD_FUSED
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, n_pix, (int)n_loss, channels == 4 ? 1 : 0, sums,
+                       rgb_weight, depth_lambda, losses, ssim_sum, (int)ssim_sum_n, ssim_scale, ssim_offset);
+    return check_launch("qed_loss_grad_ssim");
 }

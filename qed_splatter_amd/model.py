@@ -334,24 +334,24 @@ class _FusedImageLoss(torch.autograd.Function):
         v_render = torch.empty_like(render)
         v_alpha = torch.empty_like(alpha)
         st = _stream()
-        extra = (None, None, 0, 0.0, 0.0)
+        args = (n_pix, CH, L.ptr(render), L.ptr(alpha), L.ptr(background), L.ptr(gt_rgb), L.ptr(gt_depth), L.ptr(mask))
+        L.check(lib.qed_loss_reduce(*args, L.ptr(sums), st), "qed_loss_reduce")
         if ssim_lambda > 0.0:
-            # main = (1 - l) L1 + l (1 - SSIM): the SSIM gradient w.r.t. the clamped colour is formed
-            # first and pass 2 below pushes it through the clamp / background composite with the L1 part
+            # main = (1 - l) L1 + l (1 - SSIM): ONE launch forms the SSIM gradient w.r.t. the clamped colour and pushes
+            # it, with the L1 part and the depth term, through the clamp / background composite (qed_loss_grad_ssim)
             n_out = 3.0 * (H - 10) * (W - 10)
             maps = torch.empty(lib.qed_ssim_maps_floats(H, W), dtype=torch.float32, device=dev)
-            v_rgb = torch.empty(H, W, 3, dtype=torch.float32, device=dev)
             ssum = torch.empty(lib.qed_ssim_sum_floats(H, W), dtype=torch.float32, device=dev)
             L.check(lib.qed_ssim_fwd(H, W, CH, L.ptr(render), L.ptr(alpha), L.ptr(background), L.ptr(gt_rgb),
                                      L.ptr(mask), L.ptr(maps), L.ptr(ssum), st), "qed_ssim_fwd")
-            L.check(lib.qed_ssim_bwd(H, W, CH, L.ptr(render), L.ptr(alpha), L.ptr(background), L.ptr(gt_rgb),
-                                     L.ptr(mask), L.ptr(maps), -ssim_lambda / n_out, None, L.ptr(v_rgb), st),
-                    "qed_ssim_bwd")
-            extra = (L.ptr(v_rgb), L.ptr(ssum), ssum.numel(), -ssim_lambda / n_out, ssim_lambda)
-        args = (n_pix, CH, L.ptr(render), L.ptr(alpha), L.ptr(background), L.ptr(gt_rgb), L.ptr(gt_depth), L.ptr(mask))
-        L.check(lib.qed_loss_reduce(*args, L.ptr(sums), st), "qed_loss_reduce")
-        L.check(lib.qed_loss_grad(*args, L.ptr(sums), 1.0 - ssim_lambda, depth_lambda, L.ptr(v_render),
-                                  L.ptr(v_alpha), L.ptr(losses), *extra, st), "qed_loss_grad")
+            L.check(lib.qed_loss_grad_ssim(H, W, CH, L.ptr(render), L.ptr(alpha), L.ptr(background), L.ptr(gt_rgb),
+                                           L.ptr(gt_depth), L.ptr(mask), L.ptr(maps), L.ptr(sums), 1.0 - ssim_lambda,
+                                           depth_lambda, -ssim_lambda / n_out, L.ptr(v_render), L.ptr(v_alpha),
+                                           L.ptr(losses), L.ptr(ssum), ssum.numel(), ssim_lambda, st),
+                    "qed_loss_grad_ssim")
+        else:
+            L.check(lib.qed_loss_grad(*args, L.ptr(sums), 1.0, depth_lambda, L.ptr(v_render), L.ptr(v_alpha),
+                                      L.ptr(losses), None, None, 0, 0.0, 0.0, st), "qed_loss_grad")
         ctx.save_for_backward(v_render, v_alpha)
         total = losses[2:3].view(())
         parts = losses[0:2]

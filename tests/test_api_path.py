@@ -460,3 +460,61 @@ def test_ssim_forward_shared_between_metrics_and_loss(cuda, uint8_image):
         out = m.get_outputs(cam)
         m.get_metrics_dict(out, batch)
     assert getattr(m, "_ssim_shared", None) is None                   # nothing kept outside training
+
+
+@pytest.mark.parametrize("ch,masked,size", [(4, False, (75, 101)), (4, True, (64, 96)), (3, False, (45, 70)), (3, True, (33, 33))])
+def test_fused_ssim_backward_and_loss_gradient_equals_the_two_passes(cuda, lib, ch, masked, size):
+    """qed_loss_grad_ssim (SSIM backward + loss gradient in one launch) against qed_ssim_bwd followed by qed_loss_grad on
+    random buffers: colours on both sides of the clamp, alpha == 0 pixels (depth fix-up), invalid ground-truth depths,
+    image sizes that are not multiples of the 32 x 32 tile."""
+    from qed_splatter_amd import _lib as L
+    H, W = size
+    g = torch.Generator().manual_seed(H * 1000 + W + ch)
+    render = (torch.rand(H, W, ch, generator=g) * 1.6 - 0.3)
+    if ch == 4:
+        render[..., 3] = torch.rand(H, W, generator=g) * 10.0
+    alpha = torch.rand(H, W, 1, generator=g)
+    alpha[torch.rand(H, W, 1, generator=g) < 0.1] = 0.0
+    bg = torch.tensor([0.2, 0.5, 0.9])
+    gt = torch.rand(H, W, 3, generator=g)
+    gd = torch.rand(H, W, 1, generator=g) * 10.0
+    gd[torch.rand(H, W, 1, generator=g) < 0.1] = 0.0
+    gd[0, 0, 0] = float("nan")
+    mask = (torch.rand(H, W, 1, generator=g) > 0.3).float() if masked else None
+    render, alpha, bg, gt, gd = (t.to(cuda).contiguous() for t in (render, alpha, bg, gt, gd))
+    mask = mask.to(cuda).contiguous() if masked else None
+    lam, dl = 0.2, 0.2
+    n_out = 3.0 * (H - 10) * (W - 10)
+    st = torch.cuda.current_stream().cuda_stream
+    maps = torch.empty(lib.qed_ssim_maps_floats(H, W), device=cuda)
+    ssum = torch.empty(lib.qed_ssim_sum_floats(H, W), device=cuda)
+    L.check(lib.qed_ssim_fwd(H, W, ch, L.ptr(render), L.ptr(alpha), L.ptr(bg), L.ptr(gt), L.ptr(mask), L.ptr(maps),
+                             L.ptr(ssum), st), "qed_ssim_fwd")
+    args = (H * W, ch, L.ptr(render), L.ptr(alpha), L.ptr(bg), L.ptr(gt), L.ptr(gd), L.ptr(mask))
+    out = []
+    for fused in (False, True):
+        sums = torch.full((L.LOSS_SUMS_FLOATS,), float("nan"), device=cuda)
+        losses = torch.empty(3, device=cuda)
+        v_r, v_a = torch.full_like(render, 7.0), torch.full_like(alpha, 7.0)
+        L.check(lib.qed_loss_reduce(*args, L.ptr(sums), st), "qed_loss_reduce")
+        if fused:
+            L.check(lib.qed_loss_grad_ssim(H, W, ch, L.ptr(render), L.ptr(alpha), L.ptr(bg), L.ptr(gt), L.ptr(gd),
+                                           L.ptr(mask), L.ptr(maps), L.ptr(sums), 1.0 - lam, dl, -lam / n_out, L.ptr(v_r),
+                                           L.ptr(v_a), L.ptr(losses), L.ptr(ssum), ssum.numel(), lam, st),
+                    "qed_loss_grad_ssim")
+        else:
+            v_rgb = torch.empty(H, W, 3, device=cuda)
+            L.check(lib.qed_ssim_bwd(H, W, ch, L.ptr(render), L.ptr(alpha), L.ptr(bg), L.ptr(gt), L.ptr(mask), L.ptr(maps),
+                                     -lam / n_out, None, L.ptr(v_rgb), st), "qed_ssim_bwd")
+            L.check(lib.qed_loss_grad(*args, L.ptr(sums), 1.0 - lam, dl, L.ptr(v_r), L.ptr(v_a), L.ptr(losses), L.ptr(v_rgb),
+                                      L.ptr(ssum), ssum.numel(), -lam / n_out, lam, st), "qed_loss_grad")
+        torch.cuda.synchronize()
+        out.append((v_r, v_a, losses))
+    (r0, a0, l0), (r1, a1, l1) = out
+    assert torch.isfinite(r1).all() and torch.isfinite(a1).all()
+    # same expressions, evaluated by another kernel: at most a fused-multiply-add of difference
+    assert float((r1 - r0).abs().max()) <= 1e-9 + 2e-7 * float(r0.abs().max())
+    assert float((a1 - a0).abs().max()) <= 1e-9 + 2e-7 * float(a0.abs().max())
+    assert torch.allclose(l1, l0, rtol=2e-6, atol=0.0), (l1, l0)
+    if ch == 3:
+        assert float(l1[1]) == 0.0
