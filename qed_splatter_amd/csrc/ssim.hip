@@ -243,36 +243,44 @@ ssim_fwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
 
 // v_pred[H,W,3] = scale * (scale_dev ? scale_dev[0] : 1) * d(sum of the SSIM map)/d pred, pred = the colour BEFORE the
 // mask multiply (MASKED: x = m pred, y = m gt entered the SSIM, so the chain rule adds one factor m)
-// FUSE_CH = 3 / 4 (COMPOSITE only): the pass also does the work of loss.hip's gradient pass for a render of that many
-// channels -- instead of storing the SSIM gradient v_pred for qed_loss_grad to read back together with render, alpha and
-// the ground truth (116 MB of re-reads and one launch at 1080p), every thread finishes its four pixels on the spot:
-// L1 gradient + SSIM gradient through the clamp and the background composite -> v_render / v_alpha, depth-L1 gradient
-// into channel 3, and the workgroup's partial loss sums added to the slots qed_loss_reduce zeroed.
+// FUSE: the pass also does the work of the loss-gradient pass that would follow it, instead of storing the SSIM gradient
+// for that pass to read back together with the images (116 MB of re-reads and one launch at 1080p):
+//   FUSE = 3 / 4 (COMPOSITE; the fused training step, qed_loss_grad_ssim): loss.hip's loss_grad_kernel for a render of
+//     that many channels.  Inside each channel pass the thread's own colour is at hand before and after the clamp, so
+//     the L1 term, the clamp mask and the background-composite gradient are formed there; after the last pass only
+//     the depth channel is left: -> v_render / v_alpha, and the workgroup's loss sums are added to the slots
+//     qed_loss_reduce zeroed.
+//   FUSE = 1 (plain images; get_loss_dict's backward, qed_image_losses_ssim_bwd): image_loss_grad_kernel -- the L1 term
+//     scaled by its upstream gradient joins the SSIM term in v_pred, the depth-L1 gradient goes to v_depth.
 struct LossFuse {
+    const float* depth;     // FUSE 1: the depth image [H,W]
     const float* gt_depth;
-    float* sums;            // the loss passes' workspace (pass 1 = qed_loss_reduce has run: n_valid, max depth partials)
-    int n_loss_blocks;      // pass 1's grid
+    float* sums;            // the loss passes' workspace (FUSE 3/4: pass 1 = qed_loss_reduce has run; FUSE 1: sums[2] = n_valid)
+    int n_loss_blocks;      // FUSE 3/4: pass 1's grid
     float w_rgb;            // rgb_weight / (3 n_pix)
     float depth_lambda;
-    float* v_render;
+    const float* g_main;    // FUSE 1: upstream gradients of the two loss terms (device scalars; NULL = that term has none)
+    const float* g_depth;
+    float* v_render;        // FUSE 3/4 outputs
     float* v_alpha;
+    float* v_depth;         // FUSE 1 output (may be NULL)
 };
 
-template <bool COMPOSITE, bool MASKED, class T, int FUSE_CH = 0>
+template <bool COMPOSITE, bool MASKED, class T, int FUSE = 0>
 #ifndef QED_SSIM_BWD_WAVES
 #define QED_SSIM_BWD_WAVES 4
 #endif
 #ifndef QED_SSIM_FUSED_WAVES
-#define QED_SSIM_FUSED_WAVES 3      // the fused form holds its four pixels' inputs across the channel passes: 170 VGPRs
+#define QED_SSIM_FUSED_WAVES 3      // FUSE 3/4 holds the depth inputs and the alpha gradients of its four pixels as well
 #endif
 __global__ void __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(FUSE_CH ? QED_SSIM_FUSED_WAVES : QED_SSIM_BWD_WAVES,
-                                   FUSE_CH ? QED_SSIM_FUSED_WAVES : QED_SSIM_BWD_WAVES)))
+__attribute__((amdgpu_waves_per_eu(FUSE >= 3 ? QED_SSIM_FUSED_WAVES : QED_SSIM_BWD_WAVES,
+                                   FUSE >= 3 ? QED_SSIM_FUSED_WAVES : QED_SSIM_BWD_WAVES)))
 ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, const float* __restrict__ alpha,
                 const float* __restrict__ bg, const float* __restrict__ gt, const float* __restrict__ mask,
                 const float* __restrict__ maps, float scale, const float* __restrict__ scale_dev,
                 float* __restrict__ v_pred, LossFuse lf) {
-    static_assert(FUSE_CH == 0 || COMPOSITE, "the fused loss gradient works on the rendered buffers");
+    static_assert(FUSE == 0 || (FUSE == 1 && !COMPOSITE) || ((FUSE == 3 || FUSE == 4) && COMPOSITE), "see LossFuse");
     constexpr int TW = T::TW, PW = T::PW, PH = T::PH, SP = T::SP, SH = T::SH, CB = T::CB;
     __shared__ __attribute__((aligned(16))) float s_m[3][PH * SP];
     __shared__ __attribute__((aligned(16))) float s_h[3][PH * SH];
@@ -292,18 +300,22 @@ ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
     const int tx = tid % TW, ty0 = (tid / TW) * CB;
     const int ix = ox + tx;
     if (scale_dev != nullptr) scale *= scale_dev[0];
-    // FUSE: everything the epilogue needs is REQUESTED here, ahead of the three channel passes, and used after them --
-    // pass 1's per-workgroup partials (n_valid, largest rendered depth: folded as loss_grad_kernel does) and the four
-    // pixels' render / alpha / ground truth.  Requested at the end instead, their latency was exposed once per workgroup
-    // generation and the fused pass took 100 us against 50 + 29 for the two it replaces.
-    float l1 = 0.f, dsum = 0.f;
-    float ep_nv[4] = {0.f, 0.f, 0.f, 0.f}, ep_dm[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
-    float4 ep_c[CB];
-    float ep_a[CB], ep_gd[CB];
-    Float3 ep_g[CB];
-    if constexpr (FUSE_CH != 0) {
-        static_assert(kLossMaxGrid <= 4 * 256, "four partials per thread cover pass 1's grid");
-        if constexpr (FUSE_CH == 4) {
+    // FUSE: what the depth part needs is REQUESTED here, ahead of the three channel passes, and used after them (asked for
+    // at the end, its latency is exposed once per workgroup generation: the first fused form took 100 us against 50 + 29
+    // for the two passes it replaces).  FUSE 4: pass 1's per-workgroup partials (n_valid, the largest rendered depth),
+    // folded as loss_grad_kernel does.
+    float l1 = 0.f, dsum = 0.f, w_rgb = 0.f, w_d = 0.f, dmax = 0.f;
+    float ep_d[CB], ep_a[CB], ep_gd[CB], va[CB];
+    bool inside[CB];
+#pragma unroll
+    for (int o = 0; o < CB; ++o) { ep_d[o] = 0.f; ep_a[o] = 1.f; ep_gd[o] = 0.f; va[o] = 0.f; inside[o] = ix < W && oy + ty0 + o < H; }
+    if constexpr (FUSE != 0) {
+        w_rgb = lf.w_rgb;
+        if constexpr (FUSE == 1) w_rgb *= lf.g_main != nullptr ? lf.g_main[0] : 0.f;
+        const bool want_depth = FUSE == 4 || (FUSE == 1 && lf.v_depth != nullptr);
+        float ep_nv[4] = {0.f, 0.f, 0.f, 0.f}, ep_dm[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+        if constexpr (FUSE == 4) {
+            static_assert(kLossMaxGrid <= 4 * 256, "four partials per thread cover pass 1's grid");
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int b = tid + 256 * j;
@@ -313,33 +325,30 @@ ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
                 ep_dm[j] = b < lf.n_loss_blocks ? dm : -3.0e38f;
             }
         }
+        if (want_depth) {
 #pragma unroll
-        for (int o = 0; o < CB; ++o) {
-            const size_t pix = (size_t)min(oy + ty0 + o, H - 1) * W + min(ix, W - 1);
-            if constexpr (FUSE_CH == 4) {
-                ep_c[o] = *reinterpret_cast<const float4*>(pred + 4 * pix);
+            for (int o = 0; o < CB; ++o) {
+                const size_t pix = (size_t)min(oy + ty0 + o, H - 1) * W + min(ix, W - 1);
+                if constexpr (FUSE == 4) { ep_d[o] = pred[4 * pix + 3]; ep_a[o] = alpha[pix]; }
+                else ep_d[o] = lf.depth[pix];
                 ep_gd[o] = lf.gt_depth[pix];
-            } else {
-                const Float3 t = *reinterpret_cast<const Float3*>(pred + 3 * pix);
-                ep_c[o] = make_float4(t.a, t.b, t.c, 0.f);
-                ep_gd[o] = 0.f;
             }
-            ep_a[o] = alpha[pix];
-            ep_g[o] = *reinterpret_cast<const Float3*>(gt + pix * 3);
         }
-    }
-    float w_d = 0.f, dmax = 0.f;
-    if constexpr (FUSE_CH == 4) {
-        float nv = (ep_nv[0] + ep_nv[1]) + (ep_nv[2] + ep_nv[3]);
-        float dm = fmaxf(fmaxf(ep_dm[0], ep_dm[1]), fmaxf(ep_dm[2], ep_dm[3]));
-        nv = wave_sum(nv);
-        dm = wave_max(dm);
-        if ((tid & 63) == 0) { s_red[0][tid >> 6] = nv; s_red[1][tid >> 6] = dm; }
-        __syncthreads();
-        const float nvalid = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
-        dmax = fmaxf(fmaxf(s_red[1][0], s_red[1][1]), fmaxf(s_red[1][2], s_red[1][3]));
-        w_d = nvalid > 0.f ? lf.depth_lambda / nvalid : 0.f;
-        // (s_red is written again only after the channel passes, each of which starts with a barrier)
+        if constexpr (FUSE == 4) {
+            float nv = (ep_nv[0] + ep_nv[1]) + (ep_nv[2] + ep_nv[3]);
+            float dm = fmaxf(fmaxf(ep_dm[0], ep_dm[1]), fmaxf(ep_dm[2], ep_dm[3]));
+            nv = wave_sum(nv);
+            dm = wave_max(dm);
+            if ((tid & 63) == 0) { s_red[0][tid >> 6] = nv; s_red[1][tid >> 6] = dm; }
+            __syncthreads();
+            const float nvalid = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+            dmax = fmaxf(fmaxf(s_red[1][0], s_red[1][1]), fmaxf(s_red[1][2], s_red[1][3]));
+            w_d = nvalid > 0.f ? lf.depth_lambda / nvalid : 0.f;
+            // (s_red is written again only after the channel passes, each of which starts with a barrier)
+        } else if constexpr (FUSE == 1) {
+            const float nvalid = lf.sums[2];
+            w_d = nvalid > 0.f ? (lf.g_depth != nullptr ? lf.g_depth[0] : 0.f) * lf.depth_lambda / nvalid : 0.f;
+        }
     }
     float r0[CB], r1[CB];            // channels 0 and 1 wait for channel 2: one 12-byte store per pixel
     float mo[CB];
@@ -360,11 +369,18 @@ ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
             mv[j][0] = in ? al : 0.f; mv[j][1] = in ? bl : 0.f; mv[j][2] = in ? cl : 0.f;
         }
         // the output pixels' own colours, requested with the maps so their latency hides behind both passes
-        float xo[CB], yo[CB];
+        float xo[CB], yo[CB], pre[CB];
+        const float bgk = COMPOSITE ? bg[k] : 0.f;
 #pragma unroll
         for (int o = 0; o < CB; ++o) {
             const size_t pix = (size_t)min(oy + ty0 + o, H - 1) * W + min(ix, W - 1);
-            xo[o] = pred_at<COMPOSITE>(pred, alpha, bg, channels, pix, k);
+            if constexpr (COMPOSITE) {
+                pre[o] = pred[pix * channels + k] + (1.f - alpha[pix]) * bgk;     // model.py:296 before the clamp
+                xo[o] = fminf(fmaxf(pre[o], 0.f), 1.f);
+            } else {
+                pre[o] = 0.f;
+                xo[o] = pred[pix * 3 + k];
+            }
             yo[o] = gt[pix * 3 + k];
             if constexpr (MASKED) { xo[o] *= mo[o]; yo[o] *= mo[o]; }
         }
@@ -407,59 +423,56 @@ ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
         for (int o = 0; o < CB; ++o) {
             float r = scale * (g[0][o] + 2.f * xo[o] * g[1][o] + yo[o] * g[2][o]);
             if constexpr (MASKED) r *= mo[o];
+            if constexpr (FUSE != 0) {
+                // the L1 term of the same (masked) colours; FUSE 3/4: then through the clamp and the background composite
+                const float diff = xo[o] - yo[o];
+                if (inside[o]) l1 += fabsf(diff);
+                const float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+                r = w_rgb * sg * mo[o] + r;
+                if constexpr (COMPOSITE) {
+                    r = (pre[o] >= 0.f && pre[o] <= 1.f) ? r : 0.f;               // torch.clamp backward (inclusive)
+                    va[o] -= r * bgk;
+                }
+            }
             if (k == 0) r0[o] = r;
             else if (k == 1) r1[o] = r;
-            else {
-                const int iy = oy + ty0 + o;
-                if (ix < W && iy < H) {
-                    const size_t pix = (size_t)iy * W + ix;
-                    if constexpr (FUSE_CH == 0) {
-                        Float3 v; v.a = r0[o]; v.b = r1[o]; v.c = r;
-                        *reinterpret_cast<Float3*>(v_pred + pix * 3) = v;
-                    } else {
-                        // loss_grad_kernel's pixel (loss.hip), with the SSIM gradient straight from registers
-                        const float c[4] = {ep_c[o].x, ep_c[o].y, ep_c[o].z, ep_c[o].w};
-                        const float a = ep_a[o];
-                        const Float3 g3 = ep_g[o];
-                        const float gk[3] = {g3.a, g3.b, g3.c};
-                        const float vs[3] = {r0[o], r1[o], r};
-                        const float m = MASKED ? mo[o] : 1.f;
-                        float vr[4] = {0.f, 0.f, 0.f, 0.f};
-                        float va = 0.f;
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) {
-                            const float pre = c[q] + (1.f - a) * bg[q];
-                            const float col = fminf(fmaxf(pre, 0.f), 1.f);
-                            const float diff = col * m - gk[q] * m;
-                            l1 += fabsf(diff);
-                            const float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
-                            const bool pass = pre >= 0.f && pre <= 1.f;           // torch.clamp backward (inclusive)
-                            const float g_in = lf.w_rgb * sg * m + vs[q];
-                            const float g = pass ? g_in : 0.f;
-                            vr[q] = g;
-                            va -= g * bg[q];
-                        }
-                        if constexpr (FUSE_CH == 4) {
-                            const float dg = ep_gd[o] * m;
-                            const float dsel = a > 0.f ? c[3] : dmax;             // model.py:306
-                            const float dp = dsel * m;
+            else if (inside[o]) {
+                const size_t pix = (size_t)(oy + ty0 + o) * W + ix;
+                if constexpr (FUSE == 0 || FUSE == 1) {
+                    Float3 v; v.a = r0[o]; v.b = r1[o]; v.c = r;
+                    *reinterpret_cast<Float3*>(v_pred + pix * 3) = v;
+                    if constexpr (FUSE == 1) {
+                        if (lf.v_depth != nullptr) {
+                            const float dp = ep_d[o] * mo[o], dg = ep_gd[o] * mo[o];
+                            float gd = 0.f;
                             if (isfinite(dp) && isfinite(dg) && dg > 0.f) {
-                                const float diff = dp - dg;
-                                dsum += fabsf(diff);
-                                const float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
-                                if (a > 0.f) vr[3] = w_d * sg * m;
+                                const float dd = dp - dg;
+                                gd = w_d * (dd > 0.f ? 1.f : (dd < 0.f ? -1.f : 0.f)) * mo[o];
                             }
-                            *reinterpret_cast<float4*>(lf.v_render + 4 * pix) = make_float4(vr[0], vr[1], vr[2], vr[3]);
-                        } else {
-                            lf.v_render[3 * pix] = vr[0]; lf.v_render[3 * pix + 1] = vr[1]; lf.v_render[3 * pix + 2] = vr[2];
+                            lf.v_depth[pix] = gd;
                         }
-                        lf.v_alpha[pix] = va;
                     }
+                } else if constexpr (FUSE == 4) {
+                    const float a = ep_a[o];
+                    const float dg = ep_gd[o] * mo[o];
+                    const float dp = (a > 0.f ? ep_d[o] : dmax) * mo[o];               // model.py:306
+                    float v3 = 0.f;
+                    if (isfinite(dp) && isfinite(dg) && dg > 0.f) {
+                        const float dd = dp - dg;
+                        dsum += fabsf(dd);
+                        if (a > 0.f) v3 = w_d * (dd > 0.f ? 1.f : (dd < 0.f ? -1.f : 0.f)) * mo[o];
+                    }
+                    *reinterpret_cast<float4*>(lf.v_render + 4 * pix) = make_float4(r0[o], r1[o], r, v3);
+                    lf.v_alpha[pix] = va[o];
+                } else {
+                    Float3 v; v.a = r0[o]; v.b = r1[o]; v.c = r;
+                    *reinterpret_cast<Float3*>(lf.v_render + 3 * pix) = v;
+                    lf.v_alpha[pix] = va[o];
                 }
             }
         }
     }
-    if constexpr (FUSE_CH != 0) {
+    if constexpr (FUSE >= 3) {
         l1 = wave_sum(l1);
         dsum = wave_sum(dsum);
         __syncthreads();
@@ -547,7 +560,8 @@ extern "C" int qed_loss_grad_ssim(int32_t height, int32_t width, int32_t channel
     hipStream_t st = (hipStream_t)stream;
     const int n_pix = height * width;
     const unsigned n_loss = loss_reduce_grid(n_pix);
-    const LossFuse lf{gt_depth, sums, (int)n_loss, rgb_weight / (3.f * (float)n_pix), depth_lambda, v_render, v_alpha};
+    const LossFuse lf{nullptr, gt_depth, sums, (int)n_loss, rgb_weight / (3.f * (float)n_pix), depth_lambda, nullptr, nullptr,
+                      v_render, v_alpha, nullptr};
     const dim3 grid(((width + TileB::TW - 1) / TileB::TW) * ((height + TileB::TH - 1) / TileB::TH));
 #define QED_SSIM_BWD_FUSED(MASK, CHN)                                                                                \
     hipLaunchKernelGGL((ssim_bwd_kernel<true, MASK, TileB, CHN>), grid, dim3(256), 0, st, height, width, CHN, render, \
@@ -558,4 +572,28 @@ extern "C" int qed_loss_grad_ssim(int32_t height, int32_t width, int32_t channel
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, n_pix, (int)n_loss, channels == 4 ? 1 : 0, sums,
                        rgb_weight, depth_lambda, losses, ssim_sum, (int)ssim_sum_n, ssim_scale, ssim_offset);
     return check_launch("qed_loss_grad_ssim");
+}
+
+// qed_ssim_bwd + qed_image_losses_bwd in ONE launch (get_loss_dict's backward when the main loss has an upstream
+// gradient and an SSIM term): v_rgb = g_main * d main_loss / d rgb (L1 + SSIM), v_depth = g_depth * d depth_loss / d depth.
+extern "C" int qed_image_losses_ssim_bwd(int32_t height, int32_t width, const float* rgb, const float* depth,
+                                         const float* gt_rgb, const float* gt_depth, const float* mask, const float* maps,
+                                         const float* sums, float rgb_weight, float depth_lambda, float ssim_scale,
+                                         const float* g_main, const float* g_depth, float* v_rgb, float* v_depth,
+                                         void* stream) {
+    QED_REQUIRE(height > kHalo && width > kHalo, "image smaller than the 11 x 11 SSIM window");
+    QED_REQUIRE(rgb && gt_rgb && maps && sums && g_main && v_rgb, "null buffers");
+    QED_REQUIRE(v_depth == nullptr || (depth && gt_depth), "depth images required for a depth gradient");
+    hipStream_t st = (hipStream_t)stream;
+    const int n_pix = height * width;
+    const LossFuse lf{depth, gt_depth, const_cast<float*>(sums), 0, rgb_weight / (3.f * (float)n_pix), depth_lambda, g_main,
+                      g_depth, nullptr, nullptr, v_depth};
+    const dim3 grid(((width + TileB::TW - 1) / TileB::TW) * ((height + TileB::TH - 1) / TileB::TH));
+    if (mask)
+        hipLaunchKernelGGL((ssim_bwd_kernel<false, true, TileB, 1>), grid, dim3(256), 0, st, height, width, 3, rgb,
+                           (const float*)nullptr, (const float*)nullptr, gt_rgb, mask, maps, ssim_scale, g_main, v_rgb, lf);
+    else
+        hipLaunchKernelGGL((ssim_bwd_kernel<false, false, TileB, 1>), grid, dim3(256), 0, st, height, width, 3, rgb,
+                           (const float*)nullptr, (const float*)nullptr, gt_rgb, mask, maps, ssim_scale, g_main, v_rgb, lf);
+    return check_launch("qed_image_losses_ssim_bwd");
 }

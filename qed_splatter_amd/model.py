@@ -305,15 +305,17 @@ class _ImageLosses(torch.autograd.Function):
         v_rgb = torch.empty_like(rgb) if (g_main is not None and ctx.needs_input_grad[0]) else None
         v_depth = torch.empty_like(depth) if (g_depth is not None and depth is not None and ctx.needs_input_grad[1]) \
             else None
-        acc = 0
         if v_rgb is not None and ssim_lambda > 0.0:
+            # ONE launch: the L1 term joins the SSIM term inside the SSIM backward pass, the depth term rides along
             n_out = 3.0 * (H - 10) * (W - 10)
-            L.check(lib.qed_ssim_bwd(H, W, 3, L.ptr(rgb), None, None, L.ptr(gt_rgb), L.ptr(mask), L.ptr(maps),
-                                     -ssim_lambda / n_out, L.ptr(g_main), L.ptr(v_rgb), st), "qed_ssim_bwd")
-            acc = 1
-        L.check(lib.qed_image_losses_bwd(H * W, L.ptr(rgb), L.ptr(depth), L.ptr(gt_rgb), L.ptr(gt_depth), L.ptr(mask),
-                                         L.ptr(sums), 1.0 - ssim_lambda, depth_lambda, L.ptr(g_main), L.ptr(g_depth), acc,
-                                         L.ptr(v_rgb), L.ptr(v_depth), st), "qed_image_losses_bwd")
+            L.check(lib.qed_image_losses_ssim_bwd(H, W, L.ptr(rgb), L.ptr(depth), L.ptr(gt_rgb), L.ptr(gt_depth),
+                                                  L.ptr(mask), L.ptr(maps), L.ptr(sums), 1.0 - ssim_lambda, depth_lambda,
+                                                  -ssim_lambda / n_out, L.ptr(g_main), L.ptr(g_depth), L.ptr(v_rgb),
+                                                  L.ptr(v_depth), st), "qed_image_losses_ssim_bwd")
+        else:
+            L.check(lib.qed_image_losses_bwd(H * W, L.ptr(rgb), L.ptr(depth), L.ptr(gt_rgb), L.ptr(gt_depth), L.ptr(mask),
+                                             L.ptr(sums), 1.0 - ssim_lambda, depth_lambda, L.ptr(g_main), L.ptr(g_depth), 0,
+                                             L.ptr(v_rgb), L.ptr(v_depth), st), "qed_image_losses_bwd")
         return v_rgb, v_depth, None, None, None, None, None, None
 
 

@@ -518,3 +518,44 @@ def test_fused_ssim_backward_and_loss_gradient_equals_the_two_passes(cuda, lib, 
     assert torch.allclose(l1, l0, rtol=2e-6, atol=0.0), (l1, l0)
     if ch == 3:
         assert float(l1[1]) == 0.0
+
+
+@pytest.mark.parametrize("masked,with_depth", [(False, True), (True, True), (False, False)])
+def test_fused_image_losses_backward_equals_the_two_passes(cuda, lib, masked, with_depth):
+    """qed_image_losses_ssim_bwd == qed_ssim_bwd (scaled by the device-resident upstream gradient) followed by
+    qed_image_losses_bwd(accumulate): upstream gradients 2 and 3, invalid depths, a size that is not a multiple of 32."""
+    from qed_splatter_amd import _lib as L
+    H, W = 70, 107
+    g = torch.Generator().manual_seed(17)
+    rgb, gt = torch.rand(H, W, 3, generator=g), torch.rand(H, W, 3, generator=g)
+    depth, gd = torch.rand(H, W, 1, generator=g) * 9 + 0.5, torch.rand(H, W, 1, generator=g) * 10
+    gd[torch.rand(H, W, 1, generator=g) < 0.15] = 0.0
+    gd[3, 4, 0] = float("inf")
+    mask = (torch.rand(H, W, 1, generator=g) > 0.25).float().to(cuda) if masked else None
+    rgb, gt, depth, gd = (t.to(cuda).contiguous() for t in (rgb, gt, depth, gd))
+    lam, dl = 0.2, 0.2
+    n_out = 3.0 * (H - 10) * (W - 10)
+    st = torch.cuda.current_stream().cuda_stream
+    maps = torch.empty(lib.qed_ssim_maps_floats(H, W), device=cuda)
+    ssum = torch.empty(lib.qed_ssim_sum_floats(H, W), device=cuda)
+    sums = torch.empty(L.LOSS_SUMS_FLOATS, device=cuda)
+    losses = torch.empty(3, device=cuda)
+    L.check(lib.qed_ssim_fwd(H, W, 3, L.ptr(rgb), None, None, L.ptr(gt), L.ptr(mask), L.ptr(maps), L.ptr(ssum), st), "ssim_fwd")
+    L.check(lib.qed_image_losses_fwd(H * W, L.ptr(rgb), L.ptr(depth), L.ptr(gt), L.ptr(gd), L.ptr(mask), 1.0 - lam, dl,
+                                     L.ptr(ssum), ssum.numel(), -lam / n_out, lam, L.ptr(sums), L.ptr(losses), st), "fwd")
+    g_main, g_depth = torch.tensor([2.0], device=cuda), torch.tensor([3.0], device=cuda)
+    a_rgb, a_d = torch.empty_like(rgb), torch.empty_like(depth)
+    L.check(lib.qed_ssim_bwd(H, W, 3, L.ptr(rgb), None, None, L.ptr(gt), L.ptr(mask), L.ptr(maps), -lam / n_out,
+                             L.ptr(g_main), L.ptr(a_rgb), st), "qed_ssim_bwd")
+    L.check(lib.qed_image_losses_bwd(H * W, L.ptr(rgb), L.ptr(depth), L.ptr(gt), L.ptr(gd), L.ptr(mask), L.ptr(sums),
+                                     1.0 - lam, dl, L.ptr(g_main), L.ptr(g_depth), 1, L.ptr(a_rgb), L.ptr(a_d), st), "bwd")
+    b_rgb, b_d = torch.full_like(rgb, 5.0), torch.full_like(depth, 5.0)
+    L.check(lib.qed_image_losses_ssim_bwd(H, W, L.ptr(rgb), L.ptr(depth), L.ptr(gt), L.ptr(gd), L.ptr(mask), L.ptr(maps),
+                                          L.ptr(sums), 1.0 - lam, dl, -lam / n_out, L.ptr(g_main), L.ptr(g_depth),
+                                          L.ptr(b_rgb), L.ptr(b_d) if with_depth else None, st), "fused")
+    torch.cuda.synchronize()
+    assert float((b_rgb - a_rgb).abs().max()) <= 1e-9 + 2e-7 * float(a_rgb.abs().max())
+    if with_depth:
+        assert torch.equal(b_d, a_d) and float(a_d.abs().max()) > 0.0
+    else:
+        assert float((b_d - 5.0).abs().max()) == 0.0                   # untouched
