@@ -257,12 +257,14 @@ int qed_ssim_bwd(int32_t height, int32_t width, int32_t channels, const float* p
  * (model.py:296-297) -> v_render[H,W,channels] / v_alpha[H,W], depth-L1 gradient (model.py:87-116, :304-306) into channel
  * 3 -- instead of handing v_pred to a second pass that re-reads render, alpha and the ground truth (116 MB at 1080p).
  * losses[0..2] as qed_loss_grad with extra_sum = ssim_sum, extra_scale = ssim_scale, extra_offset = ssim_offset (=
- * ssim_lambda); sums is qed_loss_reduce's workspace (which also zeroes the slots this pass adds its loss sums to). */
+ * ssim_lambda); sums is qed_loss_reduce's workspace (which also zeroes the slots this pass adds its loss sums to).
+ * zero_buf (may be NULL; 16-byte aligned, zero_floats a multiple of 4): a buffer the same launch zeroes -- the vsplat
+ * accumulator qed_composite_bwd needs zeroed, which saves the fill launch in front of that kernel. */
 int qed_loss_grad_ssim(int32_t height, int32_t width, int32_t channels, const float* render, const float* alpha,
                        const float* background, const float* gt_rgb, const float* gt_depth, const float* mask,
                        const float* maps, float* sums, float rgb_weight, float depth_lambda, float ssim_scale,
                        float* v_render, float* v_alpha, float* losses, const float* ssim_sum,
-                       int32_t ssim_sum_n, float ssim_offset, void* stream);
+                       int32_t ssim_sum_n, float ssim_offset, float* zero_buf, int64_t zero_floats, void* stream);
 
 /* qed_ssim_bwd and qed_image_losses_bwd in ONE launch (get_loss_dict's backward): v_rgb[H,W,3] = g_main[0] * d main_loss /
  * d rgb (the L1 term joins the SSIM term inside the SSIM backward pass, which has the pixel's colours at hand) and

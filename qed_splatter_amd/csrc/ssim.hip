@@ -264,6 +264,8 @@ struct LossFuse {
     float* v_render;        // FUSE 3/4 outputs
     float* v_alpha;
     float* v_depth;         // FUSE 1 output (may be NULL)
+    float4* zero_buf;       // FUSE 3/4: a buffer this launch also zeroes (the compositing backward's per-Gaussian
+    long long zero_vec;     //   accumulator: saves the fill launch in front of it), as 16-byte vectors; may be NULL
 };
 
 template <bool COMPOSITE, bool MASKED, class T, int FUSE = 0>
@@ -348,6 +350,14 @@ ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
         } else if constexpr (FUSE == 1) {
             const float nvalid = lf.sums[2];
             w_d = nvalid > 0.f ? (lf.g_depth != nullptr ? lf.g_depth[0] : 0.f) * lf.depth_lambda / nvalid : 0.f;
+        }
+    }
+    if constexpr (FUSE >= 3) {
+        // this workgroup's slice of the buffer to zero: stores only, issued beside the loads of the first pass
+        if (lf.zero_buf != nullptr) {
+            const long long per = (lf.zero_vec + gridDim.x - 1) / gridDim.x;
+            const long long lo = (long long)blockIdx.x * per, hi = lo + per < lf.zero_vec ? lo + per : lf.zero_vec;
+            for (long long i = lo + tid; i < hi; i += 256) lf.zero_buf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     float r0[CB], r1[CB];            // channels 0 and 1 wait for channel 2: one 12-byte store per pixel
@@ -551,17 +561,20 @@ extern "C" int qed_loss_grad_ssim(int32_t height, int32_t width, int32_t channel
                                   const float* background, const float* gt_rgb, const float* gt_depth, const float* mask,
                                   const float* maps, float* sums, float rgb_weight, float depth_lambda, float ssim_scale,
                                   float* v_render, float* v_alpha, float* losses, const float* ssim_sum,
-                                  int32_t ssim_sum_n, float ssim_offset, void* stream) {
+                                  int32_t ssim_sum_n, float ssim_offset, float* zero_buf, int64_t zero_floats,
+                                  void* stream) {
     QED_REQUIRE(height > kHalo && width > kHalo, "image smaller than the 11 x 11 SSIM window");
     QED_REQUIRE(channels == 3 || channels == 4, "channels must be 3 (RGB) or 4 (RGB+D)");
     QED_REQUIRE(render && alpha && background && gt_rgb && maps && sums && v_render && v_alpha && losses && ssim_sum,
                 "null buffers");
     QED_REQUIRE(channels == 3 || gt_depth, "gt_depth required with a depth channel");
+    QED_REQUIRE(zero_floats >= 0 && (zero_floats == 0 || zero_buf) && zero_floats % 4 == 0 && ((uintptr_t)zero_buf & 15) == 0,
+                "zero_buf: 16-byte aligned, a multiple of 4 floats");
     hipStream_t st = (hipStream_t)stream;
     const int n_pix = height * width;
     const unsigned n_loss = loss_reduce_grid(n_pix);
     const LossFuse lf{nullptr, gt_depth, sums, (int)n_loss, rgb_weight / (3.f * (float)n_pix), depth_lambda, nullptr, nullptr,
-                      v_render, v_alpha, nullptr};
+                      v_render, v_alpha, nullptr, zero_floats > 0 ? (float4*)zero_buf : nullptr, zero_floats / 4};
     const dim3 grid(((width + TileB::TW - 1) / TileB::TW) * ((height + TileB::TH - 1) / TileB::TH));
 #define QED_SSIM_BWD_FUSED(MASK, CHN)                                                                                \
     hipLaunchKernelGGL((ssim_bwd_kernel<true, MASK, TileB, CHN>), grid, dim3(256), 0, st, height, width, CHN, render, \
@@ -587,7 +600,7 @@ extern "C" int qed_image_losses_ssim_bwd(int32_t height, int32_t width, const fl
     hipStream_t st = (hipStream_t)stream;
     const int n_pix = height * width;
     const LossFuse lf{depth, gt_depth, const_cast<float*>(sums), 0, rgb_weight / (3.f * (float)n_pix), depth_lambda, g_main,
-                      g_depth, nullptr, nullptr, v_depth};
+                      g_depth, nullptr, nullptr, v_depth, nullptr, 0};
     const dim3 grid(((width + TileB::TW - 1) / TileB::TW) * ((height + TileB::TH - 1) / TileB::TH));
     if (mask)
         hipLaunchKernelGGL((ssim_bwd_kernel<false, true, TileB, 1>), grid, dim3(256), 0, st, height, width, 3, rgb,

@@ -324,7 +324,8 @@ class _FusedImageLoss(torch.autograd.Function):
     (model.py:295-297, 304-306, 87-116 and the parent's main loss behind :83-85)."""
 
     @staticmethod
-    def forward(ctx, render, alpha, background, gt_rgb, gt_depth, mask, ssim_lambda, depth_lambda):
+    def forward(ctx, render, alpha, background, gt_rgb, gt_depth, mask, ssim_lambda, depth_lambda, vsplat_holder=None,
+                vsplat_rows=0):
         lib = L.load()
         ctx.set_materialize_grads(False)
         C, H, W, CH = render.shape
@@ -346,11 +347,18 @@ class _FusedImageLoss(torch.autograd.Function):
             ssum = torch.empty(lib.qed_ssim_sum_floats(H, W), dtype=torch.float32, device=dev)
             L.check(lib.qed_ssim_fwd(H, W, CH, L.ptr(render), L.ptr(alpha), L.ptr(background), L.ptr(gt_rgb),
                                      L.ptr(mask), L.ptr(maps), L.ptr(ssum), st), "qed_ssim_fwd")
+            # the same launch zeroes the accumulator the compositing backward will add into (no fill launch there)
+            vsplat = None
+            if vsplat_holder is not None and vsplat_rows > 0:
+                vsplat = torch.empty(vsplat_rows, L.VSPLAT_FLOATS, dtype=torch.float32, device=dev)
             L.check(lib.qed_loss_grad_ssim(H, W, CH, L.ptr(render), L.ptr(alpha), L.ptr(background), L.ptr(gt_rgb),
                                            L.ptr(gt_depth), L.ptr(mask), L.ptr(maps), L.ptr(sums), 1.0 - ssim_lambda,
                                            depth_lambda, -ssim_lambda / n_out, L.ptr(v_render), L.ptr(v_alpha),
-                                           L.ptr(losses), L.ptr(ssum), ssum.numel(), ssim_lambda, st),
-                    "qed_loss_grad_ssim")
+                                           L.ptr(losses), L.ptr(ssum), ssum.numel(), ssim_lambda, L.ptr(vsplat),
+                                           vsplat.numel() if vsplat is not None else 0, st), "qed_loss_grad_ssim")
+            if vsplat is not None:
+                del vsplat_holder[:]
+                vsplat_holder.append(vsplat)
         else:
             L.check(lib.qed_loss_grad(*args, L.ptr(sums), 1.0, depth_lambda, L.ptr(v_render), L.ptr(v_alpha),
                                       L.ptr(losses), None, None, 0, 0.0, 0.0, st), "qed_loss_grad")
@@ -369,7 +377,7 @@ class _FusedImageLoss(torch.autograd.Function):
         # backward_fused() and needs no scaling pass; anything else (a weighted loss, a GradScaler) is applied
         if v_total.data_ptr() != _unit_grad(v_total.device).data_ptr():
             v_render, v_alpha = v_render * v_total, v_alpha * v_total
-        return v_render, v_alpha, None, None, None, None, None, None
+        return v_render, v_alpha, None, None, None, None, None, None, None, None
 
 
 class QEDSplatterModel(nn.Module):
@@ -819,16 +827,18 @@ class QEDSplatterModel(nn.Module):
         gt_rgb = _f32_image(gt_rgb[..., :3] if gt_rgb.shape[-1] > 3 else gt_rgb, H * W * 3, "batch['image']", self.device)
         gt_depth = _f32_image(self.get_gt_img(batch["depth_image"]), H * W, "batch['depth_image']", self.device)
         mask = self._loss_mask(batch, (H, W))
+        holder: list = []         # (the fused loss launch leaves the compositing backward's zeroed accumulator here)
         render, alpha, self.info = rasterization(
             means=self.means, quats=self.quats, scales=self.scales, opacities=self.opacities, colors=colors,
             viewmats=viewmat, Ks=K, width=W, height=H, tile_size=16, packed=False, near_plane=0.01, far_plane=1e10,
             render_mode="RGB+D", sh_degree=deg, sparse_grad=False, absgrad=True,
-            rasterize_mode=cfg.rasterize_mode, _flags=flags, _sh_rest=sh_rest, _sync=sync)
+            rasterize_mode=cfg.rasterize_mode, _flags=flags, _sh_rest=sh_rest, _sync=sync, _vsplat_holder=holder)
         self.xys = self.info["means2d"]
         self.radii = self.info["radii"][0]
         self.last_viewmat, self.last_sh_degree = viewmat, deg
         total, parts = _FusedImageLoss.apply(render, alpha, bg.contiguous(), gt_rgb, gt_depth, mask,
-                                             float(cfg.ssim_lambda), cfg.depth_lambda)
+                                             float(cfg.ssim_lambda), cfg.depth_lambda,
+                                             holder if torch.is_grad_enabled() else None, self.num_points)
         return {"loss": total, "main_loss": parts[0], "depth_loss": parts[1]}
 
 

@@ -300,9 +300,10 @@ def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, til
 class _Composite(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means2d, conics, rgb, opac, depths, splats, flatten_ids, offsets, backgrounds, width, height,
-                tile_w, tile_h, channels, absgrad):
+                tile_w, tile_h, channels, absgrad, vsplat_holder=None):
         lib = L.load()
         ctx.set_materialize_grads(False)
+        ctx.vsplat_holder = vsplat_holder
         C, N = opac.shape
         dev = opac.device
         render = torch.empty(C, height, width, channels, dtype=torch.float32, device=dev)
@@ -329,7 +330,12 @@ class _Composite(torch.autograd.Function):
         v_alpha = _f32c(v_alpha, "v_alpha") if v_alpha is not None else torch.zeros(
             C, height, width, 1, dtype=torch.float32, device=dev)
         R = L.VSPLAT_FLOATS
-        vsplat = torch.zeros(C * N, R, dtype=torch.float32, device=dev)
+        # the fused loss launch may already have zeroed an accumulator for this backward pass (model.fused_loss hands it
+        # over through the holder; taken once -- a second backward through a retained graph makes its own)
+        holder = ctx.vsplat_holder
+        vsplat = holder.pop() if holder else None
+        if vsplat is None or vsplat.shape != (C * N, R) or vsplat.device != dev or vsplat.dtype != torch.float32:
+            vsplat = torch.zeros(C * N, R, dtype=torch.float32, device=dev)
         L.check(lib.qed_composite_bwd(C, N, L.ptr(splats), L.ptr(flatten_ids), L.ptr(offsets), width, height, tile_w,
                                       tile_h, channels, L.ptr(bg), L.ptr(alpha), L.ptr(last_ids), L.ptr(v_render),
                                       L.ptr(v_alpha), L.ptr(vsplat), L.composite_launch_flags(), _stream()),
@@ -344,7 +350,7 @@ class _Composite(torch.autograd.Function):
         if absgrad:
             # gsplat convention (absgrad=True at model.py:284): the densifier reads means2d.absgrad
             ctx.means2d_ref.absgrad = v3[..., 2:4]
-        return (v_means2d, v_conics, v_rgb, v_opac, v_depths) + (None,) * 10
+        return (v_means2d, v_conics, v_rgb, v_opac, v_depths) + (None,) * 11
 
 
 # ==================================================================================================
@@ -356,7 +362,7 @@ def rasterization(
     far_plane: float = 1e10, render_mode: str = "RGB", sh_degree: Optional[int] = None, sparse_grad: bool = False,
     absgrad: bool = False, rasterize_mode: str = "classic", radius_clip: float = 0.0, eps2d: float = 0.3,
     backgrounds: Optional[Tensor] = None, _flags: int = 0, _sh_rest: Optional[Tensor] = None,
-    _sync: bool = True,
+    _sync: bool = True, _vsplat_holder: Optional[list] = None,
 ) -> Tuple[Tensor, Tensor, Dict]:
     """Same call surface as the reference's call (model.py:267-288).
 
@@ -419,7 +425,7 @@ def rasterization(
                                                        tile_w, tile_h, sync=_sync, splats=splats if use_packed else None)
     render, alpha, last_ids = _Composite.apply(means2d, conics, rgb, opac, depths if channels == 4 else None, splats,
                                                flatten_ids, offsets, backgrounds, int(width), int(height), tile_w,
-                                               tile_h, channels, bool(absgrad))
+                                               tile_h, channels, bool(absgrad), _vsplat_holder)
     info = {
         "camera_ids": None, "gaussian_ids": None,
         "radii": radii, "means2d": means2d, "depths": depths, "conics": conics, "opacities": opac,

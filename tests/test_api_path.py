@@ -492,6 +492,8 @@ def test_fused_ssim_backward_and_loss_gradient_equals_the_two_passes(cuda, lib, 
                              L.ptr(ssum), st), "qed_ssim_fwd")
     args = (H * W, ch, L.ptr(render), L.ptr(alpha), L.ptr(bg), L.ptr(gt), L.ptr(gd), L.ptr(mask))
     out = []
+    zall = torch.full((16 * 1237 + 64,), 3.0, device=cuda)             # the buffer the fused launch also zeroes + a guard
+    zbuf, guard = zall[: 16 * 1237], zall[16 * 1237:]
     for fused in (False, True):
         sums = torch.full((L.LOSS_SUMS_FLOATS,), float("nan"), device=cuda)
         losses = torch.empty(3, device=cuda)
@@ -500,8 +502,10 @@ def test_fused_ssim_backward_and_loss_gradient_equals_the_two_passes(cuda, lib, 
         if fused:
             L.check(lib.qed_loss_grad_ssim(H, W, ch, L.ptr(render), L.ptr(alpha), L.ptr(bg), L.ptr(gt), L.ptr(gd),
                                            L.ptr(mask), L.ptr(maps), L.ptr(sums), 1.0 - lam, dl, -lam / n_out, L.ptr(v_r),
-                                           L.ptr(v_a), L.ptr(losses), L.ptr(ssum), ssum.numel(), lam, st),
-                    "qed_loss_grad_ssim")
+                                           L.ptr(v_a), L.ptr(losses), L.ptr(ssum), ssum.numel(), lam, L.ptr(zbuf),
+                                           zbuf.numel(), st), "qed_loss_grad_ssim")
+            torch.cuda.synchronize()
+            assert float(zbuf.abs().max()) == 0.0 and float(guard.min()) == 3.0     # zeroed, and nothing beyond it
         else:
             v_rgb = torch.empty(H, W, 3, device=cuda)
             L.check(lib.qed_ssim_bwd(H, W, ch, L.ptr(render), L.ptr(alpha), L.ptr(bg), L.ptr(gt), L.ptr(mask), L.ptr(maps),
