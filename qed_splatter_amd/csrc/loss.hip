@@ -605,8 +605,8 @@ static unsigned stream_grid(long long n_items, long long cap = 2048) {
     if (g < 1) g = 1;
     return (unsigned)g;
 }
-// the loss kernels end with same-address atomics (one per workgroup): keep the grid at 2 per CU
-// both loss passes use the same grid: pass 2 reads pass 1's per-workgroup partials by index
+// both loss passes use the same grid (at most kLossMaxGrid workgroups: one slot of per-workgroup partials each):
+// pass 2 reads pass 1's partials by index
 static unsigned reduce_grid(long long n_items) { return stream_grid(n_items, kLossMaxGrid); }
 
 extern "C" int qed_loss_reduce(int32_t n_pix, int32_t channels, const float* render, const float* alpha,
