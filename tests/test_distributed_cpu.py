@@ -1,6 +1,6 @@
 """World-size-2 `gloo` tests of the camera-sharded data-parallel path on CPU: the
-flat-gradient all-reduce, replica consistency after the optimiser step, and the per-rank scene
-sharding bench.py uses."""
+flat-gradient all-reduce, the compact exchange (blocking and with both collectives left in flight), replica
+consistency after the optimiser step, and the per-rank scene sharding bench.py uses."""
 from __future__ import annotations
 
 import os
@@ -62,6 +62,39 @@ def _worker(rank, world, port, q):
         visits = 3 * sum(range(1, world + 1))
         ok = ok and float(dz.vis_counts[0]) == 1.0 + visits and abs(float(dz.max_2Dsize[0]) - 0.01 * world) < 1e-9
         ok = ok and abs(float(dz.xys_grad_norm[0]) - 0.5 * sum(range(1, world + 1))) < 1e-6
+        # compact exchange, both collectives left in flight (what bench.py runs for N > 1) == the blocking form:
+        # averaged geometry gradients, one (colour gradients + view matrix) message per rank, scale 1 / world
+        from qed_splatter_amd.parallel import exchange_grads_compact, exchange_grads_compact_begin
+        results = []
+        for overlapped in (False, True):
+            m2 = QEDSplatterModel(None, **{k: sc[k] for k in PARAM_NAMES})
+            flat2 = (torch.arange(total, dtype=torch.float32) + 1.0) * (rank + 1)
+            off = 0
+            for name in m2.group_names:
+                p = m2.gauss_params[name]
+                p.grad = flat2[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+            m2.last_compact = True
+            m2.last_viewmat = torch.eye(4).reshape(1, 4, 4) * (rank + 2)
+            if overlapped:
+                ex = exchange_grads_compact_begin(m2, world)
+                ex.wait_views()
+                ex.wait_geometry()
+                ex.wait_geometry()                                   # idempotent
+            else:
+                exchange_grads_compact(m2, world, rebuild=False)
+            n_views, vms, vm_stride, v_views, view_stride, scale = m2.sh_views
+            results.append((m2.flat_grad().clone(), v_views.clone(), n_views, vm_stride, view_stride, scale))
+        b = m.group_begin
+        nv = b[5] - b[4]
+        mean_w = sum(range(1, world + 1)) / world
+        for g2, recv, n_views, vm_stride, view_stride, scale in results:
+            ok = ok and n_views == world and vm_stride == view_stride == nv + 16 and scale == 1.0 / world
+            ok = ok and torch.allclose(g2[:b[4]], (torch.arange(b[4], dtype=torch.float32) + 1.0) * mean_w)
+            for r in range(world):
+                ok = ok and torch.equal(recv[r, :nv], (torch.arange(b[4], b[5], dtype=torch.float32) + 1.0) * (r + 1))
+                ok = ok and torch.equal(recv[r, nv:], (torch.eye(4) * (r + 2)).reshape(-1))
+        ok = ok and torch.equal(results[0][0][:b[4]], results[1][0][:b[4]]) and torch.equal(results[0][1], results[1][1])
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
