@@ -86,7 +86,12 @@ template <bool COMPOSITE, bool MASKED, class T>
 #ifndef QED_SSIM_FWD_WAVES
 #define QED_SSIM_FWD_WAVES 4
 #endif
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QED_SSIM_FWD_WAVES, QED_SSIM_FWD_WAVES)))
+#ifndef QED_SSIM_FWD_PLAIN_WAVES
+#define QED_SSIM_FWD_PLAIN_WAVES 3   // the plain-image form spills 16-18 registers at four waves per SIMD: 60 -> 53 us at three
+#endif
+__global__ void __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(COMPOSITE ? QED_SSIM_FWD_WAVES : QED_SSIM_FWD_PLAIN_WAVES,
+                                   COMPOSITE ? QED_SSIM_FWD_WAVES : QED_SSIM_FWD_PLAIN_WAVES)))
 ssim_fwd_kernel(int H, int W, int channels, const float* __restrict__ pred, const float* __restrict__ alpha,
                 const float* __restrict__ bg, const float* __restrict__ gt, const float* __restrict__ mask,
                 float* __restrict__ maps, float* __restrict__ ssim_sum) {

@@ -30,3 +30,13 @@ for it in range(iters):
     ev[2].record()
     torch.cuda.synchronize()
     print(f"fwd {ev[0].elapsed_time(ev[1]) * 1e3:.1f} us  bwd {ev[1].elapsed_time(ev[2]) * 1e3:.1f} us", flush=True)
+# the plain-image forms (get_loss_dict / the rgb_ssim metric): no compositing, [H,W,3] images
+rgb = torch.rand(H, W, 3, device=dev)
+for it in range(iters):
+    ev[0].record()
+    L.check(lib.qed_ssim_fwd(H, W, 3, L.ptr(rgb), None, None, L.ptr(gt), None, L.ptr(maps), L.ptr(ssum), st), "f")
+    ev[1].record()
+    L.check(lib.qed_ssim_bwd(H, W, 3, L.ptr(rgb), None, None, L.ptr(gt), None, L.ptr(maps), -1e-7, None, L.ptr(v), st), "b")
+    ev[2].record()
+    torch.cuda.synchronize()
+    print(f"plain images: fwd {ev[0].elapsed_time(ev[1]) * 1e3:.1f} us  bwd {ev[1].elapsed_time(ev[2]) * 1e3:.1f} us", flush=True)
