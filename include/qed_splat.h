@@ -52,6 +52,10 @@ extern "C" {
 #define QED_F_TIGHT_TILES 32u   /* list only the tiles of the 3-sigma square that can reach alpha >= 1/255:
                                    tiles_per_gauss / the sorted list become subsets of gsplat's, images and
                                    gradients are unchanged (pass `splats` to qed_bin_tiles) */
+#define QED_F_CAMERA_C2W 128u   /* qed_project_fwd: `viewmats` holds camera-to-world matrices c2w[C,3,4] (OpenGL) and `Ks`
+                                   the intrinsics [C,4] = (fx, fy, cx, cy); the kernel derives view matrix and K itself
+                                   (get_viewmat, model.py:22-38: what qed_camera_setup does in a launch of its own) and
+                                   writes them to viewmats_out[C,4,4] / Ks_out[C,3,3] for the kernels that follow */
 
 int qed_version(void);
 const char* qed_last_error(void);
@@ -91,7 +95,7 @@ int qed_project_fwd(int32_t N, int32_t C, const float* means, const float* quats
                     float near_plane, float far_plane, float radius_clip, uint32_t flags,
                     int32_t* radii, float* means2d, float* depths, float* conics, float* opac_out,
                     float* colors_out, float* splats, int32_t* tiles_per_gauss, int32_t* block_sums,
-                    void* stream);
+                    float* viewmats_out, float* Ks_out, void* stream);
 
 /* Backward of qed_project_fwd (autograd backward of the projection + SH part of model.py:267-288).
  * vsplat[C*N][16] = packed gradient row written by qed_composite_bwd:

@@ -26,7 +26,7 @@ SIGNATURES = {
     "qed_last_error": (C.c_char_p, []),
     "qed_camera_setup": (C.c_int, [_I, _P, _P, _P, _P, _P]),
     "qed_project_fwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _F, _F, _F,
-                                  _F, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+                                  _F, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qed_project_bwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _I, _F, _U, _P, _P, _P,
                                   _P, _P, _P, _P, _I, _P, _I, _P, _P]),
     "qed_isect_scan": (C.c_int, [_P, _I, _P, _P, _L, _P, _P]),
@@ -77,6 +77,7 @@ F_LOGIT_OPAC = 4
 F_DEPTH_CHANNEL = 8
 F_SIGMOID_COLORS = 16
 F_TIGHT_TILES = 32
+F_CAMERA_C2W = 128
 F_SH_GRAD_COMPACT = 64
 SPLAT_FLOATS = 12
 VSPLAT_FLOATS = 16

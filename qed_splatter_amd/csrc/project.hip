@@ -36,6 +36,46 @@ __device__ __forceinline__ Cam load_cam(const float* __restrict__ viewmats, cons
     return cam;
 }
 
+// QED_F_CAMERA_C2W: the same camera from c2w[C,3,4] (OpenGL) and intrinsics[C,4] = (fx, fy, cx, cy) -- get_viewmat
+// (model.py:22-38: flip the y/z columns of R, analytic rigid inverse) evaluated by every thread instead of a launch of
+// its own; `V_out` / `K_out` (non-NULL in ONE thread per camera) receive the view matrix and K for the later kernels.
+__device__ __forceinline__ Cam load_cam_c2w(const float* __restrict__ c2w, const float* __restrict__ intr, int c,
+                                            float* __restrict__ V_out, float* __restrict__ K_out) {
+    Cam cam;
+    const float* m = c2w + 12 * c;
+    float R[9], t[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        R[3 * i] = m[4 * i];
+        R[3 * i + 1] = -m[4 * i + 1];
+        R[3 * i + 2] = -m[4 * i + 2];
+        t[i] = m[4 * i + 3];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) cam.R[3 * i + j] = R[3 * j + i];                         // R^T
+        cam.t[i] = -(R[i] * t[0] + R[3 + i] * t[1] + R[6 + i] * t[2]);                       // -R^T t
+    }
+    cam.fx = intr[4 * c]; cam.fy = intr[4 * c + 1]; cam.cx = intr[4 * c + 2]; cam.cy = intr[4 * c + 3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)                          // as load_cam derives it from the view matrix (bit for bit)
+        cam.campos[j] = -(cam.R[0 + j] * cam.t[0] + cam.R[3 + j] * cam.t[1] + cam.R[6 + j] * cam.t[2]);
+    if (V_out != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) V_out[4 * i + j] = cam.R[3 * i + j];
+            V_out[4 * i + 3] = cam.t[i];
+        }
+        V_out[12] = 0.f; V_out[13] = 0.f; V_out[14] = 0.f; V_out[15] = 1.f;
+        K_out[0] = cam.fx; K_out[1] = 0.f; K_out[2] = cam.cx;
+        K_out[3] = 0.f; K_out[4] = cam.fy; K_out[5] = cam.cy;
+        K_out[6] = 0.f; K_out[7] = 0.f; K_out[8] = 1.f;
+    }
+    return cam;
+}
+
 // normalised wxyz quaternion -> rotation matrix (row major)
 __device__ __forceinline__ void quat_to_rotmat(float w, float x, float y, float z, float* R) {
     R[0] = 1.f - 2.f * (y * y + z * z); R[1] = 2.f * (x * y - w * z);       R[2] = 2.f * (x * z + w * y);
@@ -223,7 +263,7 @@ project_fwd_kernel(int N, int C, const float* __restrict__ means, const float* _
                    float radius_clip, unsigned flags, int* __restrict__ radii, float* __restrict__ means2d,
                    float* __restrict__ depths, float* __restrict__ conics, float* __restrict__ opac_out,
                    float* __restrict__ colors_out, float4* __restrict__ splats, int* __restrict__ tiles_per_gauss,
-                   int* __restrict__ block_sums) {
+                   int* __restrict__ block_sums, float* __restrict__ viewmats_out, float* __restrict__ Ks_out) {
     // slot = c * N + n ; 256 consecutive slots per block (block_sums granularity)
     const long long slot = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long total = (long long)C * N;
@@ -231,7 +271,9 @@ project_fwd_kernel(int N, int C, const float* __restrict__ means, const float* _
     if (slot < total) {
         const int c = ONE_CAM ? 0 : (int)(slot / N);
         const int n = (int)(slot - (long long)c * N);
-        const Cam cam = load_cam(viewmats, Ks, c);
+        const Cam cam = (flags & QED_F_CAMERA_C2W)
+                            ? load_cam_c2w(viewmats, Ks, c, n == 0 ? viewmats_out + 16 * c : nullptr, Ks_out + 9 * c)
+                            : load_cam(viewmats, Ks, c);
         float mean[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
         float q[4] = {quats[4 * n], quats[4 * n + 1], quats[4 * n + 2], quats[4 * n + 3]};
         float s[3] = {scales[3 * n], scales[3 * n + 1], scales[3 * n + 2]};
@@ -739,7 +781,8 @@ extern "C" int qed_project_fwd(int32_t N, int32_t C, const float* means, const f
                                int32_t width, int32_t height, int32_t tile_w, int32_t tile_h, float eps2d,
                                float near_plane, float far_plane, float radius_clip, uint32_t flags, int32_t* radii,
                                float* means2d, float* depths, float* conics, float* opac_out, float* colors_out,
-                               float* splats, int32_t* tiles_per_gauss, int32_t* block_sums, void* stream) {
+                               float* splats, int32_t* tiles_per_gauss, int32_t* block_sums, float* viewmats_out,
+                               float* Ks_out, void* stream) {
     QED_REQUIRE(N >= 0 && C >= 1, "N >= 0 and C >= 1 required");
     QED_REQUIRE(sh_degree <= 3, "SH degree > 3 unsupported (reference config uses sh_degree = 3)");
     QED_REQUIRE(width > 0 && height > 0 && tile_w > 0 && tile_h > 0, "bad image / tile extents");
@@ -749,13 +792,14 @@ extern "C" int qed_project_fwd(int32_t N, int32_t C, const float* means, const f
     QED_REQUIRE(sh_degree <= 0 || shN, "shN required for sh_degree > 0");
     QED_REQUIRE(radii && means2d && depths && conics && opac_out && colors_out && splats && tiles_per_gauss &&
                     block_sums, "null output");
+    QED_REQUIRE(!(flags & QED_F_CAMERA_C2W) || (viewmats_out && Ks_out), "QED_F_CAMERA_C2W needs viewmats_out and Ks_out");
     const long long total = (long long)C * N;
     const unsigned grid = (unsigned)((total + 255) / 256);
 #define QED_LAUNCH_PF(ONE)                                                                                           \
     hipLaunchKernelGGL(project_fwd_kernel<ONE>, dim3(grid), dim3(256), 0, (hipStream_t)stream, N, C, means, quats,   \
                        scales, opacities, sh0, sh0_stride, shN, shN_stride, sh_degree, viewmats, Ks, width, height,  \
                        tile_w, tile_h, eps2d, near_plane, far_plane, radius_clip, flags, radii, means2d, depths,     \
-                       conics, opac_out, colors_out, (float4*)splats, tiles_per_gauss, block_sums)
+                       conics, opac_out, colors_out, (float4*)splats, tiles_per_gauss, block_sums, viewmats_out, Ks_out)
     if (C == 1) QED_LAUNCH_PF(true);
     else QED_LAUNCH_PF(false);
 #undef QED_LAUNCH_PF

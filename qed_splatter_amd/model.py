@@ -596,15 +596,16 @@ class QEDSplatterModel(nn.Module):
         intr = getattr(camera, "intrinsics_fxfycxcy", None)
         if intr is not None and optimized_camera_to_world.dtype == torch.float32 \
                 and not optimized_camera_to_world.requires_grad and optimized_camera_to_world.is_cuda:
-            # get_viewmat + get_intrinsics_matrices in one launch (qed_camera_setup) instead of ~15 tiny eager ones
+            # get_viewmat + get_intrinsics_matrices inside the projection kernel (QED_F_CAMERA_C2W), which fills these
+            # two buffers for everything downstream -- instead of ~15 tiny eager launches, or one of qed_camera_setup
             C = optimized_camera_to_world.shape[0]
             viewmat = torch.empty(C, 4, 4, dtype=torch.float32, device=self.device)
             K = torch.empty(C, 3, 3, dtype=torch.float32, device=self.device)
-            L.check(L.load().qed_camera_setup(C, L.ptr(optimized_camera_to_world.contiguous()), L.ptr(intr()),
-                                              L.ptr(viewmat), L.ptr(K), _stream()), "qed_camera_setup")
+            cam_c2w = (optimized_camera_to_world.contiguous(), intr())
         else:
             viewmat = get_viewmat(optimized_camera_to_world)
             K = camera.get_intrinsics_matrices().to(self.device)
+            cam_c2w = None
         W, H = int(camera.width.item()), int(camera.height.item())
         self.last_size = (H, W)
         if camera_scale_fac != 1:
@@ -650,6 +651,7 @@ class QEDSplatterModel(nn.Module):
             _flags=flags,
             _sh_rest=sh_rest,
             _sync=not (self.config.async_intersection_count and self.training),
+            _c2w=cam_c2w,
         )
         self.last_compact = False
         if self.training and self.info["means2d"].requires_grad:              # model.py:289-290
@@ -790,15 +792,14 @@ class QEDSplatterModel(nn.Module):
         try:
             intr = getattr(camera, "intrinsics_fxfycxcy", None)
             if intr is not None and camera.camera_to_worlds.dtype == torch.float32 and camera.camera_to_worlds.is_cuda:
-                # a1 + a3 in one launch (qed_camera_setup) instead of ~15 tiny eager kernels
-                c2w = camera.camera_to_worlds.contiguous()
+                # a1 + a3 inside the projection kernel (QED_F_CAMERA_C2W): it fills viewmat / K for what follows
                 viewmat = torch.empty(1, 4, 4, dtype=torch.float32, device=self.device)
                 K = torch.empty(1, 3, 3, dtype=torch.float32, device=self.device)
-                L.check(L.load().qed_camera_setup(1, L.ptr(c2w), L.ptr(intr()), L.ptr(viewmat), L.ptr(K), _stream()),
-                        "qed_camera_setup")
+                cam_c2w = (camera.camera_to_worlds.contiguous(), intr())
             else:
                 viewmat = get_viewmat(camera.camera_to_worlds).to(self.device, torch.float32)
                 K = camera.get_intrinsics_matrices().to(self.device, torch.float32)
+                cam_c2w = None
             W, H = int(camera.width[0]), int(camera.height[0])
         finally:
             if d > 1:
@@ -832,7 +833,8 @@ class QEDSplatterModel(nn.Module):
             means=self.means, quats=self.quats, scales=self.scales, opacities=self.opacities, colors=colors,
             viewmats=viewmat, Ks=K, width=W, height=H, tile_size=16, packed=False, near_plane=0.01, far_plane=1e10,
             render_mode="RGB+D", sh_degree=deg, sparse_grad=False, absgrad=True,
-            rasterize_mode=cfg.rasterize_mode, _flags=flags, _sh_rest=sh_rest, _sync=sync, _vsplat_holder=holder)
+            rasterize_mode=cfg.rasterize_mode, _flags=flags, _sh_rest=sh_rest, _sync=sync, _vsplat_holder=holder,
+            _c2w=cam_c2w)
         self.xys = self.info["means2d"]
         self.radii = self.info["radii"][0]
         self.last_viewmat, self.last_sh_degree = viewmat, deg

@@ -102,7 +102,7 @@ def _workspace(device) -> _Workspace:
 class _ProjectSH(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, quats, scales, opacities, sh0, shN, viewmats, Ks, width, height, tile_w, tile_h,
-                sh_degree, flags, eps2d, near_plane, far_plane, radius_clip):
+                sh_degree, flags, eps2d, near_plane, far_plane, radius_clip, c2w=None, intr=None):
         lib = L.load()
         # undefined output gradients arrive as None instead of freshly zero-filled tensors (autograd would
         # otherwise fill one per output per step, the 24 MB splat record included)
@@ -115,6 +115,14 @@ class _ProjectSH(torch.autograd.Function):
         sh0 = _f32c(sh0, "colors")
         shN = _f32c(shN, "colors") if shN is not None else None
         viewmats, Ks = _f32c(viewmats, "viewmats"), _f32c(Ks, "Ks")
+        cam_in = (viewmats, Ks)
+        if c2w is not None:
+            # QED_F_CAMERA_C2W: the kernel derives the view matrices from the camera-to-world matrices itself and fills
+            # `viewmats` / `Ks` (the caller's uninitialised buffers) for the backward pass and everything downstream
+            assert c2w.dtype == torch.float32 and c2w.is_contiguous() and tuple(c2w.shape) == (C, 3, 4)
+            assert intr.dtype == torch.float32 and intr.is_contiguous() and tuple(intr.shape) == (C, 4)
+            assert not viewmats.requires_grad, "no gradient reaches camera-to-world matrices through this path"
+            cam_in, flags = (c2w, intr), flags | L.F_CAMERA_C2W
         sh0_stride = sh0.stride(0) if sh0.dim() > 1 else 3
         # a [N,K,3] colours tensor is passed as (colors, 3K, colors + 3, 3K) -- no copy
         if sh0.dim() == 3:
@@ -140,10 +148,12 @@ class _ProjectSH(torch.autograd.Function):
         block_sums = torch.empty(max(n_blocks, 1), dtype=torch.int32, device=dev)
         L.check(lib.qed_project_fwd(
             N, C, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opacities), L.ptr(sh0_flat), sh0_stride,
-            shN_ptr, shN_stride, sh_degree, L.ptr(viewmats), L.ptr(Ks), width, height, tile_w, tile_h, eps2d,
+            shN_ptr, shN_stride, sh_degree, L.ptr(cam_in[0]), L.ptr(cam_in[1]), width, height, tile_w, tile_h, eps2d,
             near_plane, far_plane, radius_clip, flags, L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics),
-            L.ptr(opac), L.ptr(rgb), L.ptr(splats), L.ptr(tiles_per_gauss), L.ptr(block_sums), _stream()),
+            L.ptr(opac), L.ptr(rgb), L.ptr(splats), L.ptr(tiles_per_gauss), L.ptr(block_sums),
+            L.ptr(viewmats) if c2w is not None else None, L.ptr(Ks) if c2w is not None else None, _stream()),
             "qed_project_fwd")
+        flags &= ~L.F_CAMERA_C2W                  # (the backward pass reads the view matrices the kernel wrote)
         ctx.save_for_backward(means, quats, scales, opacities, sh0, shN, viewmats, Ks, radii)
         ctx.meta = (N, C, width, height, sh_degree, flags, eps2d, sh0_stride, shN_stride)
         ctx.opac_shape = opac_shape
@@ -195,7 +205,7 @@ class _ProjectSH(torch.autograd.Function):
             L.ptr(vsplat), L.ptr(v_means), L.ptr(v_quats), L.ptr(v_scales), L.ptr(v_opacities), v_sh0_ptr,
             v_sh0_stride, v_shN_ptr, v_shN_stride, L.ptr(v_viewmats), _stream()), "qed_project_bwd")
         v_opacities = v_opacities.view(ctx.opac_shape)
-        return (v_means, v_quats, v_scales, v_opacities, v_sh0, v_shN, v_viewmats, None) + (None,) * 10
+        return (v_means, v_quats, v_scales, v_opacities, v_sh0, v_shN, v_viewmats, None) + (None,) * 12
 
 
 _VSPLAT_REGISTRY: "weakref.WeakValueDictionary[int, Tensor]" = weakref.WeakValueDictionary()
@@ -362,7 +372,7 @@ def rasterization(
     far_plane: float = 1e10, render_mode: str = "RGB", sh_degree: Optional[int] = None, sparse_grad: bool = False,
     absgrad: bool = False, rasterize_mode: str = "classic", radius_clip: float = 0.0, eps2d: float = 0.3,
     backgrounds: Optional[Tensor] = None, _flags: int = 0, _sh_rest: Optional[Tensor] = None,
-    _sync: bool = True, _vsplat_holder: Optional[list] = None,
+    _sync: bool = True, _vsplat_holder: Optional[list] = None, _c2w: Optional[Tuple[Tensor, Tensor]] = None,
 ) -> Tuple[Tensor, Tensor, Dict]:
     """Same call surface as the reference's call (model.py:267-288).
 
@@ -414,7 +424,8 @@ def rasterization(
 
     means2d, depths, conics, opac, rgb, radii, splats, tiles_per_gauss, block_sums = _ProjectSH.apply(
         means, quats, scales, opacities, sh0, shN, viewmats, Ks, int(width), int(height), tile_w, tile_h, deg, flags,
-        float(eps2d), float(near_plane), float(far_plane), float(radius_clip))
+        float(eps2d), float(near_plane), float(far_plane), float(radius_clip),
+        *(_c2w if _c2w is not None else (None, None)))
 
     # the packed tile rectangles of the records save the emit pass a recomputation; with F_TIGHT_TILES they
     # are the only place the (smaller) rectangles exist

@@ -170,6 +170,55 @@ def test_reference_viewmat_kats_through_camera_setup(cuda, lib):
     assert K0.tolist() == [[500.0, 0.0, 320.0], [0.0, 510.0, 240.0], [0.0, 0.0, 1.0]]
 
 
+def test_projection_derives_the_view_matrix_itself(cuda, lib):
+    """QED_F_CAMERA_C2W: rasterization(..., _c2w=(camera-to-world, intrinsics)) -- get_viewmat inside the projection kernel
+    -- against the same call with view matrices from qed_camera_setup, for the six random rigid poses of the reference's
+    known answers at once (C = 6): the view matrices it leaves behind match the reference's to 2 ulp of the translation,
+    everything projected from them agrees to fp32 rounding, the integer outputs exactly."""
+    from qed_splatter_amd import _lib as L
+    from qed_splatter_amd.rasterization import rasterization
+    kats = np.load(os.path.join(GOLD, "reference_kats.npz"))
+    c2w = torch.from_numpy(kats["viewmat_c2w"]).float()
+    want = torch.from_numpy(kats["viewmat_out"]).float()
+    C = c2w.shape[0]
+    # look at the origin region from a few units away so that the random poses see something
+    w, h, n = 96, 64, 1500
+    sc = scene(n, w, h, seed=31)
+    g = torch.Generator().manual_seed(3)
+    means = (torch.rand(n, 3, generator=g) - 0.5) * 8.0
+    c2w = c2w.clone()
+    c2w[:, :3, 3] = c2w[:, :3, 2] * 6.0                    # camera on its own viewing axis (OpenGL: looks down -z)
+    c2w = c2w.to(cuda).contiguous()
+    intr = torch.tensor([[80.0, 82.0, w / 2, h / 2]] * C, device=cuda)
+    vm_ref = torch.empty(C, 4, 4, device=cuda)
+    K_ref = torch.empty(C, 3, 3, device=cuda)
+    L.check(lib.qed_camera_setup(C, L.ptr(c2w), L.ptr(intr), L.ptr(vm_ref), L.ptr(K_ref),
+                                 torch.cuda.current_stream().cuda_stream), "qed_camera_setup")
+    kw = dict(means=means.to(cuda), quats=sc["quats"].to(cuda), scales=sc["scales"].exp().to(cuda),
+              opacities=torch.sigmoid(sc["opacities"]).reshape(-1).to(cuda),
+              colors=torch.cat([sc["features_dc"][:, None], sc["features_rest"]], 1).to(cuda), width=w, height=h,
+              sh_degree=3, render_mode="RGB+D")
+    r0, a0, i0 = rasterization(viewmats=vm_ref, Ks=K_ref, **kw)
+    vm, Ks = torch.full((C, 4, 4), 7.0, device=cuda), torch.full((C, 3, 3), 7.0, device=cuda)
+    r1, a1, i1 = rasterization(viewmats=vm, Ks=Ks, _c2w=(c2w, intr), **kw)
+    torch.cuda.synchronize()
+    assert int(i0["n_isects"]) > 1000
+    assert torch.equal(Ks, K_ref)
+    assert torch.equal(vm[:, :3, :3], vm_ref[:, :3, :3]) and torch.equal(vm[:, 3], vm_ref[:, 3])
+    scale = float(c2w[:, :3, 3].abs().max())
+    assert float((vm[:, :3, 3] - vm_ref[:, :3, 3]).abs().max()) <= 2 * np.spacing(np.float32(scale)) * 3
+    same_t = torch.equal(vm, vm_ref)
+    for k in ("radii", "tiles_per_gauss"):
+        assert same_t is False or torch.equal(i1[k], i0[k])
+        assert float((i1[k] != i0[k]).float().mean()) < 2e-3            # (a rounding-level shift can move a tile edge)
+    assert_close(i1["means2d"], i0["means2d"], 1e-5, "means2d")
+    assert_close(i1["depths"], i0["depths"], 1e-5, "depths")
+    if same_t:
+        assert torch.equal(r1, r0) and torch.equal(a1, a0)
+    else:
+        assert float((r1 - r0).abs().max()) < 5e-3 and float((a1 - a0).abs().max()) < 5e-3
+
+
 # ---- parent-class semantics (SURVEY a13) -----------------------------------------------------------------------------
 def test_masked_rgb_loss_api_fused_and_oracle_agree(cuda):
     """The mask multiplies BOTH images before L1 and SSIM (parent) and both depths (model.py:93-97): API route, fused
