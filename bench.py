@@ -332,10 +332,11 @@ def main():
     if use_graph:
         from qed_splatter_amd.graph import GraphedTrainStep
 
-        def fwd_bwd():
+        def fwd_bwd(tick_for=None):
             for p in model.parameters():
                 p.grad = None
-            losses = model.fused_loss(cam, batch, background=bg, sync=False, compact_sh_grad=dp_compact)
+            losses = model.fused_loss(cam, batch, background=bg, sync=False, compact_sh_grad=dp_compact,
+                                      optimizer=tick_for)
             model.backward_fused(losses)
             return losses
 
@@ -352,7 +353,9 @@ def main():
             return {}
 
         def graph_step():
-            losses = fwd_bwd()
+            # one graph for the whole step: the loss pass's fold launch also advances the optimiser's device step
+            # state (FlatAdam.take_tick), so the Adam launches that follow need no one-thread launch for it
+            losses = fwd_bwd(opt if fused_sh else None)
             adam_only()
             return losses
 
@@ -393,6 +396,7 @@ def main():
         except Exception as e:                         # capture is an optimisation of dispatch only
             log(f"graph capture failed ({type(e).__name__}: {e})")
             torch.cuda.synchronize()
+            opt.drop_tick()
             captured = False
         if dist is not None:                           # every rank must issue the same collectives from here on
             ok = torch.tensor([1 if captured else 0], device=dev, dtype=torch.int32)

@@ -263,12 +263,23 @@ int qed_ssim_bwd(int32_t height, int32_t width, int32_t channels, const float* p
  * losses[0..2] as qed_loss_grad with extra_sum = ssim_sum, extra_scale = ssim_scale, extra_offset = ssim_offset (=
  * ssim_lambda); sums is qed_loss_reduce's workspace (which also zeroes the slots this pass adds its loss sums to).
  * zero_buf (may be NULL; 16-byte aligned, zero_floats a multiple of 4): a buffer the same launch zeroes -- the vsplat
- * accumulator qed_composite_bwd needs zeroed, which saves the fill launch in front of that kernel. */
+ * accumulator qed_composite_bwd needs zeroed, which saves the fill launch in front of that kernel.
+ * tick (may be NULL): the optimiser's device-resident step state is advanced by the one-workgroup fold launch of this call
+ * (what qed_adam_step_dev / qed_adam_step_sh otherwise do in a one-thread launch of their own: this call sits between
+ * the previous step's Adam launches and this step's); follow with qed_adam_step_sh(parts | QED_ADAM_PART_TICKED). */
+typedef struct {
+    float* dev_state;        /* as qed_adam_step_dev */
+    float beta1, beta2;
+    float* dev_lr_slot;      /* NULL, or &dev_lr[scheduled group]: receives the exponential decay of qed_lr_exp_decay_dev */
+    float lr_init, lr_final;
+    int32_t max_steps;
+} qed_adam_tick_t;
 int qed_loss_grad_ssim(int32_t height, int32_t width, int32_t channels, const float* render, const float* alpha,
                        const float* background, const float* gt_rgb, const float* gt_depth, const float* mask,
                        const float* maps, float* sums, float rgb_weight, float depth_lambda, float ssim_scale,
                        float* v_render, float* v_alpha, float* losses, const float* ssim_sum,
-                       int32_t ssim_sum_n, float ssim_offset, float* zero_buf, int64_t zero_floats, void* stream);
+                       int32_t ssim_sum_n, float ssim_offset, float* zero_buf, int64_t zero_floats,
+                       const qed_adam_tick_t* tick, void* stream);
 
 /* qed_ssim_bwd and qed_image_losses_bwd in ONE launch (get_loss_dict's backward): v_rgb[H,W,3] = g_main[0] * d main_loss /
  * d rgb (the L1 term joins the SSIM term inside the SSIM backward pass, which has the pixel's colours at hand) and
@@ -408,6 +419,7 @@ int qed_adam_step_dev(float* params, const float* grads, float* exp_avg, float* 
  * same `step`; with device state only the SH part advances it. */
 #define QED_ADAM_PART_SH 1
 #define QED_ADAM_PART_LEADING 2
+#define QED_ADAM_PART_TICKED 4   /* device state already advanced for this step (qed_loss_grad_ssim's tick) */
 int qed_adam_step_sh(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                      int32_t n_groups, const int64_t* h_group_begin, const float* h_lr, float* dev_lr,
                      float beta1, float beta2, float eps, int32_t step, float* dev_state,

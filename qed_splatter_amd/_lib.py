@@ -60,13 +60,19 @@ SIGNATURES = {
     "qed_image_losses_fwd": (C.c_int, [_I, _P, _P, _P, _P, _P, _F, _F, _P, _I, _F, _F, _P, _P, _P]),
     "qed_image_losses_bwd": (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _I, _P, _P, _P]),
     "qed_loss_grad_ssim": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _P, _P, _P, _I, _F, _P, _L,
-                                     _P]),
+                                     _P, _P]),
     "qed_image_losses_ssim_bwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _P, _P, _P, _P]),
     "qed_adam_step": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _F, _F, _F, _I, _P]),
     "qed_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _F, _F, _F, _P, _P]),
     "qed_adam_step_sh": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _P, _F, _F, _F, _I, _P, _I, _F, _F, _I, _I, _I, _P, _I,
                                    _P, _L, _P, _L, _F, _I, _P]),
 }
+
+class AdamTick(C.Structure):
+    """qed_adam_tick_t (include/qed_splat.h): the optimiser's device step state, advanced by qed_loss_grad_ssim."""
+    _fields_ = [("dev_state", C.c_void_p), ("beta1", C.c_float), ("beta2", C.c_float), ("dev_lr_slot", C.c_void_p),
+                ("lr_init", C.c_float), ("lr_final", C.c_float), ("max_steps", C.c_int32)]
+
 
 # flags (include/qed_splat.h)
 LOSS_SUMS_FLOATS = 8 + 4 * 1024          # QED_LOSS_SUMS_FLOATS

@@ -182,7 +182,8 @@ loss_grad_kernel(int n_pix, const float* __restrict__ render, const float* __res
 __global__ void __launch_bounds__(256)
 loss_finalize_kernel(int n_pix, int n_blocks, int has_depth, float* __restrict__ sums, float rgb_weight,
                      float depth_lambda, float* __restrict__ losses, const float* __restrict__ extra_sum, int extra_n,
-                     float extra_scale, float extra_offset) {
+                     float extra_scale, float extra_offset, AdamTick tick) {
+    if (threadIdx.x == 64 && tick.state != nullptr) adam_tick(tick);     // (a passenger: see AdamTick)
     float nv = 0.f, dm = -3.0e38f, tl = 0.f, td = 0.f, ex = 0.f;
     if (extra_sum != nullptr)                               // per-workgroup partials of the SSIM map sum (qed_ssim_fwd)
         for (int b = threadIdx.x; b < extra_n; b += 256) ex += extra_sum[b];
@@ -566,19 +567,9 @@ adam_sh_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__
     }
 }
 
-// state = {step (as float), 1 / (1 - beta1^step), 1 / sqrt(1 - beta2^step)}; advances the step by one
-__global__ void adam_tick_kernel(float* __restrict__ state, float beta1, float beta2, float* __restrict__ lr_slot,
-                                 float log_init, float log_final, float inv_max_steps) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        if (lr_slot != nullptr) {       // scheduled rate of the step about to be taken (lr_exp_decay_kernel's formula)
-            const float u = fminf(fmaxf(state[0] * inv_max_steps, 0.f), 1.f);
-            lr_slot[0] = expf(log_init * (1.f - u) + log_final * u);
-        }
-        const float t = state[0] + 1.f;
-        state[0] = t;
-        state[1] = 1.f / (1.f - powf(beta1, t));
-        state[2] = 1.f / sqrtf(1.f - powf(beta2, t));
-    }
+// advances the step by one (AdamTick, qed_common.h)
+__global__ void adam_tick_kernel(AdamTick tick) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) adam_tick(tick);
 }
 
 // ExponentialDecayScheduler of the "means" group (config.py:46-51) evaluated from the device step
@@ -643,7 +634,7 @@ extern "C" int qed_loss_grad(int32_t n_pix, int32_t channels, const float* rende
         hipLaunchKernelGGL(loss_grad_kernel<3>, dim3(grid), dim3(256), 0, st, n_pix, render, alpha, background, gt_rgb,
                            gt_depth, mask, sums_rw, rgb_weight, depth_lambda, v_render, v_alpha, v_rgb_extra);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, n_pix, (int)grid, channels == 4 ? 1 : 0, sums_rw,
-                       rgb_weight, depth_lambda, losses, extra_sum, (int)extra_n, extra_scale, extra_offset);
+                       rgb_weight, depth_lambda, losses, extra_sum, (int)extra_n, extra_scale, extra_offset, AdamTick{});
     return check_launch("qed_loss_grad");
 }
 
@@ -695,7 +686,7 @@ extern "C" int qed_image_losses_fwd(int32_t n_pix, const float* rgb, const float
                        sums);
     // has_depth = -1: fold row 0 (the valid count) but no row of maxima
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, n_pix, (int)grid, -1, sums, rgb_weight,
-                       depth_lambda, losses, extra_sum, (int)extra_n, extra_scale, extra_offset);
+                       depth_lambda, losses, extra_sum, (int)extra_n, extra_scale, extra_offset, AdamTick{});
     return check_launch("qed_image_losses_fwd");
 }
 
@@ -730,8 +721,8 @@ extern "C" int qed_adam_step_dev(float* params, const float* grads, float* exp_a
                                  int32_t n_groups, const int64_t* h_group_begin, const float* dev_lr, float beta1,
                                  float beta2, float eps, float* dev_state, void* stream) {
     QED_REQUIRE(dev_lr && dev_state, "device lr / state required");
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dev_state, beta1, beta2,
-                       (float*)nullptr, 0.f, 0.f, 0.f);
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+                       AdamTick{dev_state, beta1, beta2, nullptr, 0.f, 0.f, 0.f});
     return adam_launch(params, grads, exp_avg, exp_avg_sq, n_groups, h_group_begin, nullptr, beta1, beta2, eps, 1,
                        dev_state, dev_lr, stream);
 }
@@ -748,7 +739,8 @@ extern "C" int qed_adam_step_sh(float* params, const float* grads, float* exp_av
     QED_REQUIRE(dev_state || (h_lr && step >= 1), "host rates and a 1-based step, or device state");
     QED_REQUIRE(params && exp_avg && exp_avg_sq && N > 0 && means && n_views >= 1 && viewmats && v_views,
                 "bad arguments");
-    QED_REQUIRE(parts >= 1 && parts <= 3, "parts: QED_ADAM_PART_SH | QED_ADAM_PART_LEADING");
+    QED_REQUIRE((parts & 3) != 0 && parts >= 1 && parts <= 7, "parts: QED_ADAM_PART_SH | QED_ADAM_PART_LEADING [| QED_ADAM_PART_TICKED]");
+    QED_REQUIRE(!(parts & QED_ADAM_PART_TICKED) || dev_state, "QED_ADAM_PART_TICKED is about the device-resident state");
     QED_REQUIRE(grads || n_groups == 2 || !(parts & QED_ADAM_PART_LEADING), "gradients of the leading groups required");
     QED_REQUIRE((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
                 "buffers must be 16-byte aligned");
@@ -778,10 +770,13 @@ extern "C" int qed_adam_step_sh(float* params, const float* grads, float* exp_av
                            dev_state ? 1 : step, dev_state, dev_lr, stream);
     }
     if (dev_state != nullptr) {
-        const bool sched = sched_group >= 0;
-        hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, st, dev_state, beta1, beta2,
-                           sched ? dev_lr + sched_group : (float*)nullptr, sched ? logf(sched_lr_init) : 0.f,
-                           sched ? logf(sched_lr_final) : 0.f, sched ? 1.f / (float)sched_max_steps : 0.f);
+        if (!(parts & QED_ADAM_PART_TICKED)) {           // (else qed_loss_grad_ssim's fold launch has advanced the state)
+            const bool sched = sched_group >= 0;
+            hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, st,
+                               AdamTick{dev_state, beta1, beta2, sched ? dev_lr + sched_group : (float*)nullptr,
+                                        sched ? logf(sched_lr_init) : 0.f, sched ? logf(sched_lr_final) : 0.f,
+                                        sched ? 1.f / (float)sched_max_steps : 0.f});
+        }
     } else {
         co.inv_bc1 = (float)(1.0 / (1.0 - pow((double)beta1, (double)step)));
         co.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));

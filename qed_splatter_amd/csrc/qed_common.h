@@ -157,9 +157,31 @@ __device__ __forceinline__ int wave_max_i(int v) {
 constexpr int kLossMaxGrid = (QED_LOSS_SUMS_FLOATS - 8) / 4;
 __device__ __forceinline__ float* loss_part(float* sums, int row) { return sums + 8 + row * kLossMaxGrid; }
 
+// Advancing the optimiser's device-resident step state (qed_adam_step_dev / qed_adam_step_sh): state = {step (as float),
+// 1 / (1 - beta1^step), 1 / sqrt(1 - beta2^step)}; one thread.  A launch of its own (adam_tick_kernel) or, in the fused
+// training step, a passenger of the loss pass's one-workgroup fold launch (qed_loss_grad_ssim's `tick`): that launch
+// sits between the previous step's Adam launches and this step's, which is all the tick needs.
+struct AdamTick {
+    float* state;           // NULL: nothing to do
+    float beta1, beta2;
+    float* lr_slot;         // NULL, or the scheduled group's learning-rate slot (lr_exp_decay_kernel's formula)
+    float log_init, log_final, inv_max_steps;
+};
+
+__device__ __forceinline__ void adam_tick(const AdamTick& t) {
+    if (t.lr_slot != nullptr) {         // scheduled rate of the step about to be taken
+        const float u = fminf(fmaxf(t.state[0] * t.inv_max_steps, 0.f), 1.f);
+        t.lr_slot[0] = expf(t.log_init * (1.f - u) + t.log_final * u);
+    }
+    const float n = t.state[0] + 1.f;
+    t.state[0] = n;
+    t.state[1] = 1.f / (1.f - powf(t.beta1, n));
+    t.state[2] = 1.f / sqrtf(1.f - powf(t.beta2, n));
+}
+
 __global__ void loss_finalize_kernel(int n_pix, int n_blocks, int has_depth, float* __restrict__ sums, float rgb_weight,
                                      float depth_lambda, float* __restrict__ losses, const float* __restrict__ extra_sum,
-                                     int extra_n, float extra_scale, float extra_offset);
+                                     int extra_n, float extra_scale, float extra_offset, AdamTick tick);
 
 // grid of the two streaming loss passes (pass 2 reads pass 1's per-workgroup partials by index)
 inline unsigned loss_reduce_grid(long long n_pix) {

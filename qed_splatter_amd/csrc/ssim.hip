@@ -569,7 +569,7 @@ extern "C" int qed_loss_grad_ssim(int32_t height, int32_t width, int32_t channel
                                   const float* maps, float* sums, float rgb_weight, float depth_lambda, float ssim_scale,
                                   float* v_render, float* v_alpha, float* losses, const float* ssim_sum,
                                   int32_t ssim_sum_n, float ssim_offset, float* zero_buf, int64_t zero_floats,
-                                  void* stream) {
+                                  const qed_adam_tick_t* tick, void* stream) {
     QED_REQUIRE(height > kHalo && width > kHalo, "image smaller than the 11 x 11 SSIM window");
     QED_REQUIRE(channels == 3 || channels == 4, "channels must be 3 (RGB) or 4 (RGB+D)");
     QED_REQUIRE(render && alpha && background && gt_rgb && maps && sums && v_render && v_alpha && losses && ssim_sum,
@@ -589,8 +589,17 @@ extern "C" int qed_loss_grad_ssim(int32_t height, int32_t width, int32_t channel
     if (channels == 4) { if (mask) QED_SSIM_BWD_FUSED(true, 4); else QED_SSIM_BWD_FUSED(false, 4); }
     else { if (mask) QED_SSIM_BWD_FUSED(true, 3); else QED_SSIM_BWD_FUSED(false, 3); }
 #undef QED_SSIM_BWD_FUSED
+    AdamTick tk{};
+    if (tick != nullptr) {
+        QED_REQUIRE(tick->dev_state && tick->beta1 > 0.f && tick->beta2 > 0.f, "tick: device state and betas required");
+        QED_REQUIRE(tick->dev_lr_slot == nullptr || (tick->lr_init > 0.f && tick->lr_final > 0.f && tick->max_steps > 0),
+                    "tick: a scheduled rate needs positive rates and max_steps");
+        tk = AdamTick{tick->dev_state, tick->beta1, tick->beta2, tick->dev_lr_slot,
+                      tick->dev_lr_slot ? logf(tick->lr_init) : 0.f, tick->dev_lr_slot ? logf(tick->lr_final) : 0.f,
+                      tick->dev_lr_slot ? 1.f / (float)tick->max_steps : 0.f};
+    }
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, n_pix, (int)n_loss, channels == 4 ? 1 : 0, sums,
-                       rgb_weight, depth_lambda, losses, ssim_sum, (int)ssim_sum_n, ssim_scale, ssim_offset);
+                       rgb_weight, depth_lambda, losses, ssim_sum, (int)ssim_sum_n, ssim_scale, ssim_offset, tk);
     return check_launch("qed_loss_grad_ssim");
 }
 

@@ -325,7 +325,8 @@ class _FusedImageLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, render, alpha, background, gt_rgb, gt_depth, mask, ssim_lambda, depth_lambda, vsplat_holder=None,
-                vsplat_rows=0):
+                vsplat_rows=0, tick=None):
+        import ctypes
         lib = L.load()
         ctx.set_materialize_grads(False)
         C, H, W, CH = render.shape
@@ -355,7 +356,8 @@ class _FusedImageLoss(torch.autograd.Function):
                                            L.ptr(gt_depth), L.ptr(mask), L.ptr(maps), L.ptr(sums), 1.0 - ssim_lambda,
                                            depth_lambda, -ssim_lambda / n_out, L.ptr(v_render), L.ptr(v_alpha),
                                            L.ptr(losses), L.ptr(ssum), ssum.numel(), ssim_lambda, L.ptr(vsplat),
-                                           vsplat.numel() if vsplat is not None else 0, st), "qed_loss_grad_ssim")
+                                           vsplat.numel() if vsplat is not None else 0,
+                                           ctypes.addressof(tick) if tick is not None else None, st), "qed_loss_grad_ssim")
             if vsplat is not None:
                 del vsplat_holder[:]
                 vsplat_holder.append(vsplat)
@@ -377,7 +379,7 @@ class _FusedImageLoss(torch.autograd.Function):
         # backward_fused() and needs no scaling pass; anything else (a weighted loss, a GradScaler) is applied
         if v_total.data_ptr() != _unit_grad(v_total.device).data_ptr():
             v_render, v_alpha = v_render * v_total, v_alpha * v_total
-        return v_render, v_alpha, None, None, None, None, None, None, None, None
+        return v_render, v_alpha, None, None, None, None, None, None, None, None, None
 
 
 class QEDSplatterModel(nn.Module):
@@ -778,7 +780,7 @@ class QEDSplatterModel(nn.Module):
 
     # ---- fused training step: model.py:199-321 + 73-118 in as few passes as possible ----
     def fused_loss(self, camera, batch, background: Optional[Tensor] = None, sync: bool = True,
-                   compact_sh_grad: bool = False) -> Dict[str, Tensor]:
+                   compact_sh_grad: bool = False, optimizer: Optional["FlatAdam"] = None) -> Dict[str, Tensor]:
         """Forward + K8 fused loss.  Returns {"loss", "main_loss", "depth_loss"}: ``loss`` = main + depth is
         the differentiable total (call ``.backward()`` on it as is: the kernel already wrote its gradient
         for an upstream gradient of 1); the two parts are detached views for logging.  Numerically the
@@ -829,6 +831,11 @@ class QEDSplatterModel(nn.Module):
         gt_depth = _f32_image(self.get_gt_img(batch["depth_image"]), H * W, "batch['depth_image']", self.device)
         mask = self._loss_mask(batch, (H, W))
         holder: list = []         # (the fused loss launch leaves the compositing backward's zeroed accumulator here)
+        # ``optimizer`` (a FlatAdam stepped with device_state=True, fused_sh=True right after this step's backward): the
+        # loss pass's fold launch advances its device step state, so that the optimiser needs no launch of its own for it
+        tick = None
+        if optimizer is not None and torch.is_grad_enabled() and cfg.ssim_lambda > 0.0:
+            tick = optimizer.take_tick()
         render, alpha, self.info = rasterization(
             means=self.means, quats=self.quats, scales=self.scales, opacities=self.opacities, colors=colors,
             viewmats=viewmat, Ks=K, width=W, height=H, tile_size=16, packed=False, near_plane=0.01, far_plane=1e10,
@@ -840,7 +847,7 @@ class QEDSplatterModel(nn.Module):
         self.last_viewmat, self.last_sh_degree = viewmat, deg
         total, parts = _FusedImageLoss.apply(render, alpha, bg.contiguous(), gt_rgb, gt_depth, mask,
                                              float(cfg.ssim_lambda), cfg.depth_lambda,
-                                             holder if torch.is_grad_enabled() else None, self.num_points)
+                                             holder if torch.is_grad_enabled() else None, self.num_points, tick)
         return {"loss": total, "main_loss": parts[0], "depth_loss": parts[1]}
 
 
@@ -889,6 +896,28 @@ class FlatAdam:
         self.dev_state = torch.zeros(4, dtype=torch.float32, device=model.device)
         self.dev_lr = torch.zeros(8, dtype=torch.float32, device=model.device)
         self.dev_lr[:len(self.lr)] = torch.tensor(self.lr)
+
+    def take_tick(self):
+        """The qed_adam_tick_t that lets ANOTHER launch of the step advance this optimiser's device step state
+        (model.fused_loss(optimizer=...): the loss pass's fold launch does it); the next
+        ``step(device_state=True, fused_sh=True)`` then launches no tick of its own.  None while a tick is pending."""
+        if getattr(self, "_ticked", False):
+            return None
+        i = self.model.group_names.index("means")
+        t = L.AdamTick()
+        t.dev_state, t.beta1, t.beta2 = self.dev_state.data_ptr(), self.betas[0], self.betas[1]
+        if self.means_schedule is not None:
+            lr_final, max_steps = self.means_schedule
+            t.dev_lr_slot = self.dev_lr[i:i + 1].data_ptr()
+            t.lr_init, t.lr_final, t.max_steps = self._means_lr_init, float(lr_final), int(max_steps)
+        else:
+            t.dev_lr_slot, t.lr_init, t.lr_final, t.max_steps = None, 0.0, 0.0, 0
+        self._tick_struct, self._ticked = t, True               # (kept alive: the C call reads it through a pointer)
+        return t
+
+    def drop_tick(self) -> None:
+        """Forget a tick handed out by take_tick() whose launch never happened (a failed graph capture)."""
+        self._ticked = False
 
     def set_lr(self, name: str, lr: float) -> None:
         i = self.model.group_names.index(name)
@@ -992,6 +1021,11 @@ class FlatAdam:
                 b = m.group_begin
                 views = (1, m.last_viewmat, 16, g[b[-3]:b[-2]], 0, 1.0)
             n_views, viewmats, vm_stride, v_views, view_stride, scale = views
+            if getattr(self, "_ticked", False) and (part & 1):       # take_tick(): the state is advanced already
+                if not device_state:
+                    raise RuntimeError("the device step state was advanced by fused_loss(optimizer=...): step with "
+                                       "device_state=True")
+                part, self._ticked = part | 4, False
             L.check(lib.qed_adam_step_sh(
                 L.ptr(p), L.ptr(g), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), len(self.lr),
                 C.cast(self._begin, C.c_void_p), None if device_state else C.cast(self._lr, C.c_void_p),

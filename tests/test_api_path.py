@@ -552,7 +552,7 @@ def test_fused_ssim_backward_and_loss_gradient_equals_the_two_passes(cuda, lib, 
             L.check(lib.qed_loss_grad_ssim(H, W, ch, L.ptr(render), L.ptr(alpha), L.ptr(bg), L.ptr(gt), L.ptr(gd),
                                            L.ptr(mask), L.ptr(maps), L.ptr(sums), 1.0 - lam, dl, -lam / n_out, L.ptr(v_r),
                                            L.ptr(v_a), L.ptr(losses), L.ptr(ssum), ssum.numel(), lam, L.ptr(zbuf),
-                                           zbuf.numel(), st), "qed_loss_grad_ssim")
+                                           zbuf.numel(), None, st), "qed_loss_grad_ssim")
             torch.cuda.synchronize()
             assert float(zbuf.abs().max()) == 0.0 and float(guard.min()) == 3.0     # zeroed, and nothing beyond it
         else:
@@ -612,3 +612,42 @@ def test_fused_image_losses_backward_equals_the_two_passes(cuda, lib, masked, wi
         assert torch.equal(b_d, a_d) and float(a_d.abs().max()) > 0.0
     else:
         assert float((b_d - 5.0).abs().max()) == 0.0                   # untouched
+
+
+def test_optimizer_tick_riding_on_the_loss_launch(cuda):
+    """fused_loss(optimizer=opt): the loss pass's fold launch advances the optimiser's device step state and the Adam call
+    launches no tick of its own -- same parameters, moments, step counter and scheduled rate as the plain sequence over
+    several steps; a second fused_loss before the step does not tick twice; a host-state step after a taken tick raises."""
+    from qed_splatter_amd.model import FlatAdam
+    w, h, n = 128, 96, 2000
+    sc = scene(n, w, h, seed=41)
+    runs = []
+    for hook in (False, True):
+        m, cam, batch = _model(sc, cuda)
+        opt = FlatAdam(m, means_schedule=(1.6e-6, 50))
+        saved = []
+        for it in range(4):
+            for p in m.parameters():
+                p.grad = None
+            losses = m.fused_loss(cam, batch, compact_sh_grad=True, optimizer=opt if hook else None)
+            if hook and it == 2:                                   # a repeated forward pass before the step
+                losses = m.fused_loss(cam, batch, compact_sh_grad=True, optimizer=opt)
+            m.backward_fused(losses)
+            # identical gradients in both runs (the compositing backward's atomics are not order-deterministic)
+            if hook:
+                m.flat_grad().copy_(runs[0][2][it])
+            else:
+                saved.append(m.flat_grad().clone())
+            opt.step(device_state=True, fused_sh=True)
+        torch.cuda.synchronize()
+        runs.append((m, opt, saved))
+    (m0, o0, _), (m1, o1, _) = runs
+    assert float(o0.dev_state[0]) == float(o1.dev_state[0]) == 4.0
+    assert torch.equal(o1.dev_state, o0.dev_state) and torch.equal(o1.dev_lr, o0.dev_lr)
+    assert torch.equal(m1.flat_params, m0.flat_params)
+    assert torch.equal(o1.exp_avg, o0.exp_avg) and torch.equal(o1.exp_avg_sq, o0.exp_avg_sq)
+    m, cam, batch = _model(sc, cuda)
+    opt = FlatAdam(m)
+    m.backward_fused(m.fused_loss(cam, batch, compact_sh_grad=True, optimizer=opt))
+    with pytest.raises(RuntimeError, match="device_state=True"):
+        opt.step(fused_sh=True)
