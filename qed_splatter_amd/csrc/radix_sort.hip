@@ -391,13 +391,23 @@ static int sort_pairs_impl(KeyT* keys, int* vals, KeyT* keys_alt, int* vals_alt,
 }
 
 constexpr int kKpt64 = 8;   // 2048 pairs per workgroup: >= 1400 workgroups at M = 3e6
+// 32-bit keys: 2048 pairs per workgroup for short lists, 4096 for long ones.  Measured on the tile sort of config B
+// (3.35 M keys, two passes; the whole of qed_bin_tiles): 1792 keys per workgroup 151 us, 2048 147, 2560 144, 3072 141,
+// 3584 / 4096 139, 5120 140, 6144 157 -- fewer, longer-lived workgroups (one generation instead of 1.07) until the
+// 38 KB of LDS per workgroup leaves too few of them per CU.  Short lists keep the small workgroups: 4096 pairs would
+// leave half the CUs idle below ~1 M keys.
 constexpr int kKpt32 = 8;
+constexpr int kKpt32Long = 16;
+constexpr long long kSortLongList = 3000000;
 
-// 32-bit-key flavour used by the two-stage tile binning (qed_bin_tiles, isect.hip)
+// 32-bit-key flavour used by the tile binning (qed_bin_tiles, isect.hip); sized for the smaller workgroups (more of them)
 long long sort32_workspace_bytes(long long capacity) { return sort_workspace_need<unsigned, kKpt32>(capacity); }
 
 int sort_pairs_u32(unsigned* keys, int* vals, unsigned* keys_alt, int* vals_alt, const int* n_dev, long long capacity,
                    int end_bit, void* workspace, long long workspace_bytes, int* status, hipStream_t st) {
+    if (capacity >= kSortLongList)
+        return sort_pairs_impl<unsigned, kKpt32Long>(keys, vals, keys_alt, vals_alt, n_dev, capacity, end_bit, workspace,
+                                                     workspace_bytes, status, st);
     return sort_pairs_impl<unsigned, kKpt32>(keys, vals, keys_alt, vals_alt, n_dev, capacity, end_bit, workspace,
                                              workspace_bytes, status, st);
 }
