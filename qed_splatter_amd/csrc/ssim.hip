@@ -314,10 +314,10 @@ ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
     // for the two passes it replaces).  FUSE 4: pass 1's per-workgroup partials (n_valid, the largest rendered depth),
     // folded as loss_grad_kernel does.
     float l1 = 0.f, dsum = 0.f, w_rgb = 0.f, w_d = 0.f, dmax = 0.f;
-    float ep_d[CB], ep_a[CB], ep_gd[CB], va[CB];
+    float ep_d[CB], ep_a[CB], ep_gd[CB];
     bool inside[CB];
 #pragma unroll
-    for (int o = 0; o < CB; ++o) { ep_d[o] = 0.f; ep_a[o] = 1.f; ep_gd[o] = 0.f; va[o] = 0.f; inside[o] = ix < W && oy + ty0 + o < H; }
+    for (int o = 0; o < CB; ++o) { ep_d[o] = 0.f; ep_a[o] = 1.f; ep_gd[o] = 0.f; inside[o] = ix < W && oy + ty0 + o < H; }
     if constexpr (FUSE != 0) {
         w_rgb = lf.w_rgb;
         if constexpr (FUSE == 1) w_rgb *= lf.g_main != nullptr ? lf.g_main[0] : 0.f;
@@ -446,10 +446,8 @@ ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
                 if (inside[o]) l1 += fabsf(diff);
                 const float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
                 r = w_rgb * sg * mo[o] + r;
-                if constexpr (COMPOSITE) {
+                if constexpr (COMPOSITE)
                     r = (pre[o] >= 0.f && pre[o] <= 1.f) ? r : 0.f;               // torch.clamp backward (inclusive)
-                    va[o] -= r * bgk;
-                }
             }
             if (k == 0) r0[o] = r;
             else if (k == 1) r1[o] = r;
@@ -480,11 +478,11 @@ ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
                         if (a > 0.f) v3 = w_d * (dd > 0.f ? 1.f : (dd < 0.f ? -1.f : 0.f)) * mo[o];
                     }
                     *reinterpret_cast<float4*>(lf.v_render + 4 * pix) = make_float4(r0[o], r1[o], r, v3);
-                    lf.v_alpha[pix] = va[o];
+                    lf.v_alpha[pix] = -((r0[o] * bg[0] + r1[o] * bg[1]) + r * bgk);   // d colour / d alpha = -background
                 } else {
                     Float3 v; v.a = r0[o]; v.b = r1[o]; v.c = r;
                     *reinterpret_cast<Float3*>(lf.v_render + 3 * pix) = v;
-                    lf.v_alpha[pix] = va[o];
+                    lf.v_alpha[pix] = -((r0[o] * bg[0] + r1[o] * bg[1]) + r * bgk);
                 }
             }
         }
