@@ -185,13 +185,35 @@ loss_finalize_kernel(int n_pix, int n_blocks, int has_depth, float* __restrict__
                      float extra_scale, float extra_offset, AdamTick tick) {
     if (threadIdx.x == 64 && tick.state != nullptr) adam_tick(tick);     // (a passenger: see AdamTick)
     float nv = 0.f, dm = -3.0e38f, tl = 0.f, td = 0.f, ex = 0.f;
-    if (extra_sum != nullptr)                               // per-workgroup partials of the SSIM map sum (qed_ssim_fwd)
-        for (int b = threadIdx.x; b < extra_n; b += 256) ex += extra_sum[b];
-    for (int b = threadIdx.x; b < n_blocks; b += 256) {
-        if (has_depth) nv += loss_part(sums, 0)[b];                      // has_depth < 0: a valid count but no max row
-        if (has_depth > 0) dm = fmaxf(dm, loss_part(sums, 1)[b]);
-        tl += loss_part(sums, 2)[b];
-        td += loss_part(sums, 3)[b];
+    // every partial this thread folds is REQUESTED before the first one is used (clamped index, switched off by a
+    // select): as a loop of load-then-add rounds this one-workgroup launch took 9 us, twice its launch floor
+    static_assert(kLossMaxGrid <= 4 * 256, "four partials per row and thread");
+    float r0[4], r1[4], r2[4], r3[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int b = threadIdx.x + 256 * j;
+        const int bc = b < n_blocks ? b : 0;
+        r0[j] = has_depth ? loss_part(sums, 0)[bc] : 0.f;               // has_depth < 0: a valid count but no max row
+        r1[j] = has_depth > 0 ? loss_part(sums, 1)[bc] : -3.0e38f;
+        r2[j] = loss_part(sums, 2)[bc];
+        r3[j] = loss_part(sums, 3)[bc];
+    }
+    if (extra_sum != nullptr) {                             // per-workgroup partials of the SSIM map sum (qed_ssim_fwd)
+        for (int b0 = threadIdx.x; b0 < extra_n; b0 += 8 * 256) {
+            float e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = extra_sum[b0 + 256 * j < extra_n ? b0 + 256 * j : 0];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ex += b0 + 256 * j < extra_n ? e[j] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool ok = (int)threadIdx.x + 256 * j < n_blocks;
+        nv += ok ? r0[j] : 0.f;
+        dm = fmaxf(dm, ok ? r1[j] : -3.0e38f);
+        tl += ok ? r2[j] : 0.f;
+        td += ok ? r3[j] : 0.f;
     }
     nv = wave_sum(nv); dm = wave_max(dm); tl = wave_sum(tl); td = wave_sum(td); ex = wave_sum(ex);
     __shared__ float s[5][4];
