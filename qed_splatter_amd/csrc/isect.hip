@@ -74,10 +74,18 @@ isect_emit_kernel(int N, int C, const float* __restrict__ means2d, const int* __
     int block_base = 0;
     if constexpr (SELF_SCAN) {
         long long before = 0, all = 0;
-        for (int i = tid; i < (int)gridDim.x; i += 256) {
-            const long long v = block_offsets[i];
-            all += v;
-            if (i < (int)blockIdx.x) before += v;
+        for (int i0 = tid; i0 < (int)gridDim.x; i0 += 8 * 256) {          // eight sums in flight per trip
+            int v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = block_offsets[i0 + 256 * j < (int)gridDim.x ? i0 + 256 * j : 0];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + 256 * j;
+                if (i < (int)gridDim.x) {
+                    all += v[j];
+                    if (i < (int)blockIdx.x) before += v[j];
+                }
+            }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o, 64); all += __shfl_xor(all, o, 64); }
