@@ -285,7 +285,7 @@ def main():
             model.fused_loss(cam, batch, background=bg, sync=True)
         M_ref = int(model.info["n_isects"])
         cfg.tight_tile_lists = True
-        _workspace(dev).capacity = 0
+        _workspace(dev).reset()
     # first step is synchronous: it calibrates the intersection-buffer capacity and gives M
     step(True)
     M = int(model.info["n_isects"])

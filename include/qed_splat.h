@@ -273,6 +273,7 @@ typedef struct {
     float* dev_lr_slot;      /* NULL, or &dev_lr[scheduled group]: receives the exponential decay of qed_lr_exp_decay_dev */
     float lr_init, lr_final;
     int32_t max_steps;
+    const int32_t* skip_flag; /* NULL, or as qed_adam_step's: non-zero -> the state is not advanced */
 } qed_adam_tick_t;
 int qed_loss_grad_ssim(int32_t height, int32_t width, int32_t channels, const float* render, const float* alpha,
                        const float* background, const float* gt_rgb, const float* gt_depth, const float* mask,
@@ -389,17 +390,21 @@ int qed_backproject_depth(int32_t height, int32_t width, const float* depth, flo
 
 /* ---- fused multi-tensor Adam over one flat parameter buffer (config.py:44-68) --
  * n_groups contiguous segments; segment g covers elements [h_group_begin[g], h_group_begin[g+1])
- * and uses learning rate h_lr[g].  bias corrections use `step` (1-based). */
+ * and uses learning rate h_lr[g].  bias corrections use `step` (1-based).  The betas are doubles: 1 - beta is
+ * formed in double and rounded once, as torch.optim.Adam's Python scalars are (exp_avg_sq then agrees to 1e-6).
+ * skip_flag (may be NULL; all three Adam entry points and qed_adam_tick_t): a DEVICE word; when it is non-zero
+ * the launch updates nothing.  Pass qed_bin_tiles' status[0]: a frame whose intersection list overflowed its
+ * buffer renders empty, and a step enqueued behind it without a host round trip must not train on it. */
 int qed_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
-                  int32_t n_groups, const int64_t* h_group_begin, const float* h_lr, float beta1,
-                  float beta2, float eps, int32_t step, void* stream);
+                  int32_t n_groups, const int64_t* h_group_begin, const float* h_lr, double beta1,
+                  double beta2, float eps, int32_t step, const int32_t* skip_flag, void* stream);
 
 /* Same update with the step state and learning rates in DEVICE memory, so that a captured hipGraph
  * can be replayed: dev_state[3] = {step, 1/(1-beta1^step), 1/sqrt(1-beta2^step)} is advanced by one
  * (zero it before the first step), dev_lr[8] holds the per-group learning rates. */
 int qed_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
-                      int32_t n_groups, const int64_t* h_group_begin, const float* dev_lr, float beta1,
-                      float beta2, float eps, float* dev_state, void* stream);
+                      int32_t n_groups, const int64_t* h_group_begin, const float* dev_lr, double beta1,
+                      double beta2, float eps, float* dev_state, const int32_t* skip_flag, void* stream);
 
 /* Adam step that never materialises the SH-coefficient gradients.  Every group is [N, width]; the LAST
  * two must be features_dc [N,3] and features_rest [N,KR,3].  Their gradient is the rank-1 product
@@ -422,11 +427,12 @@ int qed_adam_step_dev(float* params, const float* grads, float* exp_avg, float* 
 #define QED_ADAM_PART_TICKED 4   /* device state already advanced for this step (qed_loss_grad_ssim's tick) */
 int qed_adam_step_sh(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                      int32_t n_groups, const int64_t* h_group_begin, const float* h_lr, float* dev_lr,
-                     float beta1, float beta2, float eps, int32_t step, float* dev_state,
+                     double beta1, double beta2, float eps, int32_t step, float* dev_state,
                      int32_t sched_group, float sched_lr_init, float sched_lr_final,
                      int32_t sched_max_steps, int32_t N, int32_t sh_degree, const float* means,
                      int32_t n_views, const float* viewmats, int64_t viewmat_stride,
-                     const float* v_views, int64_t view_stride, float scale, int32_t parts, void* stream);
+                     const float* v_views, int64_t view_stride, float scale, int32_t parts,
+                     const int32_t* skip_flag, void* stream);
 
 /* ExponentialDecayScheduler of one group (the reference schedules "means": 1.6e-4 -> 1.6e-6 over
  * 30000 steps, config.py:46-51) from the device step counter, for graph replay: dev_lr_slot[0] =

@@ -505,7 +505,7 @@ def ssim(pred: Tensor, gt: Tensor, return_map: bool = False):
     tests/test_oracle_cpu.py (identical images -> 1, constant images -> luminance term)."""
     import torch.nn.functional as F
     H, W, C = pred.shape
-    win = ssim_window(dtype=pred.dtype)
+    win = ssim_window(dtype=pred.dtype).to(pred.device)
     x = pred.permute(2, 0, 1)[None]                       # [1,C,H,W]
     y = gt.to(pred.dtype).permute(2, 0, 1)[None]
 

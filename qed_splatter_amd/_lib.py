@@ -21,6 +21,7 @@ _I = C.c_int32
 _L = C.c_int64
 _F = C.c_float
 _U = C.c_uint32
+_D = C.c_double
 SIGNATURES = {
     "qed_version": (C.c_int, []),
     "qed_last_error": (C.c_char_p, []),
@@ -62,16 +63,16 @@ SIGNATURES = {
     "qed_loss_grad_ssim": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _P, _P, _P, _I, _F, _P, _L,
                                      _P, _P]),
     "qed_image_losses_ssim_bwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _P, _P, _P, _P]),
-    "qed_adam_step": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _F, _F, _F, _I, _P]),
-    "qed_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _F, _F, _F, _P, _P]),
-    "qed_adam_step_sh": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _P, _F, _F, _F, _I, _P, _I, _F, _F, _I, _I, _I, _P, _I,
-                                   _P, _L, _P, _L, _F, _I, _P]),
+    "qed_adam_step": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _D, _D, _F, _I, _P, _P]),
+    "qed_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _D, _D, _F, _P, _P, _P]),
+    "qed_adam_step_sh": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _P, _D, _D, _F, _I, _P, _I, _F, _F, _I, _I, _I, _P, _I,
+                                   _P, _L, _P, _L, _F, _I, _P, _P]),
 }
 
 class AdamTick(C.Structure):
     """qed_adam_tick_t (include/qed_splat.h): the optimiser's device step state, advanced by qed_loss_grad_ssim."""
     _fields_ = [("dev_state", C.c_void_p), ("beta1", C.c_float), ("beta2", C.c_float), ("dev_lr_slot", C.c_void_p),
-                ("lr_init", C.c_float), ("lr_final", C.c_float), ("max_steps", C.c_int32)]
+                ("lr_init", C.c_float), ("lr_final", C.c_float), ("max_steps", C.c_int32), ("skip_flag", C.c_void_p)]
 
 
 # flags (include/qed_splat.h)

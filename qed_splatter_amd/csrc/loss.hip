@@ -378,28 +378,42 @@ struct AdamGroups {
     int n;
 };
 
+// omb1 / omb2 = 1 - beta formed in DOUBLE on the host and rounded once, as torch.optim.Adam's Python scalars are
+// (1.f - (float)0.999 is off by 1.3e-5 relative, which exp_avg_sq then carries)
 struct AdamCoef {
-    float beta1, beta2, eps, inv_bc1, inv_bc2_sqrt;
+    float beta1, beta2, omb1, omb2, eps, inv_bc1, inv_bc2_sqrt;
 };
+static AdamCoef adam_coef(double beta1, double beta2, float eps, float inv_bc1, float inv_bc2_sqrt) {
+    return AdamCoef{(float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps, inv_bc1, inv_bc2_sqrt};
+}
+
+// `skip` (may be NULL): a device word that is non-zero when this step's frame must not be trained on -- the binning
+// status word of qed_bin_tiles: an intersection overflow rendered the frame empty.  Read by every Adam launch (and the
+// step-state tick): the update is then a no-op, with no host round trip.
+__device__ __forceinline__ bool adam_skipped(const int* __restrict__ skip) { return skip != nullptr && skip[0] != 0; }
 
 __device__ __forceinline__ float adam_update(const AdamCoef& a, float pp, float gg, float& mm, float& vv, float lr) {
-    mm = a.beta1 * mm + (1.f - a.beta1) * gg;
-    vv = a.beta2 * vv + (1.f - a.beta2) * gg * gg;
+    mm = a.beta1 * mm + a.omb1 * gg;
+    vv = a.beta2 * vv + a.omb2 * gg * gg;
     const float denom = sqrtf(vv) * a.inv_bc2_sqrt + a.eps;
     return pp - lr * a.inv_bc1 * mm / denom;
 }
 
 __global__ void __launch_bounds__(256)
 adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-            AdamGroups grp, float beta1, float beta2, float eps, float inv_bc1, float inv_bc2_sqrt,
-            const float* __restrict__ dev_state, const float* __restrict__ dev_lr) {
+            AdamGroups grp, AdamCoef co, const float* __restrict__ dev_state, const float* __restrict__ dev_lr,
+            const int* __restrict__ skip) {
+    if (adam_skipped(skip)) return;
     // device-resident step state / learning rates (hipGraph replays cannot change kernel arguments)
-    if (dev_state != nullptr) { inv_bc1 = dev_state[1]; inv_bc2_sqrt = dev_state[2]; }
+    if (dev_state != nullptr) { co.inv_bc1 = dev_state[1]; co.inv_bc2_sqrt = dev_state[2]; }
     float lrs[8];                                        // (not written back into grp: a modified by-value
 #pragma unroll                                           //  kernel argument is copied to scratch)
     for (int k = 0; k < 8; ++k) lrs[k] = dev_lr != nullptr ? dev_lr[k] : grp.lr[k];
     const long long total = grp.begin[grp.n];
     const long long nvec = total >> 2;
+    // a gradient that is a view at an odd offset of a larger allocation (one group of separately held parameters, N not
+    // a multiple of 4) is read with dword loads: a wave-uniform choice
+    const bool g_aligned = (reinterpret_cast<uintptr_t>(g) & 15) == 0;
     auto lr_of = [&](long long i) {
         float lr = lrs[0];
 #pragma unroll
@@ -407,14 +421,15 @@ adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restric
             if (k < grp.n && i >= grp.begin[k]) lr = lrs[k];
         return lr;
     };
-    const AdamCoef co{beta1, beta2, eps, inv_bc1, inv_bc2_sqrt};
     auto upd = [&](float pp, float gg, float& mm, float& vv, float lr) { return adam_update(co, pp, gg, mm, vv, lr); };
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
         // gradient and moments: read / written once per step -> non-temporal, so that they do not displace the
         // parameters (re-read by the next projection pass) from the last-level cache
         typedef float v4f __attribute__((ext_vector_type(4)));
         float4 pp = reinterpret_cast<float4*>(p)[i];
-        const v4f g4 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(g) + i);
+        v4f g4;
+        if (g_aligned) g4 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(g) + i);
+        else g4 = (v4f){g[4 * i], g[4 * i + 1], g[4 * i + 2], g[4 * i + 3]};
         const v4f m4 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(m) + i);
         const v4f v4 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(v) + i);
         const float4 gg = make_float4(g4.x, g4.y, g4.z, g4.w);
@@ -511,9 +526,10 @@ adam_sh_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__
                int RW, int N, const float* __restrict__ means, int n_views, const float* __restrict__ viewmats,
                long long viewmat_stride, const float* __restrict__ v_views, long long view_stride, float scale,
                AdamCoef a, const float* __restrict__ dev_state, const float* __restrict__ dev_lr, int dc_group,
-               float lr_dc, float lr_rest) {
+               float lr_dc, float lr_rest, const int* __restrict__ skip) {
     extern __shared__ float s_g[];                       // kShChunk * RW + 4 floats
     constexpr int K = (DEG + 1) * (DEG + 1);             // coefficient rows with a non-zero gradient
+    if (adam_skipped(skip)) return;
     if (dev_state != nullptr) { a.inv_bc1 = dev_state[1]; a.inv_bc2_sqrt = dev_state[2]; }
     if (dev_lr != nullptr) { lr_dc = dev_lr[dc_group]; lr_rest = dev_lr[dc_group + 1]; }
     const int tid = threadIdx.x;
@@ -656,7 +672,7 @@ extern "C" int qed_loss_grad(int32_t n_pix, int32_t channels, const float* rende
         hipLaunchKernelGGL(loss_grad_kernel<3>, dim3(grid), dim3(256), 0, st, n_pix, render, alpha, background, gt_rgb,
                            gt_depth, mask, sums_rw, rgb_weight, depth_lambda, v_render, v_alpha, v_rgb_extra);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, n_pix, (int)grid, channels == 4 ? 1 : 0, sums_rw,
-                       rgb_weight, depth_lambda, losses, extra_sum, (int)extra_n, extra_scale, extra_offset, AdamTick{});
+                       rgb_weight, depth_lambda, losses, extra_sum, (int)extra_n, extra_scale, extra_offset, AdamTick{nullptr, 0.f, 0.f, nullptr, 0.f, 0.f, 0.f, nullptr});
     return check_launch("qed_loss_grad");
 }
 
@@ -708,7 +724,7 @@ extern "C" int qed_image_losses_fwd(int32_t n_pix, const float* rgb, const float
                        sums);
     // has_depth = -1: fold row 0 (the valid count) but no row of maxima
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, n_pix, (int)grid, -1, sums, rgb_weight,
-                       depth_lambda, losses, extra_sum, (int)extra_n, extra_scale, extra_offset, AdamTick{});
+                       depth_lambda, losses, extra_sum, (int)extra_n, extra_scale, extra_offset, AdamTick{nullptr, 0.f, 0.f, nullptr, 0.f, 0.f, 0.f, nullptr});
     return check_launch("qed_image_losses_fwd");
 }
 
@@ -728,34 +744,34 @@ extern "C" int qed_image_losses_bwd(int32_t n_pix, const float* rgb, const float
 }
 
 static int adam_launch(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t n_groups,
-                       const int64_t* h_group_begin, const float* h_lr, float beta1, float beta2, float eps,
-                       int32_t step, float* dev_state, const float* dev_lr, void* stream);
+                       const int64_t* h_group_begin, const float* h_lr, double beta1, double beta2, float eps,
+                       int32_t step, float* dev_state, const float* dev_lr, const int32_t* skip, void* stream);
 
 extern "C" int qed_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t n_groups,
-                             const int64_t* h_group_begin, const float* h_lr, float beta1, float beta2, float eps,
-                             int32_t step, void* stream) {
+                             const int64_t* h_group_begin, const float* h_lr, double beta1, double beta2, float eps,
+                             int32_t step, const int32_t* skip_flag, void* stream) {
     QED_REQUIRE(h_lr && step >= 1, "bad arguments");
     return adam_launch(params, grads, exp_avg, exp_avg_sq, n_groups, h_group_begin, h_lr, beta1, beta2, eps, step,
-                       nullptr, nullptr, stream);
+                       nullptr, nullptr, skip_flag, stream);
 }
 
 extern "C" int qed_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
-                                 int32_t n_groups, const int64_t* h_group_begin, const float* dev_lr, float beta1,
-                                 float beta2, float eps, float* dev_state, void* stream) {
+                                 int32_t n_groups, const int64_t* h_group_begin, const float* dev_lr, double beta1,
+                                 double beta2, float eps, float* dev_state, const int32_t* skip_flag, void* stream) {
     QED_REQUIRE(dev_lr && dev_state, "device lr / state required");
     hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
-                       AdamTick{dev_state, beta1, beta2, nullptr, 0.f, 0.f, 0.f});
+                       AdamTick{dev_state, (float)beta1, (float)beta2, nullptr, 0.f, 0.f, 0.f, skip_flag});
     return adam_launch(params, grads, exp_avg, exp_avg_sq, n_groups, h_group_begin, nullptr, beta1, beta2, eps, 1,
-                       dev_state, dev_lr, stream);
+                       dev_state, dev_lr, skip_flag, stream);
 }
 
 extern "C" int qed_adam_step_sh(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t n_groups,
-                                const int64_t* h_group_begin, const float* h_lr, float* dev_lr, float beta1,
-                                float beta2, float eps, int32_t step, float* dev_state, int32_t sched_group,
+                                const int64_t* h_group_begin, const float* h_lr, float* dev_lr, double beta1,
+                                double beta2, float eps, int32_t step, float* dev_state, int32_t sched_group,
                                 float sched_lr_init, float sched_lr_final, int32_t sched_max_steps, int32_t N,
                                 int32_t sh_degree, const float* means, int32_t n_views, const float* viewmats,
                                 int64_t viewmat_stride, const float* v_views, int64_t view_stride, float scale,
-                                int32_t parts, void* stream) {
+                                int32_t parts, const int32_t* skip_flag, void* stream) {
     QED_REQUIRE(n_groups >= 2 && n_groups <= 8 && h_group_begin, "2..8 groups, the last two features_dc, features_rest");
     QED_REQUIRE((dev_state != nullptr) == (dev_lr != nullptr), "device state and device rates go together");
     QED_REQUIRE(dev_state || (h_lr && step >= 1), "host rates and a 1-based step, or device state");
@@ -785,23 +801,24 @@ extern "C" int qed_adam_step_sh(float* params, const float* grads, float* exp_av
     QED_REQUIRE(sh_degree >= 0 && sh_degree <= 3 && 3 * ((sh_degree + 1) * (sh_degree + 1) - 1) <= RW,
                 "sh_degree 0..3 within the stored coefficient rows");
     hipStream_t st = (hipStream_t)stream;
-    AdamCoef co{beta1, beta2, eps, 1.f, 1.f};
+    AdamCoef co = adam_coef(beta1, beta2, eps, 1.f, 1.f);
     if (!(parts & QED_ADAM_PART_SH)) {                 // the leading groups only: the SH part of this step has ticked
         if (n_groups == 2) return QED_OK;
         return adam_launch(params, grads, exp_avg, exp_avg_sq, n_groups - 2, h_group_begin, h_lr, beta1, beta2, eps,
-                           dev_state ? 1 : step, dev_state, dev_lr, stream);
+                           dev_state ? 1 : step, dev_state, dev_lr, skip_flag, stream);
     }
     if (dev_state != nullptr) {
         if (!(parts & QED_ADAM_PART_TICKED)) {           // (else qed_loss_grad_ssim's fold launch has advanced the state)
             const bool sched = sched_group >= 0;
             hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, st,
-                               AdamTick{dev_state, beta1, beta2, sched ? dev_lr + sched_group : (float*)nullptr,
+                               AdamTick{dev_state, (float)beta1, (float)beta2,
+                                        sched ? dev_lr + sched_group : (float*)nullptr,
                                         sched ? logf(sched_lr_init) : 0.f, sched ? logf(sched_lr_final) : 0.f,
-                                        sched ? 1.f / (float)sched_max_steps : 0.f});
+                                        sched ? 1.f / (float)sched_max_steps : 0.f, skip_flag});
         }
     } else {
-        co.inv_bc1 = (float)(1.0 / (1.0 - pow((double)beta1, (double)step)));
-        co.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
+        co.inv_bc1 = (float)(1.0 / (1.0 - pow(beta1, (double)step)));
+        co.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow(beta2, (double)step)));
     }
     // 3 workgroups per CU (46 KB of LDS each; measured at 500 k, both launches: 256 -> 150 us, 512 -> 125 us,
     // 768 -> 121 us, 1024 -> 132 us).  Folding the leading groups into the same launch was slower in two
@@ -817,7 +834,7 @@ extern "C" int qed_adam_step_sh(float* params, const float* grads, float* exp_av
                        grp.begin[n_groups - 2], grp.begin[n_groups - 1], RW, N, means, n_views, viewmats,            \
                        (long long)viewmat_stride, v_views, (long long)view_stride, scale, co,                        \
                        (const float*)dev_state, (const float*)dev_lr, n_groups - 2, grp.lr[n_groups - 2],            \
-                       grp.lr[n_groups - 1])
+                       grp.lr[n_groups - 1], skip_flag)
     switch (sh_degree) {
         case 0: QED_LAUNCH_ASH(0); break;
         case 1: QED_LAUNCH_ASH(1); break;
@@ -827,7 +844,7 @@ extern "C" int qed_adam_step_sh(float* params, const float* grads, float* exp_av
 #undef QED_LAUNCH_ASH
     if (n_groups == 2 || !(parts & QED_ADAM_PART_LEADING)) return check_launch("qed_adam_step_sh");
     return adam_launch(params, grads, exp_avg, exp_avg_sq, n_groups - 2, h_group_begin, h_lr, beta1, beta2, eps,
-                       dev_state ? 1 : step, dev_state, dev_lr, stream);
+                       dev_state ? 1 : step, dev_state, dev_lr, skip_flag, stream);
 }
 
 extern "C" int qed_lr_exp_decay_dev(float* dev_lr_slot, const float* dev_state, float lr_init, float lr_final,
@@ -839,12 +856,12 @@ extern "C" int qed_lr_exp_decay_dev(float* dev_lr_slot, const float* dev_state, 
 }
 
 static int adam_launch(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t n_groups,
-                       const int64_t* h_group_begin, const float* h_lr, float beta1, float beta2, float eps,
-                       int32_t step, float* dev_state, const float* dev_lr, void* stream) {
+                       const int64_t* h_group_begin, const float* h_lr, double beta1, double beta2, float eps,
+                       int32_t step, float* dev_state, const float* dev_lr, const int32_t* skip, void* stream) {
     QED_REQUIRE(n_groups >= 1 && n_groups <= 8, "1..8 parameter groups");
     QED_REQUIRE(params && grads && exp_avg && exp_avg_sq && h_group_begin && step >= 1, "bad arguments");
-    QED_REQUIRE((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
-                "buffers must be 16-byte aligned");
+    QED_REQUIRE((((uintptr_t)params | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0 && ((uintptr_t)grads & 3) == 0,
+                "params / moments must be 16-byte aligned (grads: 4)");
     AdamGroups grp;
     for (int i = 0; i <= n_groups; ++i) grp.begin[i] = h_group_begin[i];
     for (int i = n_groups + 1; i < 9; ++i) grp.begin[i] = h_group_begin[n_groups];
@@ -853,12 +870,12 @@ static int adam_launch(float* params, const float* grads, float* exp_avg, float*
     QED_REQUIRE(grp.begin[0] == 0, "group 0 must start at element 0");
     const long long total = grp.begin[n_groups];
     if (total == 0) return QED_OK;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
     // 2 workgroups per CU: measured 136 us (6.1 TB/s) against 157 us with 8 per CU and 196 us with 1 --
     // seven concurrent streams per wave favour fewer, longer-running waves (DRAM page locality)
     hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(total / 4 + 1, 512)), dim3(256), 0, (hipStream_t)stream, params, grads,
-                       exp_avg, exp_avg_sq, grp, beta1, beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)),
-                       (const float*)dev_state, dev_lr);
+                       exp_avg, exp_avg_sq, grp, adam_coef(beta1, beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2))),
+                       (const float*)dev_state, dev_lr, skip);
     return check_launch("qed_adam_step");
 }

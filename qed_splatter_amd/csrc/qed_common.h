@@ -166,9 +166,11 @@ struct AdamTick {
     float beta1, beta2;
     float* lr_slot;         // NULL, or the scheduled group's learning-rate slot (lr_exp_decay_kernel's formula)
     float log_init, log_final, inv_max_steps;
+    const int* skip;        // NULL, or the word that makes the step a no-op when non-zero (see adam_skipped, loss.hip)
 };
 
 __device__ __forceinline__ void adam_tick(const AdamTick& t) {
+    if (t.skip != nullptr && t.skip[0] != 0) return;
     if (t.lr_slot != nullptr) {         // scheduled rate of the step about to be taken
         const float u = fminf(fmaxf(t.state[0] * t.inv_max_steps, 0.f), 1.f);
         t.lr_slot[0] = expf(t.log_init * (1.f - u) + t.log_final * u);

@@ -594,7 +594,7 @@ extern "C" int qed_loss_grad_ssim(int32_t height, int32_t width, int32_t channel
                     "tick: a scheduled rate needs positive rates and max_steps");
         tk = AdamTick{tick->dev_state, tick->beta1, tick->beta2, tick->dev_lr_slot,
                       tick->dev_lr_slot ? logf(tick->lr_init) : 0.f, tick->dev_lr_slot ? logf(tick->lr_final) : 0.f,
-                      tick->dev_lr_slot ? 1.f / (float)tick->max_steps : 0.f};
+                      tick->dev_lr_slot ? 1.f / (float)tick->max_steps : 0.f, tick->skip_flag};
     }
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, n_pix, (int)n_loss, channels == 4 ? 1 : 0, sums,
                        rgb_weight, depth_lambda, losses, ssim_sum, (int)ssim_sum_n, ssim_scale, ssim_offset, tk);

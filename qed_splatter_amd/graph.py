@@ -21,7 +21,10 @@ class GraphedTrainStep:
     of scalar loss tensors) after a few eager warm-up runs on a side stream; ``replay()`` re-runs it.
 
     ``check_every``: every that many replays the intersection-overflow word is read back (one small
-    D2H copy); an overflow raises, because that frame rendered empty.
+    D2H copy).  A frame that overflowed the captured buffer rendered empty and the optimiser launches of
+    that and the following replays were no-ops on the device (``skip_flag`` of ``qed_adam_step*``);
+    ``check()`` then makes room, captures again, warns and returns False -- nothing is trained on an
+    empty frame and nothing raises a step late.
     """
 
     def __init__(self, step_fn: Callable[[], Dict[str, torch.Tensor]], device, warmup: int = 3, check_every: int = 50):
@@ -48,8 +51,7 @@ class GraphedTrainStep:
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         ws.poll_pending()
-        # headroom: the captured buffers can never grow
-        ws.capacity = int(ws.capacity * 1.25) + 4096
+        # (the captured buffers can never grow: the workspace keeps _Workspace.HEADROOM x the longest list seen)
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: HIP calls made by other threads (e.g. the RCCL watchdog polling its events in a
         # data-parallel job) must not invalidate this thread's capture
@@ -64,13 +66,22 @@ class GraphedTrainStep:
             self.check()
         return self.outputs
 
-    def check(self) -> None:
+    def check(self) -> bool:
+        """True when every replay since the last check had room for its list.  Otherwise: grow, re-capture, warn."""
+        import warnings
         status = self.ws.status.tolist()        # synchronises
-        if status[0]:
-            need = int(status[0])
-            self.ws.status.zero_()
-            raise L.QedSplatError(
-                f"a graphed step needed {need} tile intersections, more than the captured capacity "
-                f"{self.ws.capacity}; re-capture with a larger capacity")
         if status[1]:
+            self.ws.status.zero_()
             raise L.QedSplatError("radix-sort look-back watchdog fired")
+        if status[0]:
+            need, old = int(status[0]), self.ws.capacity
+            self.ws.status.zero_()
+            self.ws.overflows += 1
+            self.ws.capacity = max(self.ws.capacity, int(need * self.ws.HEADROOM) + 4096)
+            self.ws.force_sync = True           # the warm-up call of the re-capture reads M back
+            warnings.warn(f"qed_splatter_amd: a graphed step needed {need} tile intersections, more than the captured "
+                          f"capacity {old}; the frames since rendered empty and their optimiser steps were skipped on "
+                          f"the device.  Re-captured with capacity {self.ws.capacity}.", RuntimeWarning, stacklevel=2)
+            self.recapture()
+            return False
+        return True

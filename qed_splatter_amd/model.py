@@ -373,7 +373,7 @@ class _FusedImageLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_total, _v_parts):
         if v_total is None:
-            return (None,) * 8
+            return (None,) * 11
         v_render, v_alpha = ctx.saved_tensors
         # the kernel wrote d(total)/d(render, alpha).  The usual upstream gradient is the cached unit tensor of
         # backward_fused() and needs no scaling pass; anything else (a weighted loss, a GradScaler) is applied
@@ -386,17 +386,30 @@ class QEDSplatterModel(nn.Module):
     """Mirror of QEDSplatterModel (model.py:50-321) for the render hot path."""
 
     def __init__(self, config: Optional[QEDSplatterModelConfig] = None, *, means: Tensor, scales: Tensor,
-                 quats: Tensor, opacities: Tensor, features_dc: Tensor, features_rest: Tensor):
+                 quats: Tensor, opacities: Tensor, features_dc: Tensor, features_rest: Tensor,
+                 separate_params: bool = False):
         super().__init__()
         self.config = config or QEDSplatterModelConfig()
         N = means.shape[0]
+        srcs = dict(means=means, scales=scales, quats=quats, opacities=opacities.reshape(N, 1),
+                    features_dc=features_dc.reshape(N, 3), features_rest=features_rest)
+        self.group_names = list(GROUP_ORDER)
+        self.step = 0
+        self.crop_box = None
+        self.camera_optimizer = None
+        if separate_params:
+            # Six independent tensors, as Nerfstudio's parent class holds them (model.py:12,50-58; one optimiser per
+            # group, config.py:44-68).  get_outputs / get_loss_dict / fused_loss run unchanged; what needs the flat
+            # layout (FlatAdam, Densifier, the data-parallel exchange) refuses.
+            self._flat = None
+            self.group_begin = []
+            self.gauss_params = nn.ParameterDict(
+                {n: nn.Parameter(srcs[n].detach().to(torch.float32).clone().contiguous()) for n in self.group_names})
+            return
         # One flat buffer holds all six groups (59 N floats for SH degree 3); the six Parameters are
         # leaf views into it.  _ProjectSH.backward lays the six gradients out in the same order in
         # one allocation, so the data-parallel all-reduce (SURVEY 8e) and the fused Adam step each
         # touch a single contiguous range and nothing is ever concatenated.
-        srcs = dict(means=means, scales=scales, quats=quats, opacities=opacities.reshape(N, 1),
-                    features_dc=features_dc.reshape(N, 3), features_rest=features_rest)
-        self.group_names = list(GROUP_ORDER)
         total = sum(srcs[n].numel() for n in self.group_names)
         flat = torch.empty(total, dtype=torch.float32, device=means.device)
         self.group_begin: List[int] = [0]
@@ -411,9 +424,6 @@ class QEDSplatterModel(nn.Module):
             self.group_begin.append(off)
         self._flat = flat
         self.gauss_params = nn.ParameterDict(params)          # same container name as SplatfactoModel
-        self.step = 0
-        self.crop_box = None
-        self.camera_optimizer = None
 
     def rebind_flat(self, flat: Tensor, n_points: int) -> None:
         """Adopt a new flat parameter buffer (densification changes N): the six Parameters are
@@ -444,11 +454,14 @@ class QEDSplatterModel(nn.Module):
 
     @property
     def device(self):
-        return self._flat.device
+        return self.gauss_params["means"].device
 
     @property
     def flat_params(self) -> Tensor:
         """All six groups as one contiguous [59 N] tensor (aliases the Parameters)."""
+        if self._flat is None:
+            raise RuntimeError("this model holds six separate Parameters (separate_params=True): there is no flat buffer "
+                               "(FlatAdam, Densifier and the data-parallel exchange need the default layout)")
         return self._flat
 
     def flat_grad(self) -> Optional[Tensor]:
@@ -457,6 +470,8 @@ class QEDSplatterModel(nn.Module):
         grads = [self.gauss_params[n].grad for n in self.group_names]
         if any(g is None for g in grads):
             return None
+        if self._flat is None:
+            self.flat_params                     # (raises: no flat layout)
         g0 = grads[0]
         base, ok = g0.storage_offset(), True
         for g, beg in zip(grads, self.group_begin):
@@ -484,6 +499,8 @@ class QEDSplatterModel(nn.Module):
         buffer on the new device and re-create the Parameters as views of it (optimisers must be rebuilt, as after
         any parameter replacement; FlatAdam / QedAdam detect a stale buffer and raise)."""
         super()._apply(fn, *args, **kwargs)
+        if self._flat is None:
+            return self
         ps = [self.gauss_params[n] for n in self.group_names]
         if any(p.data_ptr() != self._flat.data_ptr() + 4 * b or p.device != self._flat.device
                for p, b in zip(ps, self.group_begin)):
@@ -756,7 +773,12 @@ class QEDSplatterModel(nn.Module):
             return torch.nn.functional.interpolate(img.permute(2, 0, 1)[None].float(), size=size, mode="bilinear",
                                                    align_corners=False, antialias=False)[0].permute(1, 2, 0)
 
-        gt_rgb = self.get_gt_img(resize(batch["image"]))[..., :3]
+        if d <= 1:
+            gt_rgb = self.get_gt_img(batch["image"])[..., :3]              # (the conversion get_loss_dict will reuse)
+        else:
+            # model.py:131-135 resizes the batch image itself -- NOT through get_gt_img, which would halve it again
+            img = batch["image"]
+            gt_rgb = resize(img.float() / 255.0 if img.dtype == torch.uint8 else img).to(self.device)[..., :3]
         pred_rgb = outputs["rgb"][0] if outputs["rgb"].dim() == 4 else outputs["rgb"]
         has_depth = "depth_image" in batch and outputs.get("depth") is not None
         gt_depth = resize(batch["depth_image"]).to(self.device) if has_depth else None
@@ -836,18 +858,25 @@ class QEDSplatterModel(nn.Module):
         tick = None
         if optimizer is not None and torch.is_grad_enabled() and cfg.ssim_lambda > 0.0:
             tick = optimizer.take_tick()
-        render, alpha, self.info = rasterization(
-            means=self.means, quats=self.quats, scales=self.scales, opacities=self.opacities, colors=colors,
-            viewmats=viewmat, Ks=K, width=W, height=H, tile_size=16, packed=False, near_plane=0.01, far_plane=1e10,
-            render_mode="RGB+D", sh_degree=deg, sparse_grad=False, absgrad=True,
-            rasterize_mode=cfg.rasterize_mode, _flags=flags, _sh_rest=sh_rest, _sync=sync, _vsplat_holder=holder,
-            _c2w=cam_c2w)
-        self.xys = self.info["means2d"]
-        self.radii = self.info["radii"][0]
-        self.last_viewmat, self.last_sh_degree = viewmat, deg
-        total, parts = _FusedImageLoss.apply(render, alpha, bg.contiguous(), gt_rgb, gt_depth, mask,
-                                             float(cfg.ssim_lambda), cfg.depth_lambda,
-                                             holder if torch.is_grad_enabled() else None, self.num_points, tick)
+        try:
+            render, alpha, self.info = rasterization(
+                means=self.means, quats=self.quats, scales=self.scales, opacities=self.opacities, colors=colors,
+                viewmats=viewmat, Ks=K, width=W, height=H, tile_size=16, packed=False, near_plane=0.01, far_plane=1e10,
+                render_mode="RGB+D", sh_degree=deg, sparse_grad=False, absgrad=True,
+                rasterize_mode=cfg.rasterize_mode, _flags=flags, _sh_rest=sh_rest, _sync=sync, _vsplat_holder=holder,
+                _c2w=cam_c2w)
+            self.xys = self.info["means2d"]
+            self.radii = self.info["radii"][0]
+            self.last_viewmat, self.last_sh_degree = viewmat, deg
+            total, parts = _FusedImageLoss.apply(render, alpha, bg.contiguous(), gt_rgb, gt_depth, mask,
+                                                 float(cfg.ssim_lambda), cfg.depth_lambda,
+                                                 holder if torch.is_grad_enabled() else None, self.num_points, tick)
+        except BaseException:
+            # the launch that would have advanced the optimiser's device step state did not happen: the optimiser
+            # must tick for itself on the next step (otherwise its counter would be off by one from here on)
+            if tick is not None:
+                optimizer.drop_tick()
+            raise
         return {"loss": total, "main_loss": parts[0], "depth_loss": parts[1]}
 
 
@@ -890,7 +919,7 @@ class FlatAdam:
         self.betas, self.eps = betas, eps
         self.exp_avg = torch.zeros_like(model.flat_params)
         self.exp_avg_sq = torch.zeros_like(model.flat_params)
-        self._flat_ptr = model.flat_params.data_ptr()
+        self._flat_ref = model.flat_params         # (held: a freed buffer's address can be handed out again)
         self.t = 0
         # device-resident step state + learning rates: what a captured hipGraph replays against
         self.dev_state = torch.zeros(4, dtype=torch.float32, device=model.device)
@@ -906,6 +935,7 @@ class FlatAdam:
         i = self.model.group_names.index("means")
         t = L.AdamTick()
         t.dev_state, t.beta1, t.beta2 = self.dev_state.data_ptr(), self.betas[0], self.betas[1]
+        t.skip_flag = self._skip()
         if self.means_schedule is not None:
             lr_final, max_steps = self.means_schedule
             t.dev_lr_slot = self.dev_lr[i:i + 1].data_ptr()
@@ -916,7 +946,38 @@ class FlatAdam:
         return t
 
     def drop_tick(self) -> None:
-        """Forget a tick handed out by take_tick() whose launch never happened (a failed graph capture)."""
+        """Forget a tick handed out by take_tick() whose launch never happened (a failed graph capture, an exception
+        between take_tick() and the loss launch)."""
+        self._ticked = False
+
+    def _skip(self) -> int:
+        """``skip_flag`` of the Adam entry points: the binning overflow word of this device (a frame whose intersection
+        list overflowed renders empty; a step enqueued behind it without a host round trip must be a no-op)."""
+        from .rasterization import _workspace
+        return _workspace(self.model.device).skip_flag_ptr()
+
+    # ---- checkpointing (config.py:29 steps_per_save: the trainer saves every optimiser's state_dict) ----
+    def state_dict(self) -> Dict:
+        return {"t": self.t, "lr": list(self.lr), "betas": tuple(self.betas), "eps": self.eps,
+                "means_schedule": self.means_schedule, "means_lr_init": self._means_lr_init,
+                "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
+                "dev_state": self.dev_state.clone(), "dev_lr": self.dev_lr.clone(), "numel": self.exp_avg.numel()}
+
+    def load_state_dict(self, sd: Dict) -> None:
+        if int(sd["numel"]) != self.model.flat_params.numel():
+            raise ValueError(f"FlatAdam.load_state_dict: the checkpoint holds moments for {sd['numel']} parameters, the "
+                             f"model has {self.model.flat_params.numel()} (load the model's Gaussians first)")
+        self._check("load_state_dict", compact_ok=True)
+        self.t = int(sd["t"])
+        self.betas, self.eps = tuple(sd["betas"]), float(sd["eps"])
+        self.means_schedule, self._means_lr_init = sd["means_schedule"], float(sd["means_lr_init"])
+        for i, lr in enumerate(sd["lr"]):
+            self.lr[i] = float(lr)
+            self._lr[i] = float(lr)
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.dev_state.copy_(sd["dev_state"])
+        self.dev_lr.copy_(sd["dev_lr"])
         self._ticked = False
 
     def set_lr(self, name: str, lr: float) -> None:
@@ -933,13 +994,13 @@ class FlatAdam:
         begins = list(self.model.group_begin)
         self._begin = (C.c_int64 * len(begins))(*begins)
         self.exp_avg, self.exp_avg_sq = exp_avg, exp_avg_sq
-        self._flat_ptr = self.model.flat_params.data_ptr()
+        self._flat_ref = self.model.flat_params
 
     def _check(self, who: str, compact_ok: bool = False) -> None:
         """Refuse to train on garbage: a flat buffer the Parameters no longer alias (model.to() / densification
         without rebind()), or compact SH gradients consumed by a plain step."""
         m = self.model
-        if m.flat_params.data_ptr() != self._flat_ptr or m.flat_params.device != self.exp_avg.device:
+        if m.flat_params is not self._flat_ref or m.flat_params.device != self.exp_avg.device:
             raise RuntimeError(f"FlatAdam.{who}: the model adopted a new flat parameter buffer (model.to() or "
                                "densification); call rebind(exp_avg, exp_avg_sq) or build a new optimiser")
         if not compact_ok and getattr(m, "last_compact", False):
@@ -974,7 +1035,7 @@ class FlatAdam:
         L.check(L.load().qed_adam_step(L.ptr(p[lo:hi]), L.ptr(g[lo:hi]), L.ptr(self.exp_avg[lo:hi]),
                                        L.ptr(self.exp_avg_sq[lo:hi]), len(self.lr), C.cast(h_begin, C.c_void_p),
                                        C.cast(self._lr, C.c_void_p), self.betas[0], self.betas[1], self.eps, self.t,
-                                       _stream()), "qed_adam_step")
+                                       self._skip(), _stream()), "qed_adam_step")
 
     @torch.no_grad()
     def step(self, device_state: bool = False, fused_sh: bool = False, part: int = 3) -> None:
@@ -1032,17 +1093,18 @@ class FlatAdam:
                 L.ptr(self.dev_lr) if device_state else None, self.betas[0], self.betas[1], self.eps, self.t,
                 L.ptr(self.dev_state) if device_state else None, *sched, m.num_points, int(m.last_sh_degree or 0),
                 L.ptr(m.means), n_views, L.ptr(viewmats), vm_stride, L.ptr(v_views), view_stride, float(scale),
-                int(part), _stream()), "qed_adam_step_sh")
+                int(part), self._skip(), _stream()), "qed_adam_step_sh")
             return
         if device_state:
             L.check(lib.qed_adam_step_dev(L.ptr(p), L.ptr(g), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
                                           len(self.lr), C.cast(self._begin, C.c_void_p), L.ptr(self.dev_lr),
-                                          self.betas[0], self.betas[1], self.eps, L.ptr(self.dev_state), _stream()),
-                    "qed_adam_step_dev")
+                                          self.betas[0], self.betas[1], self.eps, L.ptr(self.dev_state), self._skip(),
+                                          _stream()), "qed_adam_step_dev")
             return
         L.check(lib.qed_adam_step(L.ptr(p), L.ptr(g), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
                                   len(self.lr), C.cast(self._begin, C.c_void_p), C.cast(self._lr, C.c_void_p),
-                                  self.betas[0], self.betas[1], self.eps, self.t, _stream()), "qed_adam_step")
+                                  self.betas[0], self.betas[1], self.eps, self.t, self._skip(), _stream()),
+                "qed_adam_step")
 
 
 class _SharedFlatState:
@@ -1095,10 +1157,15 @@ class QedAdamSet:
             steps[beg] = old.t.get(old_off, 0) if old is not None else 0
             opt.param_groups[0]["params"] = [m.gauss_params[name]]
             opt._shared = None
+            opt.state.clear()                                    # (views of the old moments, keyed by the old Parameter)
         st = self._state()                                       # a fresh shared state over the new flat buffer
         assert exp_avg.numel() == st.numel == exp_avg_sq.numel()
         st.exp_avg, st.exp_avg_sq = exp_avg, exp_avg_sq
         st.t.update(steps)
+        for opt in self.optimizers.values():                     # optimizer.state[param]: views of the adopted moments
+            opt.state.clear()
+            if opt._shared is st:
+                opt._expose_views(st)
 
     def _state_or_none(self) -> Optional[_SharedFlatState]:
         return self.optimizers[self.model.group_names[0]]._shared
@@ -1108,17 +1175,29 @@ _FLAT_STATES: "weakref.WeakValueDictionary[int, _SharedFlatState]" = weakref.Wea
 _ALL_QED_ADAMS: "weakref.WeakSet[QedAdam]" = weakref.WeakSet()
 
 
-class QedAdam(torch.optim.Optimizer):
-    """``torch.optim.Adam`` semantics (no weight decay, no amsgrad) for Parameters that are views of ONE flat buffer
-    -- the six Gaussian groups of ``QEDSplatterModel`` -- as a ``torch.optim.Optimizer`` subclass, so that
-    Nerfstudio's ``AdamOptimizerConfig(_target=QedAdam, lr=..., eps=1e-15)`` builds it unchanged for every group
-    of config.py:44-68 and its schedulers / GradScaler / checkpointing keep working (``param_groups[0]["lr"]`` is
-    read at every step).
+def _skip_flag(device) -> int:
+    from .rasterization import _workspace
+    return _workspace(device).skip_flag_ptr()
 
-    Nerfstudio creates one optimiser PER GROUP and steps them one after the other; the instances of one flat
-    buffer find each other through a registry and the LAST one to be stepped launches a single ``qed_adam_step``
-    over the whole buffer with one rate per group (one pass at HBM speed instead of six times ~10 eager launches).
-    A group that is stepped twice before the others, or ``flush()``, updates just the waiting groups' ranges."""
+
+class QedAdam(torch.optim.Optimizer):
+    """``torch.optim.Adam`` semantics (no weight decay, no amsgrad) for ONE parameter group of the Gaussians, as a
+    ``torch.optim.Optimizer`` subclass: Nerfstudio's ``AdamOptimizerConfig(_target=QedAdam, lr=..., eps=1e-15)`` builds
+    it unchanged for every group of config.py:44-68 and its schedulers / GradScaler / checkpointing keep working
+    (``param_groups[0]["lr"]`` is read at every step).  Two layouts, told apart by the Parameter's storage:
+
+    * **separately held Parameters** (what Nerfstudio's parent class keeps: six tensors in a ``ParameterDict``,
+      model.py:12,50-58): the moments live in ``self.state[param]`` exactly as ``torch.optim.Adam`` keeps them
+      (``step`` / ``exp_avg`` / ``exp_avg_sq``), so code that rewrites them when the number of Gaussians changes (the
+      parent's dup / remove-from-optimiser routines, gsplat's strategies) works unchanged; every ``step()`` is one
+      ``qed_adam_step`` launch over that tensor.
+    * **views of ONE flat buffer** (this package's ``QEDSplatterModel``): the instances of one buffer find each other
+      through a registry and the LAST one to be stepped launches a single ``qed_adam_step`` over the whole buffer with
+      one rate per group (one pass at HBM speed instead of six times ~10 eager launches).  The shared moments are
+      visible as VIEWS under ``self.state[param]``; replacing them there is refused with an error that names
+      ``densify.Densifier`` / ``QedAdamSet`` (which rewrite parameters and moments in one pass).  A group that is
+      stepped twice before the others, ``zero_grad()``, ``state_dict()`` or ``flush()`` update just the waiting groups'
+      ranges -- so a group whose ``.grad`` is None in some iteration never delays the others past that iteration."""
 
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
         if weight_decay != 0.0:
@@ -1126,19 +1205,28 @@ class QedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         ps = [p for g in self.param_groups for p in g["params"]]
         if len(ps) != 1:
-            raise ValueError("QedAdam steps one parameter group of the flat buffer per instance "
+            raise ValueError("QedAdam steps one parameter group per instance "
                              "(Nerfstudio builds one optimiser per group name)")
         self._shared: Optional[_SharedFlatState] = None
         _ALL_QED_ADAMS.add(self)
 
-    # -- registry ---------------------------------------------------------------------------------------
+    # -- layout -----------------------------------------------------------------------------------------
     def _param(self) -> Tensor:
         return self.param_groups[0]["params"][0]
 
+    @staticmethod
+    def _is_flat_view(p: Tensor) -> bool:
+        """A view into a larger allocation (the flat buffer) rather than a tensor that owns its storage."""
+        return p.storage_offset() != 0 or p.untyped_storage().nbytes() > 4 * p.numel()
+
+    @staticmethod
+    def _require_gpu(p: Tensor) -> None:
+        if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+            raise L.QedSplatError("QedAdam needs contiguous float32 GPU parameters (there is no CPU path)")
+
     def _attach(self) -> _SharedFlatState:
         p = self._param()
-        if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
-            raise L.QedSplatError("QedAdam needs contiguous float32 GPU parameters")
+        self._require_gpu(p)
         base = p.untyped_storage().data_ptr()
         st = _FLAT_STATES.get(base)
         if st is None or self._shared is not st:
@@ -1159,7 +1247,26 @@ class QedAdam(torch.optim.Optimizer):
         off = p.storage_offset()
         st.members[off] = self
         st.t.setdefault(off, 0)
+        self._expose_views(st)
         return st
+
+    def _expose_views(self, st: _SharedFlatState) -> None:
+        """``self.state[param]`` in torch.optim.Adam's layout, as views of the shared moments."""
+        p = self._param()
+        off, n = p.storage_offset(), p.numel()
+        cur = self.state.get(p)
+        m, v = st.exp_avg[off:off + n].view(p.shape), st.exp_avg_sq[off:off + n].view(p.shape)
+        if cur is not None and len(cur) and "exp_avg" in cur:
+            if cur["exp_avg"].data_ptr() == m.data_ptr() and cur["exp_avg_sq"].data_ptr() == v.data_ptr() \
+                    and cur["exp_avg"].shape == p.shape:
+                return
+            raise RuntimeError(
+                "QedAdam: optimizer.state[param] of a flat-buffer group was replaced from outside (the parent class's "
+                "dup / remove-from-optimiser routines do that).  With Parameters that are views of one flat buffer the "
+                "number of Gaussians is changed by qed_splatter_amd.densify.Densifier(model, QedAdamSet(model, "
+                "optimizers)), which rewrites parameters and both moments in one pass; or hold the six Parameters as "
+                "separate tensors, in which case QedAdam keeps torch.optim.Adam's own per-parameter state.")
+        self.state[p] = {"step": torch.tensor(float(st.t.get(off, 0))), "exp_avg": m, "exp_avg_sq": v}
 
     # -- stepping ---------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -1167,6 +1274,9 @@ class QedAdam(torch.optim.Optimizer):
         loss = closure() if closure is not None else None
         p = self._param()
         if p.grad is None:
+            return loss
+        if not self._is_flat_view(p):
+            self._step_own(p)
             return loss
         st = self._attach()
         off = p.storage_offset()
@@ -1177,11 +1287,50 @@ class QedAdam(torch.optim.Optimizer):
             self._launch(st, sorted(st.pending))
         return loss
 
+    def _step_own(self, p: Tensor) -> None:
+        """A Parameter that owns its storage: torch.optim.Adam's state layout, one fused launch."""
+        import ctypes as C
+        self._require_gpu(p)
+        g = p.grad
+        grp = self.param_groups[0]
+        state = self.state[p]
+        if len(state) == 0:
+            state["step"] = torch.tensor(0.0)
+            state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        m, v = state["exp_avg"], state["exp_avg_sq"]
+        if m.shape != p.shape or v.shape != p.shape:
+            raise RuntimeError(f"QedAdam: the moments in optimizer.state ({tuple(m.shape)}) do not match the parameter "
+                               f"({tuple(p.shape)}): resize both when the number of Gaussians changes")
+        if not (m.is_contiguous() and v.is_contiguous()):
+            m = state["exp_avg"] = m.contiguous()
+            v = state["exp_avg_sq"] = v.contiguous()
+        state["step"] += 1
+        t = int(state["step"])
+        if g.dtype != torch.float32 or not g.is_contiguous():
+            g = g.to(torch.float32).contiguous()
+        beta1, beta2 = grp["betas"]
+        if (p.data_ptr() | m.data_ptr() | v.data_ptr()) % 16 or g.data_ptr() % 4:
+            raise L.QedSplatError("QedAdam: parameter / moment tensors must be 16-byte aligned")
+        n = p.numel()
+        h_begin = (C.c_int64 * 2)(0, n)
+        h_lr = (C.c_float * 1)(float(grp["lr"]))
+        L.check(L.load().qed_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), 1,
+                                       C.cast(h_begin, C.c_void_p), C.cast(h_lr, C.c_void_p), float(beta1), float(beta2),
+                                       float(grp["eps"]), t, _skip_flag(p.device), _stream()), "qed_adam_step")
+
     def flush(self) -> None:
         """Launch the update of the groups that have called step() but are still waiting for the others."""
         st = self._shared
         if st is not None and st.pending:
             self._launch(st, sorted(st.pending))
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        # a waiting update reads .grad at launch time: launch it before the gradients go away (a group that skipped
+        # this iteration -- .grad None, or a GradScaler that found an inf for that optimiser -- must not hold the
+        # others' update back into the next iteration's gradients)
+        self.flush()
+        super().zero_grad(set_to_none=set_to_none)
 
     @staticmethod
     def _launch(st: _SharedFlatState, offs) -> None:
@@ -1189,7 +1338,8 @@ class QedAdam(torch.optim.Optimizer):
         lib = L.load()
         members = [st.members[o] for o in offs]
         ps = [m._param() for m in members]
-        g0 = ps[0].grad
+        for mem in members:
+            mem._expose_views(st)              # (also refuses moments that were replaced from outside)
         # maximal runs of groups that are adjacent in the flat buffer, share betas / eps / step count and whose
         # gradients are adjacent views of one allocation (what _ProjectSH.backward produces): one launch per run
         runs, cur = [], [0]
@@ -1209,6 +1359,7 @@ class QedAdam(torch.optim.Optimizer):
                 cur = [i]
         runs.append(cur)
         stream = _stream()
+        skip = _skip_flag(ps[0].device)
         for run in runs:
             first, last = run[0], run[-1]
             lo, hi = offs[first], offs[last] + ps[last].numel()
@@ -1216,9 +1367,9 @@ class QedAdam(torch.optim.Optimizer):
             beta1, beta2 = members[first].param_groups[0]["betas"]
             eps = members[first].param_groups[0]["eps"]
             t = st.t[offs[first]] + 1
-            if lo % 4 != 0 or g.data_ptr() % 16 != 0 or not g.is_contiguous() or g.dtype != torch.float32:
-                # a lone group whose range or gradient is not 16-byte aligned (only when the groups are stepped out
-                # of step with each other, or N is not a multiple of 4): the same update with eager torch ops
+            if lo % 4 != 0 or g.data_ptr() % 4 != 0 or not g.is_contiguous() or g.dtype != torch.float32:
+                # a lone group whose range is not 16-byte aligned (only when the groups are stepped out of step with
+                # each other and N is not a multiple of 4): the same update with eager torch ops
                 for i in run:
                     o, n = offs[i], ps[i].numel()
                     gi = ps[i].grad.reshape(-1).to(torch.float32)
@@ -1228,6 +1379,7 @@ class QedAdam(torch.optim.Optimizer):
                     denom = (v.sqrt() / math.sqrt(1 - beta2 ** t)).add_(eps)
                     ps[i].data.reshape(-1).addcdiv_(m, denom, value=-st.pending[offs[i]] / (1 - beta1 ** t))
                     st.t[offs[i]] = t
+                    members[i].state[ps[i]]["step"].fill_(float(t))
                 continue
             begins = [offs[i] - lo for i in run] + [hi - lo]
             lrs = [st.pending[offs[i]] for i in run]
@@ -1235,22 +1387,27 @@ class QedAdam(torch.optim.Optimizer):
             h_lr = (C.c_float * len(lrs))(*lrs)
             flat = st._keepalive_flat
             L.check(lib.qed_adam_step(L.ptr(flat[lo:hi]), g.data_ptr(), L.ptr(st.exp_avg[lo:hi]), L.ptr(st.exp_avg_sq[lo:hi]),
-                                      len(lrs), C.cast(h_begin, C.c_void_p), C.cast(h_lr, C.c_void_p), beta1, beta2, eps,
-                                      t, stream), "qed_adam_step")
+                                      len(lrs), C.cast(h_begin, C.c_void_p), C.cast(h_lr, C.c_void_p), float(beta1),
+                                      float(beta2), float(eps), t, skip, stream), "qed_adam_step")
             for i in run:
                 st.t[offs[i]] = t
+                members[i].state[ps[i]]["step"].fill_(float(t))
         st.pending.clear()
 
     def defaults_key(self):
         g = self.param_groups[0]
         return (tuple(g["betas"]), float(g["eps"]))
 
-    # -- checkpointing: this group's slice of the shared moments, in torch.optim.Adam's layout -----------
+    # -- checkpointing: torch.optim.Adam's layout in both cases ------------------------------------------
     def state_dict(self):
+        self.flush()
+        p = self._param()
+        if not self._is_flat_view(p):
+            return super().state_dict()
         sd = super().state_dict()
         st = self._shared
         if st is not None:
-            p = self._param()
+            # copies of this group's slice (a view would drag the whole flat buffer into the checkpoint)
             off, n = p.storage_offset(), p.numel()
             sd["state"] = {0: {"step": torch.tensor(float(st.t.get(off, 0))),
                                "exp_avg": st.exp_avg[off:off + n].view(p.shape).clone(),
@@ -1258,14 +1415,20 @@ class QedAdam(torch.optim.Optimizer):
         return sd
 
     def load_state_dict(self, state_dict):
+        p = self._param()
+        if not self._is_flat_view(p):
+            super().load_state_dict(state_dict)
+            stt = self.state.get(p)
+            if stt is not None and "step" in stt and torch.is_tensor(stt["step"]):
+                stt["step"] = stt["step"].detach().to("cpu", torch.float32).reshape(())    # host counter, as created
+            return
         state = state_dict.get("state", {})
         super().load_state_dict({"state": {}, "param_groups": state_dict["param_groups"]})
+        st = self._attach()
         if state:
-            st = self._attach()
-            p = self._param()
             off, n = p.storage_offset(), p.numel()
             s0 = state[0] if 0 in state else next(iter(state.values()))
             st.exp_avg[off:off + n] = s0["exp_avg"].reshape(-1).to(st.exp_avg)
             st.exp_avg_sq[off:off + n] = s0["exp_avg_sq"].reshape(-1).to(st.exp_avg_sq)
             st.t[off] = int(s0["step"])
-
+            self.state[p]["step"].fill_(float(st.t[off]))

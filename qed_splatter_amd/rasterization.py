@@ -21,6 +21,7 @@ gradient is ever repacked on the hot path.
 from __future__ import annotations
 
 import math
+import warnings
 import weakref
 from typing import Dict, Optional, Tuple
 
@@ -51,10 +52,19 @@ class _Workspace:
 
     Key/value buffers are taken from PyTorch's caching allocator per call (sized by a capacity
     that only grows) and stay alive until that call's backward has run.  The kernels read the
-    actual count M from device memory, so launches never need M on the host.  If a frame overflows
-    the capacity (status word set by qed_isect_scan) a synchronous call is redone with a larger
-    buffer; an asynchronous call reports it at the next call.
+    actual count M from device memory, so launches never need M on the host.
+
+    The capacity is calibrated per SHAPE ``(width, height, N, C)``: the first call of a shape reads M back (one host
+    read) whatever the caller asked for -- the reference's resolution schedule quadruples the pixel count at steps 3000
+    and 6000 (model.py:244-250) and every densification changes N (config.py:40-41), and either can multiply M.  Calls
+    of a calibrated shape may run without the read-back (``_sync=False``); their M still comes back, one call late
+    (``poll_pending``), and keeps the capacity at ``HEADROOM`` x the longest list seen.  Should a frame overflow all
+    the same, it renders empty, the status word makes the optimiser launches enqueued behind it no-ops
+    (``qed_adam_step*``'s ``skip_flag``), and the next call regrows the buffer, warns and reads M back again: no
+    exception a step late, no update from an empty frame.
     """
+
+    HEADROOM = 2.0          # capacity / longest list seen: grids are sized by it but only M entries are ever touched
 
     def __init__(self, device):
         self.device = device
@@ -63,12 +73,33 @@ class _Workspace:
         self.words = torch.zeros(1 + L.STATUS_WORDS, dtype=torch.int32, device=device)
         self.n_isect = self.words[:1]
         self.status = self.words[1:]
-        self.pending = None          # (pinned host copy of [M, overflow], event) of an async call
+        self.pending = None          # (pinned host copy of [M, overflow, watchdog], event, shape key) of an async call
+        self.m_seen: Dict[tuple, int] = {}   # shape key -> longest list read back for that shape
+        self.force_sync = False      # the next call reads M back (an asynchronous frame overflowed)
+        self.overflows = 0           # asynchronous frames that rendered empty (diagnostics / tests)
 
-    def poll_pending(self):
+    def reset(self) -> None:
+        """Forget every calibration (the next call of any shape reads M back and sizes the buffer afresh)."""
+        self.poll_pending()
+        self.capacity, self.m_seen, self.force_sync = 0, {}, False
+
+    def calibrated(self, key) -> bool:
+        return self.capacity > 0 and key in self.m_seen and not self.force_sync
+
+    def saw(self, key, M: int) -> None:
+        self.m_seen[key] = max(self.m_seen.get(key, 0), int(M))
+        if len(self.m_seen) > 64:                                   # (cameras of many sizes: keep the table small)
+            self.m_seen.pop(next(iter(self.m_seen)))
+        self.capacity = max(self.capacity, int(M * self.HEADROOM) + 4096)
+
+    def skip_flag_ptr(self) -> int:
+        """Device address of the overflow word: what the optimiser launches take as ``skip_flag``."""
+        return self.status.data_ptr()
+
+    def poll_pending(self) -> None:
         if self.pending is None:
             return
-        host, ev = self.pending
+        host, ev, key = self.pending
         ev.synchronize()
         self.pending = None
         M, overflow, watchdog = int(host[0]), int(host[1]), int(host[2])
@@ -77,12 +108,18 @@ class _Workspace:
             raise L.QedSplatError("the radix-sort look-back watchdog fired in the previous asynchronous rasterization: "
                                   "that frame's list was mis-sorted")
         if overflow:
+            # that frame rendered empty and the optimiser launches behind it did nothing (skip_flag); clear the word
+            # (stream-ordered behind those launches), make room and read M back on the call that follows
             self.status.zero_()
-            self.capacity = int(overflow * 1.5) + 4096
-            raise L.QedSplatError(
-                f"the previous asynchronous rasterization needed {overflow} tile intersections, more than the "
-                f"buffer capacity; that frame rendered empty.  Capacity raised to {self.capacity}.")
-        self.capacity = max(self.capacity, int(M * 1.25) + 4096)
+            self.overflows += 1
+            self.force_sync = True
+            old = self.capacity
+            self.saw(key, overflow)
+            warnings.warn(f"qed_splatter_amd: an asynchronous rasterization needed {overflow} tile intersections, more "
+                          f"than the buffer held ({old}); that frame rendered empty and its optimiser step was skipped "
+                          f"on the device.  Capacity raised to {self.capacity}.", RuntimeWarning, stacklevel=3)
+            return
+        self.saw(key, M)
 
 
 _WORKSPACES: Dict[int, _Workspace] = {}
@@ -249,38 +286,48 @@ def _packed_vsplat(C, N, v_means2d, v_depths, v_conics, v_opac, v_rgb, dev) -> T
 # ==================================================================================================
 # tile binning + sort + compositing
 # ==================================================================================================
-def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, tile_w, tile_h, sync=True, splats=None):
-    """Two-stage tile binning (qed_bin_tiles): depth sort of the slots, emit in depth order, stable
-    sort on the tile bits, tile offsets -- one C call.
+def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, tile_w, tile_h, sync=True, splats=None,
+                  size=None):
+    """Tile binning (qed_bin_tiles): one C call that leaves the list sorted by (camera, tile, depth) and the tile
+    offsets.
 
-    Returns (isect_ids, flatten_ids, offsets, M).  With ``sync=False`` (after a first calibrating
-    call) nothing is read back: M and isect_ids are None and flatten_ids keeps its capacity length.
+    Returns (isect_ids, flatten_ids, offsets, M).  With ``sync=False`` -- honoured only for a shape
+    ``(width, height, N, C)`` whose capacity has been calibrated by a synchronous call (_Workspace) -- nothing is read
+    back: M and isect_ids are None and flatten_ids keeps its capacity length.
     """
     lib = L.load()
     dev = means2d.device
     ws = _workspace(dev)
     n_tiles = tile_w * tile_h
+    key = (tuple(size) if size is not None else (tile_w, tile_h), N, C)
     n_isect = ws.n_isect               # (read by the kernels of this call only; launches are stream-ordered)
     offsets = torch.empty(C * n_tiles + 1, dtype=torch.int32, device=dev)
     capturing = torch.cuda.is_current_stream_capturing()
     if capturing:
         # inside a hipGraph capture nothing may touch the host: capacity is frozen at its calibrated
         # value and the overflow word is polled by the replaying code (graph.GraphedTrainStep)
-        if ws.capacity == 0:
-            raise L.QedSplatError("run one eager call before capturing: it calibrates the intersection capacity")
+        if ws.capacity == 0 or key not in ws.m_seen:
+            raise L.QedSplatError("run one eager call of this shape (image size, number of Gaussians, cameras) before "
+                                  "capturing: it calibrates the intersection capacity")
         sync = False
     else:
         ws.poll_pending()
+        if not ws.calibrated(key):
+            sync = True                                   # first call of a shape, or the call after an overflow
     if ws.capacity == 0:
-        sync = True                                   # first call calibrates the capacity
         ws.capacity = max(1 << 16, 8 * C * N)
+    # which pipeline (both give the same list bit for bit): by the longest list this shape has produced, not by the
+    # (generously padded) capacity the library's own QED_BIN_AUTO would go by
+    mode = L.bin_mode()
+    if mode == L.BIN_AUTO and ws.m_seen.get(key, 0) > 0:
+        mode = L.BIN_TILE_SORT if int(1.25 * ws.m_seen[key]) <= 1024 * C * n_tiles else L.BIN_TWO_STAGE
     for _attempt in range(2):
         cap = ws.capacity
         flatten_ids = torch.empty(cap, dtype=torch.int32, device=dev)
         isect_ids = torch.empty(cap, dtype=torch.int64, device=dev) if sync else None
         scratch = torch.empty(int(lib.qed_bin_workspace_bytes(C * N, cap)), dtype=torch.uint8, device=dev)
         L.check(lib.qed_bin_tiles(N, C, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(tiles_per_gauss), L.ptr(splats),
-                                  L.ptr(block_sums), tile_w, tile_h, cap, L.bin_mode(), L.ptr(flatten_ids), L.ptr(offsets),
+                                  L.ptr(block_sums), tile_w, tile_h, cap, mode, L.ptr(flatten_ids), L.ptr(offsets),
                                   L.ptr(n_isect), L.ptr(isect_ids), L.ptr(scratch), scratch.numel(), L.ptr(ws.status),
                                   _stream()), "qed_bin_tiles")
         if capturing:
@@ -291,7 +338,7 @@ def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, til
             host.copy_(ws.words[:3], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-            ws.pending = (host, ev)
+            ws.pending = (host, ev, key)
             return None, flatten_ids, offsets, None
         # one host read: M, the overflow word and the look-back watchdog word
         host = ws.words[:3].tolist()
@@ -300,10 +347,11 @@ def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, til
             ws.status.zero_()
             raise L.QedSplatError("the radix-sort look-back watchdog fired: the list of this frame is mis-sorted")
         if overflow == 0:
-            ws.capacity = max(ws.capacity, int(M * 1.25) + 4096)
+            ws.saw(key, M)
+            ws.force_sync = False
             return isect_ids[:M], flatten_ids[:M], offsets, M
         ws.status.zero_()
-        ws.capacity = int(overflow * 1.25) + 4096
+        ws.saw(key, overflow)
     raise L.QedSplatError("intersection buffer overflow persisted after regrowth")
 
 
@@ -433,7 +481,8 @@ def rasterization(
     if (flags & L.F_TIGHT_TILES) and not use_packed:
         raise NotImplementedError("F_TIGHT_TILES needs tile grids of at most 1023 x 2047 tiles")
     isect_ids, flatten_ids, offsets, M = _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums,
-                                                       tile_w, tile_h, sync=_sync, splats=splats if use_packed else None)
+                                                       tile_w, tile_h, sync=_sync, splats=splats if use_packed else None,
+                                                       size=(int(width), int(height)))
     render, alpha, last_ids = _Composite.apply(means2d, conics, rgb, opac, depths if channels == 4 else None, splats,
                                                flatten_ids, offsets, backgrounds, int(width), int(height), tile_w,
                                                tile_h, channels, bool(absgrad), _vsplat_holder)

@@ -21,7 +21,7 @@ lrs = (C.c_float * 1)(1e-3)
 
 
 def branch_a():
-    L.check(lib.qed_adam_step(L.ptr(P), L.ptr(G), L.ptr(M), L.ptr(V), 1, begins, lrs, 0.9, 0.999, 1e-15, 5,
+    L.check(lib.qed_adam_step(L.ptr(P), L.ptr(G), L.ptr(M), L.ptr(V), 1, begins, lrs, 0.9, 0.999, 1e-15, 5, None,
                               torch.cuda.current_stream().cuda_stream), "adam")
 
 

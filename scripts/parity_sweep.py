@@ -3,16 +3,16 @@
 size, aspect, SH degree, rasterize mode, opacity / scale distributions and masks (a wider net than the fixed
 pytest cases).  Prints one line per case and a summary; exit code 1 on any violation.
 
-Losses must agree to 1e-4 (they agree to ~1e-7); gradients to 2e-4 of the group's largest magnitude (the tests'
-definition; normalising by the largest magnitude among the KEPT Gaussians only flagged two of 100 dense scenes
-where 14 % / 28 % of weak Gaussians were left and fp32 cancellation noise of 2e-11 / 3e-8 absolute showed),
-compared over the Gaussians that are NOT listed in a tile holding a "threshold pixel" -- a pixel where the fp32 kernels and the
-fp64 oracle may legitimately take different sides of a non-smooth point: alpha >= 1/255, T <= 1e-4 (the oracle's
-margin), the colour clamp to [0,1], and the kinks of the two L1 terms (prediction == target within rounding).
-Gaussians within rounding of the SH colour clamp or of the Jacobian clamp at the frustum rim are left out too.
-The first version of this sweep flagged 2 of 40 cases; both were L1-kink pixels (the gradient of every Gaussian
-under such a pixel changes by that pixel's share), none a defect.  QED_SWEEP_CASE=k reruns one case with the
-intermediate gradients of its worst Gaussian; QED_SWEEP_TIGHT=0 turns the tight tile lists off."""
+Losses must agree to 1e-4 (they agree to ~1e-7); the gradients of EVERY Gaussian to 2e-4 of the group's largest
+magnitude (the tests' definition).  Nothing is left out of the comparison (``kept=1.00`` is asserted): the pixels
+where the fp32 kernels and the fp64 oracle may legitimately take different sides of a non-smooth point -- alpha >=
+1/255, T <= 1e-4 (the oracle's margin), the colour clamp to [0,1], the kinks of the two L1 terms (prediction ==
+target within rounding) -- are found in a first pass and put into ``batch["mask"]``, which multiplies both images and
+both depths on BOTH sides (model.py:93-97 and the parent's loss): such a pixel passes no gradient, so the Gaussians
+that share its tile stay comparable (rounds 1-2 left them out: up to 93 % of a dense scene).  The two per-GAUSSIAN
+non-smooth points (the SH colour clamp max(0, c + 0.5), the Jacobian clamp at the frustum rim) are moved off their
+edge in the scene itself before either side runs.  QED_SWEEP_CASE=k reruns one case with the intermediate gradients
+of its worst Gaussian; QED_SWEEP_TIGHT=0 turns the tight tile lists off."""
 import os
 import sys
 import time
@@ -50,26 +50,44 @@ for case in (range(n_cases) if only is None else [only]):
     sc["opacities"] = sc["opacities"] + (float(torch.rand(1, generator=g)) - 0.7) * 4
     cfg = QEDSplatterModelConfig.synthetic(sh_degree=3, sh_degree_interval=1, rasterize_mode=mode,
                                  tight_tile_lists=os.environ.get("QED_SWEEP_TIGHT", "1") == "1")
-    model = QEDSplatterModel(cfg, **{k: sc[k].to(dev) for k in NAMES})
-    model.step = deg                                                                # active SH degree = deg
     K = sc["Ks"][0]
     cam = PinholeCameras(sc["camera_to_worlds"].to(dev), float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), w, h)
     batch = {"image": sc["gt_rgb"].to(dev), "depth_image": sc["gt_depth"].to(dev)}
-    mask = None
+    # per-Gaussian non-smooth points: move the (rare) Gaussian that sits within rounding of one off it, in the scene
+    with torch.no_grad():
+        vm = O.get_viewmat(sc["camera_to_worlds"].double())
+        campos = torch.linalg.inv(vm)[0, :3, 3]
+        fx, fy, cx, cy = K[0, 0].item(), K[1, 1].item(), K[0, 2].item(), K[1, 2].item()
+        lxp, lxn = (w - cx) / fx + 0.3 * 0.5 * w / fx, cx / fx + 0.3 * 0.5 * w / fx
+        lyp, lyn = (h - cy) / fy + 0.3 * 0.5 * h / fy, cy / fy + 0.3 * 0.5 * h / fy
+        n_moved = 0
+        for _ in range(4):
+            coeffs = torch.cat([sc["features_dc"].double()[:, None, :], sc["features_rest"].double()], dim=1)
+            pre = O.eval_sh(deg, sc["means"].double() - campos, coeffs[:, : (deg + 1) ** 2]) + 0.5
+            near_clamp = pre.abs().min(dim=-1).values < 1e-4
+            pc = (vm[0, :3, :3] @ sc["means"].double().T).T + vm[0, :3, 3]
+            rx, ry = pc[:, 0] / pc[:, 2], pc[:, 1] / pc[:, 2]
+            near_jac = ((rx - lxp).abs() < 1e-5) | ((rx + lxn).abs() < 1e-5) | ((ry - lyp).abs() < 1e-5) | ((ry + lyn).abs() < 1e-5)
+            if not bool((near_clamp | near_jac).any()):
+                break
+            n_moved += int((near_clamp | near_jac).sum())
+            sc["features_dc"][near_clamp] += 1e-2 / O.SH_C0
+            sc["means"][near_jac] *= 1.0 + 1e-3
+    model = QEDSplatterModel(cfg, **{k: sc[k].to(dev) for k in NAMES})
+    model.step = deg
+    mask = torch.ones(h, w, 1)
     if use_mask:
         mask = (torch.rand(h, w, 1, generator=g) > 0.4).float()
         batch["mask"] = mask.to(dev)
-    losses = model.fused_loss(cam, batch)
-    model.backward_fused(losses)
+    # pass 1 (no gradients): the radii of this GPU run and the oracle's forward with every pixel's margin
+    with torch.no_grad():
+        model.fused_loss(cam, batch)
     torch.cuda.synchronize()
     radii = model.info["radii"].cpu()
     ps = {k: sc[k].double().requires_grad_(True) for k in NAMES}
     out = O.splatfacto_outputs(ps["means"], ps["scales"], ps["quats"], ps["opacities"], ps["features_dc"], ps["features_rest"],
                                sc["camera_to_worlds"].double(), sc["Ks"].double(), w, h, sc["background"].double(),
                                sh_degree_to_use=deg, rasterize_mode=mode, radii_override=radii, return_margin=True)
-    l_rgb = O.main_loss(out["rgb"], sc["gt_rgb"].double(), cfg.ssim_lambda, mask.double() if mask is not None else None)
-    l_d = O.depth_l1_loss(out["depth"], sc["gt_depth"].double(), mask.double() if mask is not None else None, cfg.depth_lambda)
-    (l_rgb + l_d).backward()
     safe = out["info"]["margin"][0] > 1e-4
     # torch.clamp(rgb, 0, 1) (model.py:297) is one more threshold: a pre-clamp colour within fp32 rounding of 0
     # or 1 may pass its gradient on one side and not the other
@@ -85,34 +103,20 @@ for case in (range(n_cases) if only is None else [only]):
         n_clamp_edge = int(edge.sum())
         safe = safe & ~edge
     frac_safe = float(safe.float().mean())
+    # pass 2: the step under test, with those pixels masked out on both sides
+    mask = mask * safe[..., None].float()
+    batch["mask"] = mask.to(dev)
+    losses = model.fused_loss(cam, batch)
+    model.backward_fused(losses)
+    torch.cuda.synchronize()
+    assert torch.equal(model.info["radii"].cpu(), radii)
+    l_rgb = O.main_loss(out["rgb"], sc["gt_rgb"].double(), cfg.ssim_lambda, mask.double())
+    l_d = O.depth_l1_loss(out["depth"], sc["gt_depth"].double(), mask.double(), cfg.depth_lambda)
+    (l_rgb + l_d).backward()
     e_main = abs(float(losses["main_loss"]) - float(l_rgb)) / max(float(l_rgb), 1e-12)
     e_depth = abs(float(losses["depth_loss"]) - float(l_d)) / max(float(l_d), 1e-12)
-    # gradients: exclude Gaussians listed in tiles that hold an unsafe pixel (threshold flips)
     info = out["info"]
-    keep = torch.ones(n, dtype=torch.bool)
-    ys, xs = torch.nonzero(~safe, as_tuple=True)
-    if ys.numel():
-        tw = info["tile_width"]
-        offs = info["isect_offsets"].reshape(-1).tolist() + [info["flatten_ids"].numel()]
-        for t in set((ys // 16 * tw + xs // 16).tolist()):
-            keep[info["flatten_ids"][offs[t]:offs[t + 1]].long() % n] = False
-    # non-smooth points the pixel margins do not see: the SH colour clamp max(0, c + 0.5) and the Jacobian
-    # clamp of x/z, y/z at the frustum rim -- a Gaussian within fp32 rounding of either may legitimately get the
-    # other side's derivative
-    with torch.no_grad():
-        vm = O.get_viewmat(sc["camera_to_worlds"].double())
-        campos = torch.linalg.inv(vm)[0, :3, 3]
-        coeffs = torch.cat([sc["features_dc"].double()[:, None, :], sc["features_rest"].double()], dim=1)
-        pre = O.eval_sh(deg, sc["means"].double() - campos, coeffs[:, : (deg + 1) ** 2]) + 0.5
-        near_clamp = pre.abs().min(dim=-1).values < 1e-4
-        pc = (vm[0, :3, :3] @ sc["means"].double().T).T + vm[0, :3, 3]
-        fx, fy, cx, cy = K[0, 0].item(), K[1, 1].item(), K[0, 2].item(), K[1, 2].item()
-        lim = lambda a, b: torch.minimum((a - b).abs(), (a + b).abs())                                  # noqa: E731
-        rx, ry = pc[:, 0] / pc[:, 2], pc[:, 1] / pc[:, 2]
-        lxp, lxn = (w - cx) / fx + 0.3 * 0.5 * w / fx, cx / fx + 0.3 * 0.5 * w / fx
-        lyp, lyn = (h - cy) / fy + 0.3 * 0.5 * h / fy, cy / fy + 0.3 * 0.5 * h / fy
-        near_jac = ((rx - lxp).abs() < 1e-5) | ((rx + lxn).abs() < 1e-5) | ((ry - lyp).abs() < 1e-5) | ((ry + lyn).abs() < 1e-5)
-        keep &= ~(near_clamp | near_jac)
+    keep = torch.ones(n, dtype=torch.bool)                     # every Gaussian is compared
     worst, worst_at = 0.0, ""
     for k in NAMES:
         a, b = model.gauss_params[k].grad.cpu().double(), ps[k].grad
@@ -125,14 +129,11 @@ for case in (range(n_cases) if only is None else [only]):
                 worst, worst_at = e, (f"{k}[{i}] pre={pre[i].tolist()} radius={int(radii[0, i])} "
                                      f"op={float(torch.sigmoid(sc['opacities'][i])):.4f} gpu={a[i].reshape(-1)[:4].tolist()} "
                                      f"ref={b[i].reshape(-1)[:4].tolist()}")
-    # unsafe pixels flip a threshold decision: the scalar losses then differ by O(flipped pixels / all pixels)
-    tol_loss = 1e-4 if frac_safe == 1.0 else 1e-4 + 2.0 * (1 - frac_safe)
-    # scenes so dense that nearly every tile holds a threshold pixel leave too few Gaussians to judge gradients
-    assessable = float(keep.float().mean()) >= 0.1
-    ok = e_main <= tol_loss and e_depth <= tol_loss and (worst <= 2e-4 or not assessable)
+    kept = float(keep.float().mean())
+    ok = e_main <= 1e-4 and e_depth <= 1e-4 and worst <= 2e-4 and kept == 1.0
     bad += not ok
     print(f"case {case:3d} {w:3d}x{h:3d} n={n:5d} deg={deg} {mode:11s} mask={int(use_mask)} visible={int((radii > 0).sum()):5d} "
-          f"safe={frac_safe:.4f} clamp_edge={n_clamp_edge} kept={float(keep.float().mean()):.2f} e_main={e_main:.1e} e_depth={e_depth:.1e} "
+          f"safe={frac_safe:.4f} clamp_edge={n_clamp_edge} moved={n_moved} kept={kept:.2f} e_main={e_main:.1e} e_depth={e_depth:.1e} "
           f"grad={worst:.1e} {'ok' if ok else 'VIOLATION'}", flush=True)
     if not ok:
         print("      worst:", worst_at, flush=True)

@@ -222,12 +222,21 @@ def test_projection_derives_the_view_matrix_itself(cuda, lib):
 # ---- parent-class semantics -----------------------------------------------------------------------------
 def test_masked_rgb_loss_api_fused_and_oracle_agree(cuda):
     """The mask multiplies BOTH images before L1 and SSIM (parent) and both depths (model.py:93-97): API route, fused
-    route and the oracle agree, and masked-out pixels pass no colour gradient."""
+    route and the oracle agree to the north_star's 1e-4, and masked-out pixels pass no colour gradient.  (The band
+    mask also carries the threshold pixels of this scene, tests/util.py::threshold_pixel_mask: no Gaussian is left
+    out of the comparison.)"""
+    from tests.util import threshold_pixel_mask
     w, h, n = 160, 112, 3000
     sc = scene(n, w, h, seed=5)
-    mask = torch.ones(h, w, 1)
-    mask[:, : w // 3] = 0.0                                               # a masked-out band
     m1, cam, batch = _model(sc, cuda)
+    with torch.no_grad():
+        m1.get_outputs(cam)
+    ps = {k: sc[k].double().requires_grad_(True) for k in PARAM_NAMES}
+    ref = O.splatfacto_outputs(ps["means"], ps["scales"], ps["quats"], ps["opacities"], ps["features_dc"],
+                               ps["features_rest"], sc["camera_to_worlds"][:1].double(), sc["Ks"][:1].double(), w, h,
+                               sc["background"].double(), radii_override=m1.info["radii"].cpu(), return_margin=True)
+    mask = threshold_pixel_mask(ref, sc["gt_rgb"], sc["gt_depth"], 1e-4).float()
+    mask[:, : w // 3] = 0.0                                               # a masked-out band
     batch["mask"] = (mask > 0).to(cuda)                                   # bool, as Nerfstudio delivers it
     out = m1.get_outputs(cam)
     out["rgb"].retain_grad()
@@ -239,10 +248,6 @@ def test_masked_rgb_loss_api_fused_and_oracle_agree(cuda):
     batch2["mask"] = mask.to(cuda)
     lf = m2.fused_loss(cam2, batch2)
     lf["loss"].backward()
-    ps = {k: sc[k].double().requires_grad_(True) for k in PARAM_NAMES}
-    ref = O.splatfacto_outputs(ps["means"], ps["scales"], ps["quats"], ps["opacities"], ps["features_dc"],
-                               ps["features_rest"], sc["camera_to_worlds"][:1].double(), sc["Ks"][:1].double(), w, h,
-                               sc["background"].double(), radii_override=m1.info["radii"].cpu())
     l_rgb = O.main_loss(ref["rgb"], sc["gt_rgb"].double(), 0.2, mask.double())
     l_d = O.depth_l1_loss(ref["depth"], sc["gt_depth"].double(), mask.double(), 0.2)
     for got in (ld, lf):
@@ -251,7 +256,8 @@ def test_masked_rgb_loss_api_fused_and_oracle_agree(cuda):
     (l_rgb + l_d).backward()
     for name in PARAM_NAMES:
         assert_close(m2.gauss_params[name].grad, m1.gauss_params[name].grad, 2e-5, f"fused vs api grad {name}")
-        assert_close(m1.gauss_params[name].grad.cpu(), ps[name].grad, 5e-4, f"api vs oracle grad {name}")
+        assert_close(m1.gauss_params[name].grad.cpu(), ps[name].grad, REL_TOL, f"api vs oracle grad {name}")
+        assert_close_elem(m1.gauss_params[name].grad.cpu(), ps[name].grad, f"api vs oracle grad {name}", atol_frac=1e-5)
 
 
 def test_scale_regularization_matches_oracle(cuda):
@@ -391,9 +397,9 @@ def test_qed_adam_six_instances_match_torch_adam(cuda, n, flat_grads):
     # checkpoint layout of torch.optim.Adam: per-group exp_avg / exp_avg_sq / step
     sd_q, sd_t = oq["scales"].state_dict(), ot["scales"].state_dict()
     assert float(sd_q["state"][0]["step"]) == float(sd_t["state"][0]["step"]) == 5.0
-    # (the kernel forms 1 - beta in fp32 from the fp32 beta: 1 - 0.999f differs from torch's double 1 - 0.999 by 1.3e-5)
+    # (1 - beta reaches the kernel formed in double and rounded once, as torch's Python scalars are)
     assert_close(sd_q["state"][0]["exp_avg"], sd_t["state"][0]["exp_avg"], 1e-6, "exp_avg")
-    assert_close(sd_q["state"][0]["exp_avg_sq"], sd_t["state"][0]["exp_avg_sq"], 5e-5, "exp_avg_sq")
+    assert_close(sd_q["state"][0]["exp_avg_sq"], sd_t["state"][0]["exp_avg_sq"], 1e-6, "exp_avg_sq")
     assert sd_q["param_groups"][0]["lr"] == sd_t["param_groups"][0]["lr"]
     assert oq["means"].param_groups[0]["lr"] == pytest.approx(lrs["means"] * 0.9 ** 5)
     # a group stepped on its own (out of step with the others) is updated on its own, with its own step count

@@ -80,3 +80,21 @@ def to_dev(d, dev, dtype=torch.float32):
 
 def tile_grid(w, h):
     return math.ceil(w / 16), math.ceil(h / 16)
+
+
+def threshold_pixel_mask(ref, gt_rgb, gt_depth, margin_tol, edge_tol=1e-6):
+    """[H,W,1] float64 mask for ``batch["mask"]``: 0 at the (few) pixels where the fp32 kernels and the fp64 oracle
+    may legitimately take DIFFERENT discrete decisions -- an alpha >= 1/255 or T <= 1e-4 test within ``margin_tol`` of
+    its threshold (the oracle reports every pixel's margin), a colour within ``edge_tol`` of a clamp edge, a prediction
+    within ``edge_tol`` of its target (the kink of |x - y|).  The mask multiplies both images and both depths
+    (model.py:93-97 and the parent's loss), so such a pixel passes NO gradient on either side and every Gaussian --
+    also those that share a tile with it -- can be compared element by element.  ``ref`` = oracle.splatfacto_outputs
+    (..., return_margin=True)."""
+    safe = ref["info"]["margin"][0] > margin_tol                                        # [H,W]
+    pre = (ref["render"][0, ..., :3] + (1 - ref["accumulation"]) * ref["background"]).detach()
+    near = torch.minimum(pre.abs(), (pre - 1).abs())
+    edge = ((near < edge_tol) & (near > 0)).any(-1)        # (exactly 0: an empty pixel on a black background, same on both sides)
+    kink = ((ref["rgb"].detach() - gt_rgb.to(pre.dtype)).abs() < edge_tol).any(-1)
+    if ref.get("depth") is not None and gt_depth is not None:
+        kink = kink | ((ref["depth"].detach() - gt_depth.to(pre.dtype)).abs() < edge_tol)[..., 0]
+    return (safe & ~edge & ~kink)[..., None].to(torch.float64)
