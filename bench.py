@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--plain-adam", action="store_true",
                     help="write the 48 N SH-coefficient gradients in the projection backward and read them in the plain "
                          "fused Adam step, instead of expanding them inside the optimiser pass (qed_adam_step_sh)")
+    ap.add_argument("--launch-timeout", type=float, default=900.0,
+                    help="--gpus N > 1 without a launcher: wall limit in seconds for the ranks this process starts")
     ap.add_argument("--graph-split", action="store_true",
                     help="capture forward+backward and the Adam step as two graphs with the gradient all-reduce "
                          "between them (the default for N > 1; this flag forces it at N = 1 for testing)")
@@ -107,7 +109,7 @@ def cpu_baseline(args):
     }
 
 
-def api_path_ms(args, sc, dev, optimizer: str) -> float:
+def api_path_ms(args, sc, dev, optimizer: str, separate_params: bool = False) -> float:
     """ms per training step through the REFERENCE's own call sequence, eager dispatch, same scene and same steps
     (W warm-up + K timed from the initial parameters) as the headline number:
 
@@ -116,14 +118,17 @@ def api_path_ms(args, sc, dev, optimizer: str) -> float:
 
     (/root/reference/qed_splatter/model.py:199-321, 120-197, 73-118 driven by Nerfstudio's Trainer.train_iteration).
     ``optimizer``: "qed" = QedAdam (a torch.optim.Optimizer subclass AdamOptimizerConfig._target can name; the six
-    instances share one fused launch), "torch" = six torch.optim.Adam exactly as the reference configures them."""
+    instances share one fused launch), "torch" = six torch.optim.Adam exactly as the reference configures them.
+    ``separate_params``: the six Parameters as SEPARATE tensors, which is how Nerfstudio's parent class holds them
+    (model.py:12,50-58) -- QedAdam then keeps torch.optim.Adam's per-parameter state and launches once per group."""
     import functools
     from qed_splatter_amd.model import (FlatAdam, PinholeCameras, QEDSplatterModel, QEDSplatterModelConfig, QedAdam,
                                         exponential_decay_lr)
     n, w, h = args.gaussians, args.width, args.height
     cfg = QEDSplatterModelConfig.synthetic(sh_degree=3, sh_degree_interval=1)
-    model = QEDSplatterModel(cfg, **{k: sc[k].clone() for k in ("means", "scales", "quats", "opacities", "features_dc",
-                                                                  "features_rest")})
+    model = QEDSplatterModel(cfg, separate_params=separate_params,
+                             **{k: sc[k].clone() for k in ("means", "scales", "quats", "opacities", "features_dc",
+                                                           "features_rest")})
     model.step = 30000
     model.train()
     K = sc["Ks"][0].cpu()
@@ -164,7 +169,13 @@ def api_path_ms(args, sc, dev, optimizer: str) -> float:
 def launch_ranks(args) -> int:
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as FRESH child processes
     (one per GPU, torch.distributed.run over 127.0.0.1) before this process has made any GPU call, relay their
-    output (rank 0 prints the JSON line) and return their exit status.  Nothing is re-exec'd."""
+    output (rank 0 prints the JSON line) and return their exit status.  Nothing is re-exec'd.
+
+    A wedged rank must not sit until the driver's own limit: the launcher and its ranks run in a process group of their
+    own, and after ``--launch-timeout`` seconds (QED_BENCH_LAUNCH_TIMEOUT; default 900) that group is terminated (then
+    killed) and this process exits non-zero.  The ranks themselves give every collective / rendezvous 120 s
+    (init_process_group(timeout=...))."""
+    import signal
     import socket
     import subprocess
     with socket.socket() as s:
@@ -174,8 +185,27 @@ def launch_ranks(args) -> int:
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
-    print(f"[bench] launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
-    return subprocess.run(cmd, env=env).returncode
+    limit = float(os.environ.get("QED_BENCH_LAUNCH_TIMEOUT", args.launch_timeout))
+    print(f"[bench] launching {args.gpus} ranks (wall limit {limit:.0f} s): {' '.join(cmd)}", file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)     # its own process group: exactly what we started
+    try:
+        return proc.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        print(f"[bench] the ranks did not finish within {limit:.0f} s: terminating process group {proc.pid}",
+              file=sys.stderr, flush=True)
+    except KeyboardInterrupt:
+        print("[bench] interrupted: terminating the ranks", file=sys.stderr, flush=True)
+    for sig, grace in ((signal.SIGTERM, 15.0), (signal.SIGKILL, 5.0)):
+        try:
+            os.killpg(proc.pid, sig)
+        except ProcessLookupError:
+            break
+        try:
+            proc.wait(timeout=grace)
+            break
+        except subprocess.TimeoutExpired:
+            continue
+    return 124
 
 
 def main():
@@ -197,10 +227,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        from datetime import timedelta
+        # a rank that never arrives must fail the others within two minutes, not hold them until the driver's limit
+        limit = timedelta(seconds=float(os.environ.get("QED_BENCH_COLLECTIVE_TIMEOUT", "120")))
         if rehearse:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=limit)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=limit)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     # Work on an explicit (non-legacy) stream from the start: autograd pins each leaf's gradient
@@ -537,16 +570,22 @@ def main():
             # the reference-shaped route, driver-timed in the same run (see api_path_ms)
             api_qed = api_path_ms(args, sc, dev, "qed")
             api_torch = api_path_ms(args, sc, dev, "torch")
+            api_sep = api_path_ms(args, sc, dev, "qed", separate_params=True)
             out["api_path_ms_per_step"] = api_qed
             out["api_path_torch_adam_ms_per_step"] = api_torch
+            out["api_path_separate_params_ms_per_step"] = api_sep
             out["api_path"] = {
                 "sequence": "zero_grad, get_outputs, get_metrics_dict, get_loss_dict, sum, backward, six per-group "
                             "optimisers stepped in turn, means scheduler; eager dispatch; same scene, warm-up and steps",
                 "api_path_ms_per_step": "optimisers = QedAdam (torch.optim.Optimizer subclass; the six instances share "
                                         "one fused launch)",
                 "api_path_torch_adam_ms_per_step": "optimisers = torch.optim.Adam as config.py:44-68 builds them",
+                "api_path_separate_params_ms_per_step": "QedAdam on six SEPARATELY held Parameters (how Nerfstudio's parent "
+                                                        "class keeps them): torch.optim.Adam's per-parameter state, one "
+                                                        "fused launch per group",
                 "iters_per_s": 1e3 / api_qed}
-            log(f"reference-shaped route: {api_qed:.3f} ms/step (QedAdam), {api_torch:.3f} ms/step (torch.optim.Adam)")
+            log(f"reference-shaped route: {api_qed:.3f} ms/step (QedAdam), {api_torch:.3f} ms/step (torch.optim.Adam), "
+                f"{api_sep:.3f} ms/step (QedAdam, separate Parameters)")
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

@@ -715,6 +715,24 @@ extern "C" int qed_bin_tiles(int32_t N, int32_t C, const float* means2d, const i
     QED_REQUIRE(means2d && radii && depths && tiles_per_gauss && flatten_ids, "null buffers");
     QED_REQUIRE(mode >= QED_BIN_AUTO && mode <= QED_BIN_TILE_SORT, "unknown binning mode");
     const unsigned gridS = (unsigned)((S + 255) / 256);
+    // The emit kernel adds up its predecessors' block sums itself (one launch and one serial scan less): every one of the
+    // G workgroups reads G ints, O(G^2) L2 traffic in all -- 15 MB at config B (G = 1 954), 1.5 GB at 5 M slots, and it would
+    // be ~150 GB at 50 M.  Beyond kSelfScanMaxBlocks workgroups the single-workgroup scan launch (O(G)) runs instead.
+    constexpr unsigned kSelfScanMaxBlocks = 16384;
+    int* block_offsets = (int*)(w + L.block_offsets);
+    auto launch_emit = [&](const int* bsums, const int* order, int* vals_out) {
+        if (gridS <= kSelfScanMaxBlocks) {
+            hipLaunchKernelGGL((isect_emit_kernel<unsigned, true>), dim3(gridS), dim3(256), 0, st, N, C, means2d, radii,
+                               depths, tiles_per_gauss, bsums, tile_w, tile_h, tile_bits, n_isect, order, kB0, vals_out,
+                               splats, (long long)capacity, status);
+        } else {
+            hipLaunchKernelGGL(isect_scan_kernel, dim3(1), dim3(1024), 0, st, bsums, (int)gridS, block_offsets, n_isect,
+                               (long long)capacity, status);
+            hipLaunchKernelGGL((isect_emit_kernel<unsigned, false>), dim3(gridS), dim3(256), 0, st, N, C, means2d, radii,
+                               depths, tiles_per_gauss, (const int*)block_offsets, tile_w, tile_h, tile_bits, n_isect, order,
+                               kB0, vals_out, splats, (long long)capacity, status);
+        }
+    };
     // Which pipeline: sorting every tile's run by depth costs time in proportion to the list and runs in LDS only
     // for runs of <= 2048 entries; the global depth sort of the slots costs ~12 launch latencies whatever the list.
     // The capacity (1.25 x the longest list seen) per tile decides: short lists per tile -> per-tile sort.
@@ -734,9 +752,7 @@ extern "C" int qed_bin_tiles(int32_t N, int32_t C, const float* means2d, const i
         const int passes = (end_bit + 7) / 8;
         int* v_first = (passes & 1) ? flatten_ids : vB;
         int* v_alt = (passes & 1) ? vB : flatten_ids;
-        hipLaunchKernelGGL((isect_emit_kernel<unsigned, true>), dim3(gridS), dim3(256), 0, st, N, C, means2d, radii, depths,
-                           tiles_per_gauss, bsums, tile_w, tile_h, tile_bits, n_isect, (const int*)nullptr, kB0, v_first,
-                           splats, (long long)capacity, status);
+        launch_emit(bsums, (const int*)nullptr, v_first);
         const int which = sort_pairs_u32(kB0, v_first, kB1, v_alt, n_isect, capacity, end_bit, sort_ws, L.sort_ws_bytes,
                                          status, st);
         if (which < 0) return which;
@@ -767,9 +783,7 @@ extern "C" int qed_bin_tiles(int32_t N, int32_t C, const float* means2d, const i
     const int passes = (end_bit + 7) / 8;
     int* v_first = (passes & 1) ? vB : flatten_ids;
     int* v_alt = (passes & 1) ? flatten_ids : vB;
-    hipLaunchKernelGGL((isect_emit_kernel<unsigned, true>), dim3(gridS), dim3(256), 0, st, N, C, means2d, radii, depths,
-                       tiles_per_gauss, (const int*)block_sums, tile_w, tile_h, tile_bits, n_isect, order, kB0, v_first,
-                       splats, (long long)capacity, status);
+    launch_emit((const int*)block_sums, order, v_first);
     which = sort_pairs_u32(kB0, v_first, kB1, v_alt, n_isect, capacity, end_bit, sort_ws, L.sort_ws_bytes, status, st);
     if (which < 0) return which;
     const unsigned* tile_keys = which ? kB1 : kB0;

@@ -205,7 +205,6 @@ def test_config_b_launch_shapes_agree_and_random_tiles_match_the_oracle(cuda, mo
     only gives bit-identical images / alphas / last ids and gradients equal up to atomic summation order; (ii) 16
     random tiles of the full-size render against oracle.composite_tiles run on exactly those tiles' lists (the
     oracle cannot composite 8 160 tiles, but a tile only depends on its own run of the sorted list)."""
-    from oracle import splat_oracle as O
     n, w, h = 500_000, 1920, 1080
     sc = _scene(n, w, h, 1235)
     g = torch.Generator().manual_seed(2)
@@ -226,15 +225,23 @@ def test_config_b_launch_shapes_agree_and_random_tiles_match_the_oracle(cuda, mo
         assert float((x - y).abs().max()) <= 2e-5 * (float(y.abs().max()) + 1e-30), k
     # (ii) tiles: the GPU's own projected splats (fp32) feed the oracle in fp64, so only compositing is compared
     tw, th = (w + 15) // 16, (h + 15) // 16
+    lens = (i0["isect_offsets"].flatten()[1:] - i0["isect_offsets"].flatten()[:-1]).cpu()
+    pick = torch.randperm(tw * th, generator=g)[:12].tolist() + lens.topk(2).indices.tolist() + [tw * th - 1, tw * (th - 1)]
+    _check_tiles_against_the_oracle(i0, r0, a0, w, h, pick)              # 12 random + the 2 longest + 2 cut by the border
+
+
+def _check_tiles_against_the_oracle(i0, r0, a0, w, h, pick):
+    """Tiles ``pick`` of a full-size render against oracle.composite_tiles run on exactly those tiles' runs of the sorted
+    list (the oracle cannot composite thousands of tiles, but a tile depends on its own run only)."""
+    from oracle import splat_oracle as O
+    tw, th = (w + 15) // 16, (h + 15) // 16
     offs = i0["isect_offsets"].flatten().cpu().tolist() + [int(i0["n_isects"])]
     fid = i0["flatten_ids"].cpu().long()
     m2, con = i0["means2d"][0].cpu().double(), i0["conics"][0].cpu().double()
     col = torch.cat([i0["colors"][0], i0["depths"][0][:, None]], dim=1).cpu().double()
     opa = i0["opacities"][0].cpu().double()
-    lens = torch.tensor([offs[t + 1] - offs[t] for t in range(tw * th)])
-    pick = torch.randperm(tw * th, generator=g)[:12].tolist() + lens.topk(2).indices.tolist() + [tw * th - 1, tw * (th - 1)]
     n_bad = n_pix = 0
-    for t in pick:                                                        # 12 random + the 2 longest + 2 cut by the border
+    for t in pick:
         ty, tx = divmod(t, tw)
         ids = fid[offs[t]:offs[t + 1]]
         if ids.numel() == 0:
@@ -254,4 +261,63 @@ def test_config_b_launch_shapes_agree_and_random_tiles_match_the_oracle(cuda, mo
         assert float((got_a - aa[0, ..., 0])[safe].abs().max()) <= 1e-4, t
         want_l = torch.where(aa[0, ..., 0] > 0, ll[0].long() + offs[t], torch.zeros_like(ll[0].long()))
         assert torch.equal(got_l.long()[safe], want_l[safe]), t
-    assert n_bad <= 0.002 * n_pix
+    assert n_bad <= 0.002 * max(n_pix, 1)
+
+
+@pytest.mark.parametrize("n,w,h,seed", [(5_000_000, 1920, 1080, 7), (2_000_000, 4096, 2160, 9)])
+def test_configs_d_e_backward_and_fused_step_at_full_size(cuda, monkeypatch, n, w, h, seed):
+    """BASELINE configs D (5 M Gaussians @ 1080p: the two-stage binning pipeline, runs of thousands per tile) and E (2 M
+    @ 4096 x 2160, one camera's leg) through forward + backward + optimiser at FULL size, against what can be checked
+    there: (i) whole-tile-only vs the production mixed launch -- images, alphas, last ids bit-identical, gradients equal
+    up to atomic summation order; (ii) the backward pass is linear in the upstream gradient; (iii) 8 tiles (6 random,
+    the longest, one cut by the border) against oracle.composite_tiles; (iv) four fused training steps (loss + backward
+    + fused Adam) stay finite and reduce the loss."""
+    from qed_splatter_amd.model import FlatAdam, PinholeCameras, QEDSplatterModel, QEDSplatterModelConfig
+    sc = _scene(n, w, h, seed)
+    g = torch.Generator().manual_seed(3)
+    wgt = torch.rand(1, h, w, 4, generator=g).to(cuda)
+
+    def run(scale=1.0):
+        r, a, info, ps = _render(sc, cuda, w, h, need_grad=True)
+        grads = torch.autograd.grad(scale * ((r * wgt).sum() + a.sum()), [ps[k] for k in PARAM_NAMES])
+        return r.detach(), a.detach(), info, grads
+
+    monkeypatch.delenv("QED_COMPOSITE_WAVES", raising=False)
+    r0, a0, i0, g0 = run()
+    monkeypatch.setenv("QED_COMPOSITE_WAVES", "tile")
+    r1, a1, i1, g1 = run()
+    monkeypatch.delenv("QED_COMPOSITE_WAVES", raising=False)
+    assert torch.equal(r0, r1) and torch.equal(a0, a1) and torch.equal(i0["last_ids"], i1["last_ids"])
+    for k, x, y in zip(PARAM_NAMES, g0, g1):
+        assert bool(torch.isfinite(x).all()), k
+        assert float((x - y).abs().max()) <= 2e-5 * (float(y.abs().max()) + 1e-30), k
+    del r1, a1, i1, g1
+    _, _, _, g2 = run(2.0)
+    for k, x, y in zip(PARAM_NAMES, g0, g2):
+        assert float((y - 2.0 * x).abs().max()) <= 2e-5 * (float(x.abs().max()) + 1e-30), k
+    del g2, g0
+    tw, th = (w + 15) // 16, (h + 15) // 16
+    lens = (i0["isect_offsets"].flatten()[1:] - i0["isect_offsets"].flatten()[:-1]).cpu()
+    pick = torch.randperm(tw * th, generator=g)[:6].tolist() + lens.topk(1).indices.tolist() + [tw * th - 1]
+    _check_tiles_against_the_oracle(i0, r0, a0, w, h, pick)
+    del r0, a0, i0, wgt
+    torch.cuda.empty_cache()
+    model = QEDSplatterModel(QEDSplatterModelConfig.synthetic(sh_degree_interval=1), **{k: sc[k].to(cuda) for k in PARAM_NAMES})
+    model.step = 30000
+    K = sc["Ks"][0]
+    cam = PinholeCameras(sc["camera_to_worlds"].to(cuda), float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), w, h)
+    batch = {"image": sc["gt_rgb"].to(cuda), "depth_image": sc["gt_depth"].to(cuda)}
+    opt = FlatAdam(model)
+    hist = []
+    for _ in range(4):
+        for p in model.parameters():
+            p.grad = None
+        losses = model.fused_loss(cam, batch, compact_sh_grad=True)
+        model.backward_fused(losses)
+        opt.step(fused_sh=True)
+        hist.append(losses["loss"].detach())
+    assert bool(torch.isfinite(model.flat_params).all())
+    hist = [float(v) for v in hist]
+    assert all(v == v for v in hist) and hist[-1] < hist[0], hist
+    del model, opt
+    torch.cuda.empty_cache()

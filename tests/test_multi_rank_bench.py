@@ -1,0 +1,79 @@
+"""The multi-rank control flow of bench.py inside the GPU test tier: `python bench.py --gpus 2`
+as the driver calls it -- no launcher around it -- starts its own fresh ranks, which on a one-GPU box share cuda:0 and talk
+over gloo (QED_BENCH_REHEARSE=1: RCCL needs one GPU per rank).  Everything but the transport is the N > 1 path of the
+real run: per-rank cameras, split graphs around the eager collectives, the compact gradient exchange overlapped with the
+optimiser, rank agreement, barriers, max-over-ranks timing, rank 0's JSON line.  No scaling figure comes out of this."""
+from __future__ import annotations
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal_prints_the_contract_line(cuda):
+    env = dict(os.environ, QED_BENCH_REHEARSE="1", QED_BENCH_LAUNCH_TIMEOUT="420", QED_BENCH_COLLECTIVE_TIMEOUT="120")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--gaussians", "100000", "--width", "960", "--height", "540"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]                       # rank 0 alone prints, once
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["parallelism"].startswith("dp2") and out["unit"] == "iters/s"
+    assert out["value"] > 0 and out["ms_per_step"] > 0 and out["higher_is_better"] is True
+    assert out["value"] == pytest.approx(2 * 3 / (out["ms_per_step"] * 3e-3), rel=1e-6)      # whole-job camera-steps / s
+
+
+def test_launcher_enforces_its_wall_limit_and_reaps_its_children(tmp_path):
+    """launch_ranks() must not wait for a wedged rank until the driver's own limit: the process group it started is
+    terminated at the wall limit and the exit status is non-zero.  (CPU: the 'ranks' here are a stand-in that sleeps.)"""
+    import signal
+    import textwrap
+    import time
+    stub = tmp_path / "torch" / "distributed"
+    stub.mkdir(parents=True)
+    (tmp_path / "torch" / "__init__.py").write_text("")
+    (stub / "__init__.py").write_text("")
+    pidfile = tmp_path / "child.pid"
+    # stands in for `python -m torch.distributed.run ...`: a launcher that starts one child and never returns
+    (stub / "run.py").write_text(textwrap.dedent(f"""
+        import os, subprocess, sys, time
+        c = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(600)"])
+        open({str(pidfile)!r}, "w").write(f"{{os.getpid()}} {{c.pid}}")
+        time.sleep(600)
+    """))
+    driver = textwrap.dedent(f"""
+        import sys, types
+        sys.path.insert(0, {ROOT!r})
+        sys.argv = ["bench.py", "--gpus", "2", "--launch-timeout", "3"]
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("bench_under_test", {os.path.join(ROOT, "bench.py")!r})
+        import os
+        os.environ["PYTHONPATH"] = {str(tmp_path)!r}          # the children import the stand-in launcher, not torch's
+        os.environ.pop("QED_BENCH_LAUNCH_TIMEOUT", None)
+        b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+        sys.exit(b.launch_ranks(b.parse()))
+    """)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "-c", driver], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode == 124, (p.returncode, p.stderr[-2000:])
+    assert time.time() - t0 < 60
+    assert "terminating process group" in p.stderr
+    pids = [int(x) for x in pidfile.read_text().split()]
+    time.sleep(0.5)
+    for pid in pids:                                               # launcher and its child are gone
+        try:
+            state = open(f"/proc/{pid}/stat").read().rsplit(")", 1)[1].split()[0]
+        except (FileNotFoundError, ProcessLookupError):
+            continue
+        if state != "Z":                                           # (an orphaned zombie only waits for init to reap it)
+            os.kill(pid, signal.SIGKILL)
+            raise AssertionError(f"process {pid} (state {state}) survived the launcher's wall limit")
