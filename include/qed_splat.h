@@ -189,7 +189,9 @@ int qed_tile_offsets(const uint64_t* sorted_keys, const int32_t* n_dev, int64_t 
  * launch_flags: 0 in production.  One wave composites a whole tile, or one 8x8 quadrant of it for the
  * last tiles of a launch (finer work items fill the end of the launch); QED_CL_TILE_WAVES / _QUADRANT_WAVES
  * / _HALF_AND_HALF force one shape and QED_CL_NO_CULL turns the per-quadrant culling off -- results must
- * not change (parity tests). */
+ * not change (parity tests).
+ * tile_cost (may be NULL; [C*tiles][4] i32): receives, per tile and quadrant wave, the number of (Gaussian, quadrant)
+ * visits + a staging term per batch -- the work predictor qed_composite_bwd orders its launch by. */
 #define QED_CL_TILE_WAVES 1
 #define QED_CL_QUADRANT_WAVES 2
 #define QED_CL_HALF_AND_HALF 3
@@ -197,18 +199,23 @@ int qed_tile_offsets(const uint64_t* sorted_keys, const int32_t* n_dev, int64_t 
 int qed_composite_fwd(int32_t C, int32_t N, const float* splats, const int32_t* flatten_ids,
                       const int32_t* offsets, int32_t width, int32_t height, int32_t tile_w,
                       int32_t tile_h, int32_t channels, const float* backgrounds, float* render,
-                      float* alpha, int32_t* last_ids, int32_t launch_flags, void* stream);
+                      float* alpha, int32_t* last_ids, int32_t* tile_cost, int32_t launch_flags, void* stream);
 
 /* ---- K7: alpha compositing backward ------------------------------------------------------------
  * Back-to-front replay from last_ids; per-pixel gradients are reduced across each 64-wide wave
- * (permlane swaps + DPP), accumulated per tile in LDS, and added once per (tile,Gaussian) to the
+ * (one permlane level, the rest through LDS) and added once per (tile,Gaussian) to the
  * 64-byte row vsplat[C*N][16] (layout at qed_project_bwd; includes absgrad, model.py:284).
- * vsplat must be zeroed by the caller. */
+ * vsplat must be zeroed by the caller.
+ * tile_cost (may be NULL; [C*tiles][4] i32, 16-byte aligned): what qed_composite_fwd wrote for the same list -- the
+ * tiles are then handed out costliest first (greedy longest-processing-time scheduling of the launch; tiles heavier than
+ * the average wave slot's whole share are dealt as four quadrant waves), ordered by one extra one-workgroup launch into
+ * order_ws (C*tiles + 1 ints of scratch).  Same gradients up to the order of the float atomics. */
 int qed_composite_bwd(int32_t C, int32_t N, const float* splats, const int32_t* flatten_ids,
                       const int32_t* offsets, int32_t width, int32_t height, int32_t tile_w,
                       int32_t tile_h, int32_t channels, const float* backgrounds,
                       const float* render_alpha, const int32_t* last_ids, const float* v_render,
-                      const float* v_alpha, float* vsplat, int32_t launch_flags, void* stream);
+                      const float* v_alpha, float* vsplat, const int32_t* tile_cost, int32_t* order_ws,
+                      int32_t launch_flags, void* stream);
 
 /* ---- K8: fused image-space loss + gradient ------------------------------------------------------
  * Collapses model.py:295-297 (background composite + clamp), :304-306 (depth fix-up), :87-116

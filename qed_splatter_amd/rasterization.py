@@ -368,9 +368,14 @@ class _Composite(torch.autograd.Function):
         alpha = torch.empty(C, height, width, 1, dtype=torch.float32, device=dev)
         last_ids = torch.empty(C, height, width, dtype=torch.int32, device=dev)
         bg = _f32c(backgrounds, "backgrounds") if backgrounds is not None else None
+        # per-tile work counts of this pass: the backward pass hands its tiles out costliest first (qed_composite_bwd)
+        tile_cost = None
+        if any(ctx.needs_input_grad[:5]):
+            tile_cost = torch.empty(C * tile_w * tile_h, 4, dtype=torch.int32, device=dev)
         L.check(lib.qed_composite_fwd(C, N, L.ptr(splats), L.ptr(flatten_ids), L.ptr(offsets), width, height, tile_w,
                                       tile_h, channels, L.ptr(bg), L.ptr(render), L.ptr(alpha), L.ptr(last_ids),
-                                      L.composite_launch_flags(), _stream()), "qed_composite_fwd")
+                                      L.ptr(tile_cost), L.composite_launch_flags(), _stream()), "qed_composite_fwd")
+        ctx.tile_cost = tile_cost
         ctx.save_for_backward(splats, flatten_ids, offsets, alpha, last_ids, bg)
         ctx.meta = (C, N, width, height, tile_w, tile_h, channels, absgrad)
         ctx.means2d_ref = means2d
@@ -394,9 +399,12 @@ class _Composite(torch.autograd.Function):
         vsplat = holder.pop() if holder else None
         if vsplat is None or vsplat.shape != (C * N, R) or vsplat.device != dev or vsplat.dtype != torch.float32:
             vsplat = torch.zeros(C * N, R, dtype=torch.float32, device=dev)
+        tile_cost = ctx.tile_cost
+        order_ws = torch.empty(C * tile_w * tile_h + 1, dtype=torch.int32, device=dev) if tile_cost is not None else None
         L.check(lib.qed_composite_bwd(C, N, L.ptr(splats), L.ptr(flatten_ids), L.ptr(offsets), width, height, tile_w,
                                       tile_h, channels, L.ptr(bg), L.ptr(alpha), L.ptr(last_ids), L.ptr(v_render),
-                                      L.ptr(v_alpha), L.ptr(vsplat), L.composite_launch_flags(), _stream()),
+                                      L.ptr(v_alpha), L.ptr(vsplat), L.ptr(tile_cost), L.ptr(order_ws),
+                                      L.composite_launch_flags(), _stream()),
                 "qed_composite_bwd")
         v3 = vsplat.view(C, N, R)
         v_means2d = v3[..., 0:2]

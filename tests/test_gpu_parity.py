@@ -1160,3 +1160,71 @@ def test_one_stage_entry_points_match_two_stage(cuda, lib):
                               status.data_ptr(), st) == 0
     torch.cuda.synchronize()
     assert int(status[0]) == M and int(n_isect) == 0
+
+
+# --------------------------------------------------------------------------------------------------
+# K7 launch order: costliest tiles first (qed_composite_fwd's tile_cost -> qed_composite_bwd)
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h,n,grow", [(320, 208, 20000, 0.0), (1280, 720, 120000, 0.5)])
+def test_backward_tile_order_is_costliest_first_and_changes_no_gradient(cuda, lib, w, h, n, grow):
+    """qed_composite_fwd counts every tile's (Gaussian, quadrant) visits; qed_composite_bwd, handed that array, deals its
+    tiles out in order of decreasing cost (heavy tiles as four quadrant waves): the order is a permutation sorted by
+    cost, the split count follows its definition, and the gradient rows equal those of the plain launch up to the order
+    of the float atomics."""
+    from qed_splatter_amd import _lib as L
+    from qed_splatter_amd.model import get_viewmat
+    from qed_splatter_amd.rasterization import _ProjectSH, _bin_and_sort, _stream
+    sc = scene(n, w, h, seed=41)
+    sc["scales"] = sc["scales"] + grow
+    sc["means"][: n // 4, :2] *= 0.15                               # a dense clump: some tiles far heavier than the rest
+    tw, th = (w + 15) // 16, (h + 15) // 16
+    T = tw * th
+    vm = get_viewmat(sc["camera_to_worlds"][:1].to(cuda))
+    with torch.no_grad():
+        means2d, depths, conics, opac, rgb, radii, splats, tpg, bsums = _ProjectSH.apply(
+            sc["means"].to(cuda), sc["quats"].to(cuda), sc["scales"].to(cuda), sc["opacities"].to(cuda).squeeze(-1),
+            sc["features_dc"].to(cuda), sc["features_rest"].to(cuda), vm, sc["Ks"][:1].to(cuda), w, h, tw, th, 3,
+            L.F_LOG_SCALES | L.F_LOGIT_OPAC | L.F_DEPTH_CHANNEL, 0.3, 0.01, 1e10, 0.0)
+        _, fid, offs, M = _bin_and_sort(n, 1, means2d, radii, depths, tpg, bsums, tw, th, sync=True, splats=splats,
+                                        size=(w, h))
+    render = torch.empty(1, h, w, 4, device=cuda)
+    alpha = torch.empty(1, h, w, 1, device=cuda)
+    last = torch.empty(1, h, w, dtype=torch.int32, device=cuda)
+    cost = torch.full((T, 4), -7, dtype=torch.int32, device=cuda)
+    st = _stream()
+    L.check(lib.qed_composite_fwd(1, n, L.ptr(splats), L.ptr(fid), L.ptr(offs), w, h, tw, th, 4, None, L.ptr(render),
+                                  L.ptr(alpha), L.ptr(last), L.ptr(cost), 0, st), "fwd")
+    c = cost.sum(dim=1).cpu()
+    assert int(cost.min()) >= 0 and int(c.sum()) > 0                  # every tile's entry was written
+    lens = (offs[1:] - offs[:-1]).cpu()
+    assert bool(((c == 0) == (lens == 0)).all())                       # no list <=> no work
+    # the same image with and without the cost output
+    r2 = torch.empty_like(render)
+    L.check(lib.qed_composite_fwd(1, n, L.ptr(splats), L.ptr(fid), L.ptr(offs), w, h, tw, th, 4, None, L.ptr(r2),
+                                  L.ptr(alpha), L.ptr(last), None, 0, st), "fwd")
+    assert torch.equal(r2, render)
+    g = torch.Generator().manual_seed(4)
+    v_r = torch.randn(1, h, w, 4, generator=g).to(cuda)
+    v_a = torch.randn(1, h, w, 1, generator=g).to(cuda)
+    outs = []
+    order_ws = torch.full((T + 1,), -1, dtype=torch.int32, device=cuda)
+    for with_order in (False, True):
+        vs = torch.zeros(n, L.VSPLAT_FLOATS, device=cuda)
+        L.check(lib.qed_composite_bwd(1, n, L.ptr(splats), L.ptr(fid), L.ptr(offs), w, h, tw, th, 4, None, L.ptr(alpha),
+                                      L.ptr(last), L.ptr(v_r), L.ptr(v_a), L.ptr(vs), L.ptr(cost) if with_order else None,
+                                      L.ptr(order_ws) if with_order else None, 0, st), "bwd")
+        outs.append(vs)
+    torch.cuda.synchronize()
+    order, n_split = order_ws[:T].cpu().long(), int(order_ws[T])
+    assert sorted(order.tolist()) == list(range(T))                    # a permutation of the tiles
+    key = c.clamp(max=4095)[order]
+    assert bool((key[1:] <= key[:-1]).all())                           # costliest first (cost clipped at 4095)
+    slots = torch.cuda.get_device_properties(cuda).multi_processor_count * 4 * 4
+    per_slot = float(c.sum()) / slots
+    want_split = min(int((c.clamp(max=4095) > int(min(per_slot, 4095.0))).sum()), T // 8)
+    assert n_split == want_split, (n_split, want_split, per_slot)
+    scale = float(outs[0].abs().max())
+    assert scale > 0 and float((outs[0] - outs[1]).abs().max()) <= 2e-5 * scale
+    with pytest.raises(L.QedSplatError):                               # the two buffers go together
+        L.check(lib.qed_composite_bwd(1, n, L.ptr(splats), L.ptr(fid), L.ptr(offs), w, h, tw, th, 4, None, L.ptr(alpha),
+                                      L.ptr(last), L.ptr(v_r), L.ptr(v_a), L.ptr(outs[0]), L.ptr(cost), None, 0, st), "bwd")
