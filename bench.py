@@ -109,7 +109,7 @@ def cpu_baseline(args):
     }
 
 
-def api_path_ms(args, sc, dev, optimizer: str, separate_params: bool = False) -> float:
+def api_path_ms(args, sc, dev, optimizer: str, separate_params: bool = False, host: dict = None) -> float:
     """ms per training step through the REFERENCE's own call sequence, eager dispatch, same scene and same steps
     (W warm-up + K timed from the initial parameters) as the headline number:
 
@@ -159,8 +159,11 @@ def api_path_ms(args, sc, dev, optimizer: str, separate_params: bool = False) ->
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_issue = time.perf_counter() - t0                 # host time to enqueue the steps (the GPU may still be running)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if host is not None:
+        host["enqueue_ms_per_step"] = t_issue / args.steps * 1e3
     del model, opts
     torch.cuda.empty_cache()
     return dt / args.steps * 1e3
@@ -568,12 +571,14 @@ def main():
         log(f"timed region: {ms_step:.3f} ms/step")
         if world == 1 and not args.no_api_path:
             # the reference-shaped route, driver-timed in the same run (see api_path_ms)
-            api_qed = api_path_ms(args, sc, dev, "qed")
+            api_host = {}
+            api_qed = api_path_ms(args, sc, dev, "qed", host=api_host)
             api_torch = api_path_ms(args, sc, dev, "torch")
             api_sep = api_path_ms(args, sc, dev, "qed", separate_params=True)
             out["api_path_ms_per_step"] = api_qed
             out["api_path_torch_adam_ms_per_step"] = api_torch
             out["api_path_separate_params_ms_per_step"] = api_sep
+            out["api_path_host_enqueue_ms_per_step"] = api_host.get("enqueue_ms_per_step")
             out["api_path"] = {
                 "sequence": "zero_grad, get_outputs, get_metrics_dict, get_loss_dict, sum, backward, six per-group "
                             "optimisers stepped in turn, means scheduler; eager dispatch; same scene, warm-up and steps",

@@ -40,8 +40,7 @@ class DensifyConfig:
     stop_split_at: int = 15000
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+_stream = L.current_stream
 
 
 class Densifier:

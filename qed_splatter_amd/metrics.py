@@ -24,8 +24,7 @@ METRIC_NAMES = ("rgb_mse", "rgb_psnr", "depth_abs_rel", "depth_sq_rel", "depth_r
                 "depth_a1", "depth_a2", "depth_a3", "depth_n_valid")
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+_stream = L.current_stream
 
 
 def image_metrics(pred_rgb: Optional[Tensor], gt_rgb: Optional[Tensor], pred_depth: Optional[Tensor] = None,

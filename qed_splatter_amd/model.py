@@ -552,7 +552,7 @@ class QEDSplatterModel(nn.Module):
             return memo[2]
         out = image.float() / 255.0 if image.dtype == torch.uint8 else image
         out = self._downscale_if_required(out).to(self.device)
-        self._gt_memo = (image, (image._version, d), out) if out is not image else None
+        self.__dict__["_gt_memo"] = (image, (image._version, d), out) if out is not image else None
         return out
 
     def composite_with_background(self, image: Tensor, background: Tensor) -> Tensor:
@@ -626,7 +626,8 @@ class QEDSplatterModel(nn.Module):
             K = camera.get_intrinsics_matrices().to(self.device)
             cam_c2w = None
         W, H = int(camera.width.item()), int(camera.height.item())
-        self.last_size = (H, W)
+        attrs = self.__dict__            # (plain attributes: nn.Module.__setattr__ costs ~5 us apiece, a dozen per step)
+        attrs["last_size"] = (H, W)
         if camera_scale_fac != 1:
             camera.rescale_output_resolution(camera_scale_fac)
 
@@ -648,7 +649,7 @@ class QEDSplatterModel(nn.Module):
             colors, sh_rest = features_dc_crop, None
             flags |= L.F_SIGMOID_COLORS                                       # torch.sigmoid(colors) fused
 
-        render, alpha, self.info = rasterization(
+        render, alpha, info = rasterization(
             means=means_crop,
             quats=quats_crop,                       # normalised inside the projection kernel (model.py:269)
             scales=scales_crop,
@@ -672,12 +673,12 @@ class QEDSplatterModel(nn.Module):
             _sync=not (self.config.async_intersection_count and self.training),
             _c2w=cam_c2w,
         )
-        self.last_compact = False
-        if self.training and self.info["means2d"].requires_grad:              # model.py:289-290
-            self.info["means2d"].retain_grad()
-        self.xys = self.info["means2d"]                                       # [1,N,2]
-        self.radii = self.info["radii"][0]                                    # [N]
-        alpha = alpha[:, ...]
+        attrs["info"] = info
+        attrs["last_compact"] = False
+        if self.training and info["means2d"].requires_grad:                   # model.py:289-290
+            info["means2d"].retain_grad()
+        attrs["xys"] = info["means2d"]                                        # [1,N,2]
+        attrs["radii"] = info["radii"][0]                                     # [N]
 
         background = self._get_background_color()
         # model.py:296-297 (composite + clamp) and :304-308 (depth fix-up) as one node with a fused backward
@@ -693,7 +694,7 @@ class QEDSplatterModel(nn.Module):
 
         # model.py:310-311 `del render; torch.cuda.empty_cache()` is a per-call device sync +
         # allocator flush with no effect on results; deliberately not reproduced.
-        self._last_render, self._last_alpha = render, alpha
+        attrs["_last_render"], attrs["_last_alpha"] = render, alpha
 
         if background.shape[0] == 3 and not self.training:                    # model.py:313-314
             background = background.expand(H, W, 3)
@@ -749,7 +750,8 @@ class QEDSplatterModel(nn.Module):
         depth_batch = _f32_image(self.get_gt_img(batch["depth_image"]), H * W, "batch['depth_image']", self.device)
         # the SSIM forward get_metrics_dict ran on the same two images (same storage, same version; the cache holds the
         # tensors, so neither address can have been recycled), no mask: not computed a second time
-        shared, self._ssim_shared = getattr(self, "_ssim_shared", None), None
+        shared = self.__dict__.get("_ssim_shared")
+        self.__dict__["_ssim_shared"] = None
         if shared is not None and (mask is not None or cfg.ssim_lambda <= 0.0 or
                                    shared["key"] != _ssim_key(pred_img.contiguous(), gt_img)):
             shared = None
@@ -790,7 +792,7 @@ class QEDSplatterModel(nn.Module):
         with torch.no_grad():
             out = dict(_image_metrics(pred_rgb.detach(), gt_rgb, outputs["depth"].detach() if has_depth else None, gt_depth,
                                       keep_ssim_maps=keep))
-            self._ssim_shared = out.pop("_ssim_shared", None)
+            self.__dict__["_ssim_shared"] = out.pop("_ssim_shared", None)
             out["gaussian_count"] = self.num_points
             out["avg_min_scale"] = nanmean_exp(self.scales[..., -1])                  # model.py:192-194
         return out
@@ -1226,8 +1228,11 @@ class QedAdam(torch.optim.Optimizer):
 
     def _attach(self) -> _SharedFlatState:
         p = self._param()
-        self._require_gpu(p)
         base = p.untyped_storage().data_ptr()
+        st = self._shared
+        if st is not None and st.flat_ptr == base and self._views_intact(p):      # the steady state: nothing to do
+            return st
+        self._require_gpu(p)
         st = _FLAT_STATES.get(base)
         if st is None or self._shared is not st:
             if st is None:
@@ -1250,15 +1255,26 @@ class QedAdam(torch.optim.Optimizer):
         self._expose_views(st)
         return st
 
+    def _views_intact(self, p: Tensor) -> bool:
+        """``self.state[param]`` still holds the very view objects _expose_views put there (identity, no tensor calls)."""
+        held = self.__dict__.get("_views")
+        if held is None or held[0] is not p:
+            return False
+        cur = self.state.get(p)
+        return cur is held[1] and cur.get("exp_avg") is held[2] and cur.get("exp_avg_sq") is held[3]
+
     def _expose_views(self, st: _SharedFlatState) -> None:
         """``self.state[param]`` in torch.optim.Adam's layout, as views of the shared moments."""
         p = self._param()
+        if self._views_intact(p) and self._views[2].untyped_storage().data_ptr() == st.exp_avg.untyped_storage().data_ptr():
+            return
         off, n = p.storage_offset(), p.numel()
         cur = self.state.get(p)
         m, v = st.exp_avg[off:off + n].view(p.shape), st.exp_avg_sq[off:off + n].view(p.shape)
         if cur is not None and len(cur) and "exp_avg" in cur:
             if cur["exp_avg"].data_ptr() == m.data_ptr() and cur["exp_avg_sq"].data_ptr() == v.data_ptr() \
                     and cur["exp_avg"].shape == p.shape:
+                self._views = (p, cur, cur["exp_avg"], cur["exp_avg_sq"])
                 return
             raise RuntimeError(
                 "QedAdam: optimizer.state[param] of a flat-buffer group was replaced from outside (the parent class's "
@@ -1266,25 +1282,49 @@ class QedAdam(torch.optim.Optimizer):
                 "number of Gaussians is changed by qed_splatter_amd.densify.Densifier(model, QedAdamSet(model, "
                 "optimizers)), which rewrites parameters and both moments in one pass; or hold the six Parameters as "
                 "separate tensors, in which case QedAdam keeps torch.optim.Adam's own per-parameter state.")
-        self.state[p] = {"step": torch.tensor(float(st.t.get(off, 0))), "exp_avg": m, "exp_avg_sq": v}
+        entry = {"step": torch.tensor(float(st.t.get(off, 0))), "exp_avg": m, "exp_avg_sq": v}
+        self.state[p] = entry
+        self._views = (p, entry, m, v)
 
     # -- stepping ---------------------------------------------------------------------------------------
-    @torch.no_grad()
+    # torch.optim.Optimizer wraps every subclass's step() in a profiler range + hook dispatch (~25 us of Python per call,
+    # six calls per iteration on a route whose host cost is what bounds it).  `step.hooked = True` (below the class) tells
+    # it not to; registered step hooks are honoured here, so the Optimizer contract stands.
     def step(self, closure=None):
-        loss = closure() if closure is not None else None
-        p = self._param()
+        from torch.optim import optimizer as _O
+        pre, post = self._optimizer_step_pre_hooks, self._optimizer_step_post_hooks
+        if pre or post or _O._global_optimizer_pre_hooks or _O._global_optimizer_post_hooks:
+            args, kwargs = (closure,), {}
+            for hook in (*_O._global_optimizer_pre_hooks.values(), *pre.values()):
+                result = hook(self, args, kwargs)
+                if result is not None:
+                    args, kwargs = result
+            out = self._step(*args, **kwargs)
+            for hook in (*post.values(), *_O._global_optimizer_post_hooks.values()):
+                hook(self, args, kwargs)
+            return out
+        return self._step(closure)
+
+    def _step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        p = self.param_groups[0]["params"][0]
         if p.grad is None:
             return loss
-        if not self._is_flat_view(p):
-            self._step_own(p)
-            return loss
-        st = self._attach()
-        off = p.storage_offset()
-        if off in st.pending:                  # stepped twice before the others: launch what is waiting first
-            self._launch(st, sorted(st.pending))
-        st.pending[off] = float(self.param_groups[0]["lr"])
-        if len(st.pending) == len(st.members):
-            self._launch(st, sorted(st.pending))
+        with torch.no_grad():
+            if p.storage_offset() == 0 and not self._is_flat_view(p):
+                self._step_own(p)
+                return loss
+            st = self._attach()
+            off = p.storage_offset()
+            pending = st.pending
+            if off in pending:                     # stepped twice before the others: launch what is waiting first
+                self._launch(st, sorted(pending))
+            pending[off] = float(self.param_groups[0]["lr"])
+            if len(pending) == len(st.members):
+                self._launch(st, sorted(pending))
         return loss
 
     def _step_own(self, p: Tensor) -> None:
@@ -1327,52 +1367,68 @@ class QedAdam(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         # a waiting update reads .grad at launch time: launch it before the gradients go away (a group that skipped
-        # this iteration -- .grad None, or a GradScaler that found an inf for that optimiser -- must not hold the
-        # others' update back into the next iteration's gradients)
-        self.flush()
-        super().zero_grad(set_to_none=set_to_none)
+        # this iteration -- .grad None, or a GradScaler that found an inf for that optimiser only -- must not hold the
+        # others' update back into the next iteration's gradients).  One parameter: done here, without the base class's
+        # generic (and, per call, several times costlier) walk over groups.
+        st = self._shared
+        if st is not None and st.pending:
+            self._launch(st, sorted(st.pending))
+        p = self.param_groups[0]["params"][0]
+        g = p.grad
+        if g is not None:
+            if set_to_none:
+                p.grad = None
+            else:
+                if g.grad_fn is not None:
+                    g.detach_()
+                else:
+                    g.requires_grad_(False)
+                g.zero_()
 
     @staticmethod
     def _launch(st: _SharedFlatState, offs) -> None:
         import ctypes as C
         lib = L.load()
         members = [st.members[o] for o in offs]
-        ps = [m._param() for m in members]
-        for mem in members:
-            mem._expose_views(st)              # (also refuses moments that were replaced from outside)
+        ps = [m.param_groups[0]["params"][0] for m in members]
+        gs = [p.grad for p in ps]
+        for mem, p in zip(members, ps):
+            if not mem._views_intact(p):
+                mem._expose_views(st)          # (re-creates the views, or refuses moments that were replaced from outside)
         # maximal runs of groups that are adjacent in the flat buffer, share betas / eps / step count and whose
-        # gradients are adjacent views of one allocation (what _ProjectSH.backward produces): one launch per run
+        # gradients are adjacent pieces of one allocation (what _ProjectSH.backward produces): one launch per run
+        n_el = [p.numel() for p in ps]
+        gptr = [g.data_ptr() for g in gs]
+        keys = [m.defaults_key() for m in members]
         runs, cur = [], [0]
         for i in range(1, len(ps)):
-            a, b = ps[i - 1], ps[i]
-            ga, gb = a.grad, b.grad
-            same = (offs[i] == offs[i - 1] + a.numel()
-                    and gb.is_contiguous() and ga.is_contiguous()
-                    and gb.untyped_storage().data_ptr() == ga.untyped_storage().data_ptr()
-                    and gb.storage_offset() == ga.storage_offset() + ga.numel()
-                    and members[i].defaults_key() == members[i - 1].defaults_key()
-                    and st.t[offs[i]] == st.t[offs[i - 1]])
+            same = (offs[i] == offs[i - 1] + n_el[i - 1] and gptr[i] == gptr[i - 1] + 4 * n_el[i - 1]
+                    and keys[i] == keys[i - 1] and st.t[offs[i]] == st.t[offs[i - 1]]
+                    and gs[i].dtype == torch.float32 and gs[i].is_contiguous() and gs[i - 1].is_contiguous())
             if same:
                 cur.append(i)
             else:
                 runs.append(cur)
                 cur = [i]
         runs.append(cur)
-        stream = _stream()
+        stream = L.current_stream()
         skip = _skip_flag(ps[0].device)
+        flat_ptr = st.flat_ptr
+        m_ptr, v_ptr = st.exp_avg.data_ptr(), st.exp_avg_sq.data_ptr()
         for run in runs:
             first, last = run[0], run[-1]
-            lo, hi = offs[first], offs[last] + ps[last].numel()
-            g = ps[first].grad
-            beta1, beta2 = members[first].param_groups[0]["betas"]
-            eps = members[first].param_groups[0]["eps"]
+            lo, hi = offs[first], offs[last] + n_el[last]
+            g = gs[first]
+            grp = members[first].param_groups[0]
+            beta1, beta2 = grp["betas"]
+            eps = grp["eps"]
             t = st.t[offs[first]] + 1
-            if lo % 4 != 0 or g.data_ptr() % 4 != 0 or not g.is_contiguous() or g.dtype != torch.float32:
+            if lo % 4 != 0 or gptr[first] % 4 != 0 or not g.is_contiguous() or g.dtype != torch.float32:
                 # a lone group whose range is not 16-byte aligned (only when the groups are stepped out of step with
                 # each other and N is not a multiple of 4): the same update with eager torch ops
                 for i in run:
-                    o, n = offs[i], ps[i].numel()
-                    gi = ps[i].grad.reshape(-1).to(torch.float32)
+                    o, n = offs[i], n_el[i]
+                    gi = gs[i].reshape(-1).to(torch.float32)
                     m, v = st.exp_avg[o:o + n], st.exp_avg_sq[o:o + n]
                     m.mul_(beta1).add_(gi, alpha=1 - beta1)
                     v.mul_(beta2).addcmul_(gi, gi, value=1 - beta2)
@@ -1381,22 +1437,23 @@ class QedAdam(torch.optim.Optimizer):
                     st.t[offs[i]] = t
                     members[i].state[ps[i]]["step"].fill_(float(t))
                 continue
-            begins = [offs[i] - lo for i in run] + [hi - lo]
-            lrs = [st.pending[offs[i]] for i in run]
-            h_begin = (C.c_int64 * len(begins))(*begins)
-            h_lr = (C.c_float * len(lrs))(*lrs)
-            flat = st._keepalive_flat
-            L.check(lib.qed_adam_step(L.ptr(flat[lo:hi]), g.data_ptr(), L.ptr(st.exp_avg[lo:hi]), L.ptr(st.exp_avg_sq[lo:hi]),
-                                      len(lrs), C.cast(h_begin, C.c_void_p), C.cast(h_lr, C.c_void_p), float(beta1),
-                                      float(beta2), float(eps), t, skip, stream), "qed_adam_step")
+            k = len(run)
+            h_begin = (C.c_int64 * (k + 1))(*[offs[i] - lo for i in run], hi - lo)
+            h_lr = (C.c_float * k)(*[st.pending[offs[i]] for i in run])
+            L.check(lib.qed_adam_step(flat_ptr + 4 * lo, gptr[first], m_ptr + 4 * lo, v_ptr + 4 * lo, k,
+                                      C.cast(h_begin, C.c_void_p), C.cast(h_lr, C.c_void_p), float(beta1), float(beta2),
+                                      float(eps), t, skip, stream), "qed_adam_step")
+            ft = float(t)
             for i in run:
                 st.t[offs[i]] = t
-                members[i].state[ps[i]]["step"].fill_(float(t))
+                members[i]._views[1]["step"].fill_(ft)
         st.pending.clear()
 
     def defaults_key(self):
         g = self.param_groups[0]
         return (tuple(g["betas"]), float(g["eps"]))
+
+    step.hooked = True          # (see step(): torch.optim.Optimizer must not wrap it again)
 
     # -- checkpointing: torch.optim.Adam's layout in both cases ------------------------------------------
     def state_dict(self):

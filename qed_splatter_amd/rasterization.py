@@ -31,8 +31,7 @@ from torch import Tensor
 from . import _lib as L
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+_stream = L.current_stream
 
 
 def _f32c(t: Tensor, name: str) -> Tensor:
@@ -73,10 +72,21 @@ class _Workspace:
         self.words = torch.zeros(1 + L.STATUS_WORDS, dtype=torch.int32, device=device)
         self.n_isect = self.words[:1]
         self.status = self.words[1:]
+        self.words3 = self.words[:3]
+        self._ring, self._ring_at = [], 0     # pinned read-back buffers + events of the asynchronous calls, reused
         self.pending = None          # (pinned host copy of [M, overflow, watchdog], event, shape key) of an async call
         self.m_seen: Dict[tuple, int] = {}   # shape key -> longest list read back for that shape
         self.force_sync = False      # the next call reads M back (an asynchronous frame overflowed)
         self.overflows = 0           # asynchronous frames that rendered empty (diagnostics / tests)
+
+    def host_slot(self):
+        """A pinned 3-word buffer and an event for one asynchronous read-back.  At most one read-back is pending at a time
+        (the next call polls it before it records its own), so two slots used in turn are never overwritten in flight;
+        allocating pinned memory and an event per call cost ~30 us of host time per step."""
+        if not self._ring:
+            self._ring = [(torch.empty(3, dtype=torch.int32, pin_memory=True), torch.cuda.Event()) for _ in range(2)]
+        self._ring_at ^= 1
+        return self._ring[self._ring_at]
 
     def reset(self) -> None:
         """Forget every calibration (the next call of any shape reads M back and sizes the buffer afresh)."""
@@ -334,9 +344,8 @@ def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, til
             ws.last_n_isect = n_isect                  # device tensor the replaying code polls
             return None, flatten_ids, offsets, None
         if not sync:
-            host = torch.empty(3, dtype=torch.int32, pin_memory=True)
-            host.copy_(ws.words[:3], non_blocking=True)
-            ev = torch.cuda.Event()
+            host, ev = ws.host_slot()
+            host.copy_(ws.words3, non_blocking=True)
             ev.record()
             ws.pending = (host, ev, key)
             return None, flatten_ids, offsets, None

@@ -19,4 +19,6 @@ dev = torch.device("cuda:0")
 torch.cuda.set_stream(torch.cuda.Stream(device=dev))
 args = argparse.Namespace(gaussians=500_000, width=1920, height=1080, steps=steps, warmup=10)
 sc = bench.make_scene(args.gaussians, args.width, args.height, 0, dev)
-print(f"{kind}: {bench.api_path_ms(args, sc, dev, kind):.3f} ms/step (eager, steps 10..{10 + steps} of training)")
+host = {}
+ms = bench.api_path_ms(args, sc, dev, kind, host=host)
+print(f"{kind}: {ms:.3f} ms/step (eager, steps 10..{10 + steps} of training); host enqueue {host['enqueue_ms_per_step']:.3f} ms/step")
