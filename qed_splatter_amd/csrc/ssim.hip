@@ -40,6 +40,17 @@ struct SsimTile {
     static constexpr int SP = TW + 12;                 // patch row stride: 16-float reads stay in the row; odd multiple of 4
     static constexpr int SH = TW + 4;                  // row-pass output stride (odd multiple of 4 floats)
     static constexpr int ROW_ITEMS = PH * (TW / 4);    // row pass: 4 outputs per item
+    // Row-pass work items -> threads.  Item (gx, py) reads 16 floats at py * SP + 4 gx with ds_read_b128, whose 64 lanes are
+    // served in four groups of 16 over 16 four-bank slots: slot = (SP / 4) py + gx + j (mod 16), SP / 4 odd.  Lanes of
+    // one wave with the SAME gx and consecutive py never collide; dealt as consecutive items i -> (i % PH, i / PH), every
+    // wave straddles a column change (PH = 42 rows against 64 lanes) and the reads took 6.5 instead of 4 LDS cycles
+    // (scripts/ubench/lds_patterns, profiles/r03_lds_patterns.txt).  So: one column group per wave and round, lane = row.
+    static constexpr bool WAVE_COLUMNS = PH <= 64;
+    static constexpr int ROW_SLOTS = WAVE_COLUMNS ? 64 * (TW / 4) : ROW_ITEMS;
+    static __device__ __forceinline__ bool row_item(int i, int& gx, int& py) {
+        if constexpr (WAVE_COLUMNS) { gx = i >> 6; py = i & 63; return py < PH; }
+        else { gx = i / PH; py = i - gx * PH; return true; }
+    }
     static constexpr int COL_GROUPS = 256 / TW;
     static constexpr int CB = TH / COL_GROUPS;         // column pass: CB outputs per thread
     static constexpr int RPP = 256 / PW;               // staging: patch rows per pass (thread -> one patch column)
@@ -180,8 +191,9 @@ ssim_fwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
         }
         __syncthreads();
         // rows: window sums of x, y, x^2 + y^2, x y; consecutive lanes take consecutive rows
-        for (int i = tid; i < T::ROW_ITEMS; i += 256) {
-            const int gx = i / PH, py = i - gx * PH;
+        for (int i = tid; i < T::ROW_SLOTS; i += 256) {
+            int gx, py;
+            if (!T::row_item(i, gx, py)) continue;
             float x[16], y[16], p[16];
             read16(&s_x[py * SP + 4 * gx], x);
             read16(&s_y[py * SP + 4 * gx], y);
@@ -411,8 +423,9 @@ ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
                 }
         }
         __syncthreads();
-        for (int i = tid; i < T::ROW_ITEMS; i += 256) {
-            const int gx = i / PH, py = i - gx * PH;
+        for (int i = tid; i < T::ROW_SLOTS; i += 256) {
+            int gx, py;
+            if (!T::row_item(i, gx, py)) continue;
             const int o = py * SH + 4 * gx;
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
