@@ -37,6 +37,7 @@ extern "C" {
 #define QED_TILE 16             /* BLOCK_WIDTH = 16, model.py:243 */
 #define QED_SPLAT_FLOATS 12     /* packed per-(camera,Gaussian) record, see qed_project_fwd */
 #define QED_METRICS_WS_DOUBLES (10 * 1024)  /* workspace of qed_image_metrics */
+#define QED_STEP_METRICS_WS_DOUBLES (16 * 1024)  /* workspace of qed_step_metrics */
 #define QED_LOSS_SUMS_FLOATS (8 + 4 * 1024) /* sums workspace of qed_loss_reduce / qed_loss_grad */
 #define QED_VSPLAT_FLOATS 16    /* packed per-(camera,Gaussian) gradient row, see qed_composite_bwd */
 
@@ -340,6 +341,22 @@ int qed_image_losses_bwd(int32_t n_pix, const float* rgb, const float* depth, co
  * rgb_ssim is qed_ssim_fwd's value; LPIPS (pretrained network) is not provided. */
 int qed_image_metrics(int32_t n_pix, const float* pred_rgb, const float* gt_rgb, const float* pred_depth,
                       const float* gt_depth, float tolerance, double* workspace, float* out, void* stream);
+/* Everything get_metrics_dict (model.py:120-197) needs from one training step's images in ONE streaming pass + ONE fold,
+ * with what get_loss_dict (model.py:73-118) needs from the same images riding along -- two launches instead of the eight
+ * short ones of qed_image_metrics + the SSIM map's sum + qed_nanmean_exp + qed_image_losses_fwd:
+ *   out[0..9]  as qed_image_metrics;
+ *   out[10]    rgb_ssim = ssim_norm * sum(ssim_sum[0 .. ssim_n))  (qed_ssim_fwd's partials; ssim_norm = 1 / (3 (H-10)(W-10));
+ *              NaN when ssim_sum is NULL);
+ *   out[11]    avg_min_scale = nanmean_i exp(scales[i * scale_stride]), i < n_scales (model.py:192-194; NaN when NULL);
+ *   losses[3], loss_sums[QED_LOSS_SUMS_FLOATS] (both may be NULL): exactly what qed_image_losses_fwd(rgb_weight,
+ *              depth_lambda, extra = the SSIM term with weight ssim_lambda, mask = loss_mask) would write for the same
+ *              images -- get_loss_dict then launches nothing in its forward pass.
+ * workspace: QED_STEP_METRICS_WS_DOUBLES doubles. */
+int qed_step_metrics(int32_t n_pix, const float* pred_rgb, const float* gt_rgb, const float* pred_depth,
+                     const float* gt_depth, float tolerance, const float* ssim_sum, int32_t ssim_n, float ssim_norm,
+                     const float* scales, int32_t n_scales, int32_t scale_stride, const float* loss_mask,
+                     float rgb_weight, float depth_lambda, float ssim_lambda, float* loss_sums, float* losses,
+                     double* workspace, float* out, void* stream);
 /* out[0] = nanmean_i exp(x[i * stride]), i < n (NaN when nothing is left) -- the "avg_min_scale" entry of
  * get_metrics_dict (model.py:192-194).  workspace: QED_METRICS_WS_DOUBLES doubles. */
 int qed_nanmean_exp(int32_t n, const float* x, int32_t stride, double* workspace, float* out, void* stream);

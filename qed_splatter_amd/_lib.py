@@ -52,6 +52,7 @@ SIGNATURES = {
     "qed_backproject_depth": (C.c_int, [_I, _I, _P, _F, _F, _F, _F, _P, _F, _I, _L, _P, _P, _P, _P, _P]),
     "qed_image_metrics": (C.c_int, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
     "qed_nanmean_exp": (C.c_int, [_I, _P, _I, _P, _P, _P]),
+    "qed_step_metrics": (C.c_int, [_I, _P, _P, _P, _P, _F, _P, _I, _F, _P, _I, _I, _P, _F, _F, _F, _P, _P, _P, _P, _P]),
     "qed_ssim_maps_floats": (C.c_int64, [_I, _I]),
     "qed_ssim_sum_floats": (C.c_int64, [_I, _I]),
     "qed_ssim_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -78,6 +79,7 @@ class AdamTick(C.Structure):
 # flags (include/qed_splat.h)
 LOSS_SUMS_FLOATS = 8 + 4 * 1024          # QED_LOSS_SUMS_FLOATS
 METRICS_WS_DOUBLES = 10 * 1024           # QED_METRICS_WS_DOUBLES
+STEP_METRICS_WS_DOUBLES = 16 * 1024      # QED_STEP_METRICS_WS_DOUBLES
 F_ANTIALIASED = 1
 F_LOG_SCALES = 2
 F_LOGIT_OPAC = 4

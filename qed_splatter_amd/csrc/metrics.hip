@@ -176,6 +176,152 @@ nanmean_exp_finalize_kernel(int n_blocks, const double* __restrict__ partials, f
     }
 }
 
+// ---- everything get_metrics_dict needs from the images in ONE pass + ONE fold (qed_step_metrics) -------------------
+// The reference-shaped route is made of short launches: PSNR / depth metrics (2 launches), the sum of the SSIM map's
+// per-workgroup partials and its division (2 eager launches), nanmean(exp(scales[:, -1])) (2 launches) and, in
+// get_loss_dict right behind, the L1 / depth-L1 sums of the SAME images (2 launches) -- eight launches of 4-19 us where two
+// do.  Columns 0-9 as metrics_kernel; 10 sum |m rgb - m gt|, 11 sum |m d - m dgt| over valid, 12 their count (the loss
+// terms of qed_image_losses_fwd, mask m); 13 sum exp(scale), 14 count of non-NaN.
+constexpr int kStepCols = 15;
+constexpr int kStepMaxGrid = QED_STEP_METRICS_WS_DOUBLES / 16;
+static_assert(kStepMaxGrid >= 1024, "one slot per workgroup");
+
+__global__ void __launch_bounds__(256)
+step_metrics_kernel(int n_pix, const float* __restrict__ pred_rgb, const float* __restrict__ gt_rgb,
+                    const float* __restrict__ pred_depth, const float* __restrict__ gt_depth, float tolerance,
+                    const float* __restrict__ mask, int want_loss, const float* __restrict__ scales, int n_scales,
+                    int scale_stride, double* __restrict__ partials) {
+    float acc[kStepCols];
+#pragma unroll
+    for (int i = 0; i < kStepCols; ++i) acc[i] = 0.f;
+    constexpr int kU = 4;                                    // pixels per trip, all loads of a trip issued before the first use
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x; i0 < (size_t)n_pix; i0 += kU * stride) {
+        float pr[kU][3], gr[kU][3], pd[kU], gd[kU], mk[kU];
+        bool in[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const size_t iu = i0 + u * stride;
+            in[u] = iu < (size_t)n_pix;
+            const size_t i = in[u] ? iu : i0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { pr[u][k] = pred_rgb[3 * i + k]; gr[u][k] = gt_rgb[3 * i + k]; }
+            pd[u] = pred_depth != nullptr ? pred_depth[i] : 0.f;
+            gd[u] = pred_depth != nullptr ? gt_depth[i] : 0.f;
+            mk[u] = mask != nullptr ? mask[i] : 1.f;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            if (!in[u]) continue;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float d = pr[u][k] - gr[u][k];
+                acc[0] += d * d;
+                if (want_loss) acc[10] += fabsf(pr[u][k] * mk[u] - gr[u][k] * mk[u]);
+            }
+            if (pred_depth != nullptr) {
+                const float p = pd[u], g = gd[u];
+                if (isfinite(p) && isfinite(g) && g > tolerance) {
+                    const float d = g - p;
+                    acc[1] += 1.f;
+                    acc[2] += fabsf(d) / g;
+                    acc[3] += d * d / g;
+                    acc[4] += d * d;
+                    const float l = logf(g) - logf(p);
+                    const float l2 = l * l;
+                    if (!isnan(l2)) { acc[5] += l2; acc[6] += 1.f; }
+                    const float t = fmaxf(g / p, p / g);
+                    acc[7] += t < 1.25f ? 1.f : 0.f;
+                    acc[8] += t < 1.25f * 1.25f ? 1.f : 0.f;
+                    acc[9] += t < 1.25f * 1.25f * 1.25f ? 1.f : 0.f;
+                }
+                if (want_loss) {                               // model.py:93-105: masked depths, finite, target > 0
+                    const float dp = p * mk[u], dg = g * mk[u];
+                    if (isfinite(dp) && isfinite(dg) && dg > 0.f) { acc[11] += fabsf(dp - dg); acc[12] += 1.f; }
+                }
+            }
+        }
+    }
+    if (scales != nullptr) {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n_scales; i += stride) {
+            const float e = expf(scales[i * (size_t)scale_stride]);
+            if (!isnan(e)) { acc[13] += e; acc[14] += 1.f; }
+        }
+    }
+    __shared__ double s_tmp[kStepCols * 4];
+#pragma unroll
+    for (int i = 0; i < kStepCols; ++i) park_wave_sum(acc[i], s_tmp, i);
+    __syncthreads();
+    if (threadIdx.x < kStepCols) {
+        const int i = threadIdx.x;
+        partials[(size_t)i * kStepMaxGrid + blockIdx.x] = s_tmp[4 * i] + s_tmp[4 * i + 1] + s_tmp[4 * i + 2] + s_tmp[4 * i + 3];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+step_metrics_finalize_kernel(int n_pix, int n_blocks, int has_depth, const double* __restrict__ partials,
+                             const float* __restrict__ ssim_sum, int ssim_n, float ssim_norm, int has_scales,
+                             float rgb_weight, float depth_lambda, float ssim_lambda, float* __restrict__ loss_sums,
+                             float* __restrict__ losses, float* __restrict__ out) {
+    __shared__ double s_w[kStepCols + 1][4];
+    __shared__ double s[kStepCols + 1];
+    double v[kStepCols + 1];
+#pragma unroll
+    for (int c = 0; c <= kStepCols; ++c) v[c] = 0.0;
+    for (int b = threadIdx.x; b < n_blocks; b += 256) {       // (all columns of a row of partials requested together)
+#pragma unroll
+        for (int c = 0; c < kStepCols; ++c) v[c] += partials[(size_t)c * kStepMaxGrid + b];
+    }
+    if (ssim_sum != nullptr) {
+        for (int b0 = threadIdx.x; b0 < ssim_n; b0 += 8 * 256) {
+            float e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = ssim_sum[b0 + 256 * j < ssim_n ? b0 + 256 * j : 0];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[kStepCols] += b0 + 256 * j < ssim_n ? (double)e[j] : 0.0;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c <= kStepCols; ++c) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[c] += __shfl_xor(v[c], o, 64);
+        if ((threadIdx.x & 63) == 0) s_w[c][threadIdx.x >> 6] = v[c];
+    }
+    __syncthreads();
+    if (threadIdx.x <= kStepCols) s[threadIdx.x] = s_w[threadIdx.x][0] + s_w[threadIdx.x][1] + s_w[threadIdx.x][2] + s_w[threadIdx.x][3];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const float nanv = __builtin_nanf("");
+    const double mse = s[0] / (3.0 * (double)n_pix);
+    out[0] = (float)mse;
+    out[1] = (float)(10.0 * log10(1.0 / mse));
+    const double n = s[1];
+    if (has_depth && n > 0.0) {
+        out[2] = (float)(s[2] / n);
+        out[3] = (float)(s[3] / n);
+        out[4] = (float)sqrt(s[4] / n);
+        out[5] = s[6] > 0.0 ? (float)sqrt(s[5] / s[6]) : nanv;
+        out[6] = (float)(s[7] / n);
+        out[7] = (float)(s[8] / n);
+        out[8] = (float)(s[9] / n);
+    } else {
+        for (int i = 2; i < 9; ++i) out[i] = nanv;
+    }
+    out[9] = (float)n;
+    out[10] = ssim_sum != nullptr ? (float)(s[kStepCols] * (double)ssim_norm) : nanv;
+    out[11] = has_scales && s[14] > 0.0 ? (float)(s[13] / s[14]) : nanv;          // torch.nanmean of nothing is NaN
+    if (losses != nullptr) {
+        // what qed_image_losses_fwd leaves: the two scalar losses, their sum, and sums[2] = n_valid for the backward pass
+        const float tot_l1 = (float)s[10], tot_d = (float)s[11], nvalid = (float)s[12];
+        loss_sums[0] = tot_l1; loss_sums[1] = tot_d; loss_sums[2] = nvalid; loss_sums[3] = 0.f;
+        losses[0] = rgb_weight * tot_l1 / (3.f * (float)n_pix);
+        if (ssim_sum != nullptr && ssim_lambda > 0.f)
+            losses[0] += ssim_lambda - ssim_lambda * (float)(s[kStepCols] * (double)ssim_norm);
+        losses[1] = nvalid > 0.f ? depth_lambda * tot_d / nvalid : 0.f;             // empty -> 0.0 (model.py:111-114)
+        losses[2] = losses[0] + losses[1];
+    }
+}
+
 }  // namespace qed
 
 using namespace qed;
@@ -206,4 +352,26 @@ extern "C" int qed_image_metrics(int32_t n_pix, const float* pred_rgb, const flo
     hipLaunchKernelGGL(metrics_finalize_kernel, dim3(1), dim3(256), 0, st, n_pix, (int)g, pred_rgb != nullptr ? 1 : 0,
                        pred_depth != nullptr ? 1 : 0, (const double*)workspace, out);
     return check_launch("qed_image_metrics");
+}
+
+extern "C" int qed_step_metrics(int32_t n_pix, const float* pred_rgb, const float* gt_rgb, const float* pred_depth,
+                                const float* gt_depth, float tolerance, const float* ssim_sum, int32_t ssim_n,
+                                float ssim_norm, const float* scales, int32_t n_scales, int32_t scale_stride,
+                                const float* loss_mask, float rgb_weight, float depth_lambda, float ssim_lambda,
+                                float* loss_sums, float* losses, double* workspace, float* out, void* stream) {
+    QED_REQUIRE(n_pix > 0 && pred_rgb && gt_rgb && workspace && out, "bad arguments");
+    QED_REQUIRE((pred_depth == nullptr) == (gt_depth == nullptr), "pred_depth and gt_depth go together");
+    QED_REQUIRE(ssim_sum == nullptr || ssim_n > 0, "ssim_sum needs its length");
+    QED_REQUIRE(scales == nullptr || (n_scales > 0 && scale_stride >= 1), "scales need a length and a stride");
+    QED_REQUIRE((loss_sums == nullptr) == (losses == nullptr), "loss_sums and losses go together");
+    QED_REQUIRE(losses != nullptr || loss_mask == nullptr, "a loss mask without loss outputs");
+    hipStream_t st = (hipStream_t)stream;
+    long long g = ((long long)n_pix + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(step_metrics_kernel, dim3((unsigned)g), dim3(256), 0, st, n_pix, pred_rgb, gt_rgb, pred_depth,
+                       gt_depth, tolerance, loss_mask, losses != nullptr ? 1 : 0, scales, n_scales, scale_stride, workspace);
+    hipLaunchKernelGGL(step_metrics_finalize_kernel, dim3(1), dim3(256), 0, st, n_pix, (int)g, pred_depth != nullptr ? 1 : 0,
+                       (const double*)workspace, ssim_sum, ssim_n, ssim_norm, scales != nullptr ? 1 : 0, rgb_weight,
+                       depth_lambda, ssim_lambda, loss_sums, losses, out);
+    return check_launch("qed_step_metrics");
 }

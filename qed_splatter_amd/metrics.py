@@ -89,6 +89,59 @@ def ssim_value(pred_rgb: Tensor, gt_rgb: Tensor, keep_maps: bool = False):
 
 
 @torch.no_grad()
+def step_metrics(pred_rgb: Tensor, gt_rgb: Tensor, pred_depth: Optional[Tensor], gt_depth: Optional[Tensor],
+                 scales_last: Optional[Tensor], ssim_lambda: float, depth_lambda: float, tolerance: float = 0.1):
+    """The whole of get_metrics_dict's image arithmetic for one TRAINING step in three launches -- qed_ssim_fwd (with the
+    coefficient maps the loss's backward pass needs) + qed_step_metrics (one streaming pass, one fold): MSE / PSNR, the
+    seven depth metrics, the SSIM value, avg_min_scale, and the loss sums get_loss_dict would compute from the same images
+    a moment later.  Returns (metrics dict, shared) where ``shared`` is what QEDSplatterModel.get_loss_dict takes over:
+    {"key", "maps_sum", "inputs", "loss": (sums, losses), "depth_key"}."""
+    lib = L.load()
+    H, W, _ = pred_rgb.shape
+    n_pix = H * W
+    dev = pred_rgb.device
+
+    def prep(t, last):
+        if t is None:
+            return None
+        t = t.to(torch.float32).contiguous()
+        assert t.numel() == n_pix * last, "shape mismatch between the images"
+        return t
+
+    p, g = prep(pred_rgb, 3), prep(gt_rgb, 3)
+    pd, gd = prep(pred_depth, 1), prep(gt_depth, 1)
+    n_maps = lib.qed_ssim_maps_floats(H, W)
+    if n_maps < 0:
+        raise L.QedSplatError("image smaller than the 11 x 11 SSIM window")
+    st = _stream()
+    ssum = torch.empty(lib.qed_ssim_sum_floats(H, W), dtype=torch.float32, device=dev)
+    maps = torch.empty(n_maps, dtype=torch.float32, device=dev)
+    L.check(lib.qed_ssim_fwd(H, W, 3, L.ptr(p), None, None, L.ptr(g), None, L.ptr(maps), L.ptr(ssum), st), "qed_ssim_fwd")
+    work = torch.empty(L.STEP_METRICS_WS_DOUBLES, dtype=torch.float64, device=dev)
+    out = torch.empty(12, dtype=torch.float32, device=dev)
+    sums = torch.empty(L.LOSS_SUMS_FLOATS, dtype=torch.float32, device=dev)
+    losses = torch.empty(3, dtype=torch.float32, device=dev)
+    n_sc, sc_stride = (0, 1)
+    if scales_last is not None:
+        assert scales_last.dim() == 1 and scales_last.dtype == torch.float32
+        n_sc, sc_stride = scales_last.numel(), (scales_last.stride(0) if scales_last.numel() > 1 else 1)
+    L.check(lib.qed_step_metrics(n_pix, L.ptr(p), L.ptr(g), L.ptr(pd), L.ptr(gd), float(tolerance), L.ptr(ssum), ssum.numel(),
+                                 1.0 / (3.0 * (H - 10) * (W - 10)), L.ptr(scales_last) if n_sc else None, n_sc, sc_stride,
+                                 None, 1.0 - ssim_lambda, float(depth_lambda), float(ssim_lambda), L.ptr(sums), L.ptr(losses),
+                                 L.ptr(work), L.ptr(out), st), "qed_step_metrics")
+    md = {"rgb_mse": out[0], "rgb_psnr": out[1], "rgb_ssim": out[10], "rgb_lpips": _nan(dev)}
+    if pd is not None:
+        md.update({n: out[i] for i, n in enumerate(METRIC_NAMES) if n.startswith("depth_") and n != "depth_n_valid"})
+    if n_sc:
+        md["avg_min_scale"] = out[11]
+    key = (p.data_ptr(), p._version, tuple(p.shape), g.data_ptr(), g._version, tuple(g.shape))
+    shared = {"key": key, "maps_sum": (maps, ssum), "inputs": (p, g, pd, gd), "loss": (sums, losses),
+              "depth_key": None if pd is None else (pd.data_ptr(), pd._version, gd.data_ptr(), gd._version),
+              "lambdas": (float(ssim_lambda), float(depth_lambda))}
+    return md, shared
+
+
+@torch.no_grad()
 def nanmean_exp(x: Tensor) -> Tensor:
     """``torch.nanmean(torch.exp(x))`` of a (possibly strided) 1-D view as one pass + a fold (model.py:192-194 applies it
     to ``self.scales[..., -1]`` every step: ~8 eager launches in the reference)."""

@@ -254,7 +254,7 @@ class _ImageLosses(torch.autograd.Function):
     multiplies each term's gradient by its upstream gradient, read from device memory."""
 
     @staticmethod
-    def forward(ctx, rgb, depth, gt_rgb, gt_depth, mask, ssim_lambda, depth_lambda, ssim_shared=None):
+    def forward(ctx, rgb, depth, gt_rgb, gt_depth, mask, ssim_lambda, depth_lambda, ssim_shared=None, loss_shared=None):
         lib = L.load()
         ctx.set_materialize_grads(False)
         if not rgb.is_cuda:
@@ -265,6 +265,13 @@ class _ImageLosses(torch.autograd.Function):
         rgb = rgb.contiguous()
         depth = depth.contiguous() if depth is not None else None
         st = _stream()
+        if loss_shared is not None and ssim_shared is not None:
+            # get_metrics_dict ran qed_step_metrics on these very images a moment ago: the sums and the two losses exist
+            sums, losses = loss_shared
+            maps = ssim_shared[0]
+            ctx.save_for_backward(rgb, depth, gt_rgb, gt_depth, mask, maps, sums)
+            ctx.lams = (float(ssim_lambda), float(depth_lambda))
+            return losses[0:1].view(()), losses[1:2].view(())
         sums = torch.empty(L.LOSS_SUMS_FLOATS, dtype=torch.float32, device=dev)
         losses = torch.empty(3, dtype=torch.float32, device=dev)
         maps = None
@@ -316,7 +323,7 @@ class _ImageLosses(torch.autograd.Function):
             L.check(lib.qed_image_losses_bwd(H * W, L.ptr(rgb), L.ptr(depth), L.ptr(gt_rgb), L.ptr(gt_depth), L.ptr(mask),
                                              L.ptr(sums), 1.0 - ssim_lambda, depth_lambda, L.ptr(g_main), L.ptr(g_depth), 0,
                                              L.ptr(v_rgb), L.ptr(v_depth), st), "qed_image_losses_bwd")
-        return v_rgb, v_depth, None, None, None, None, None, None
+        return v_rgb, v_depth, None, None, None, None, None, None, None
 
 
 class _FusedImageLoss(torch.autograd.Function):
@@ -755,8 +762,15 @@ class QEDSplatterModel(nn.Module):
         if shared is not None and (mask is not None or cfg.ssim_lambda <= 0.0 or
                                    shared["key"] != _ssim_key(pred_img.contiguous(), gt_img)):
             shared = None
+        # ... and its L1 / depth sums, when get_metrics_dict took them along (same depth tensors, same weights)
+        loss_shared = None
+        if shared is not None and shared.get("loss") is not None:
+            dc = depth_out.contiguous()
+            if shared["depth_key"] == (dc.data_ptr(), dc._version, depth_batch.data_ptr(), depth_batch._version) \
+                    and shared["lambdas"] == (float(cfg.ssim_lambda), float(cfg.depth_lambda)):
+                loss_shared = shared["loss"]
         main, depth = _ImageLosses.apply(pred_img, depth_out, gt_img, depth_batch, mask, float(cfg.ssim_lambda),
-                                         float(cfg.depth_lambda), shared["maps_sum"] if shared else None)
+                                         float(cfg.depth_lambda), shared["maps_sum"] if shared else None, loss_shared)
         return {"main_loss": main, "scale_reg": self._scale_reg(), "depth_loss": depth}
 
     # ---- get_metrics_dict (model.py:120-197) ----
@@ -790,6 +804,14 @@ class QEDSplatterModel(nn.Module):
         keep = (self.training and torch.is_grad_enabled() and self.config.ssim_lambda > 0.0 and d <= 1
                 and pred_rgb.is_cuda and pred_rgb.dtype == torch.float32)
         with torch.no_grad():
+            if keep and has_depth:
+                # a training step: the metrics, and what the loss that follows needs from the same images, in one pass
+                from .metrics import step_metrics
+                out, shared = step_metrics(pred_rgb.detach(), gt_rgb, outputs["depth"].detach(), gt_depth,
+                                           self.scales[..., -1], float(self.config.ssim_lambda), float(self.config.depth_lambda))
+                self.__dict__["_ssim_shared"] = shared
+                out["gaussian_count"] = self.num_points
+                return out
             out = dict(_image_metrics(pred_rgb.detach(), gt_rgb, outputs["depth"].detach() if has_depth else None, gt_depth,
                                       keep_ssim_maps=keep))
             self.__dict__["_ssim_shared"] = out.pop("_ssim_shared", None)

@@ -484,17 +484,32 @@ def test_ssim_forward_shared_between_metrics_and_loss(cuda, uint8_image):
         finally:
             L.TIMER.active = False
         n_fwd = len(L.TIMER.events.get("qed_ssim_fwd", []))
+        calls = {k: len(v) for k, v in L.TIMER.events.items()}
         sum(ld.values()).backward()
         assert getattr(m, "_ssim_shared", None) is None              # consumed (or never made)
+        run.last = (m, out, batch, calls)
         return md, ld, out["rgb"].grad.clone(), n_fwd
 
     _, ld0, g0, n0 = run(False)
     md1, ld1, g1, n1 = run(True)
     assert n0 == 1 and n1 == 1, (n0, n1)                              # metrics + loss: still ONE SSIM forward
-    assert torch.equal(ld1["main_loss"], ld0["main_loss"]) and torch.equal(ld1["depth_loss"], ld0["depth_loss"])
+    # ... and ONE reduction pass: qed_step_metrics took the loss sums along, get_loss_dict's forward launched nothing
+    m1, out1, batch1, calls = run.last
+    assert calls.get("qed_step_metrics") == 1 and "qed_image_losses_fwd" not in calls and "qed_image_metrics" not in calls \
+        and "qed_nanmean_exp" not in calls, calls
+    assert float(ld1["main_loss"]) == pytest.approx(float(ld0["main_loss"]), rel=2e-6)      # (fp64 fold vs fp32 fold)
+    assert float(ld1["depth_loss"]) == pytest.approx(float(ld0["depth_loss"]), rel=2e-6)
     assert torch.equal(g1, g0)
     # rgb_ssim is the value the loss used: main = 0.8 L1 + 0.2 (1 - ssim)
     assert 0.0 < float(md1["rgb_ssim"]) < 1.0
+    # the one-pass metrics equal the separate entry points' (the eval-mode route of get_metrics_dict)
+    from qed_splatter_amd.metrics import metrics_dict, nanmean_exp
+    ref = metrics_dict(out1["rgb"].detach(), m1.get_gt_img(batch1["image"])[..., :3], out1["depth"].detach(), batch1["depth_image"])
+    for k, v in ref.items():
+        if k != "rgb_lpips":
+            assert float(md1[k]) == pytest.approx(float(v), rel=1e-5), k
+    assert float(md1["avg_min_scale"]) == pytest.approx(float(nanmean_exp(m1.scales[..., -1].detach())), rel=1e-6)
+    assert md1["gaussian_count"] == n and set(md1) == set(ref) | {"gaussian_count", "avg_min_scale"}
 
     def add_mask(m, out, batch):
         batch["mask"] = torch.ones(h, w, 1, device=cuda)
