@@ -193,6 +193,26 @@ int qed_tile_offsets(const uint64_t* sorted_keys, const int32_t* n_dev, int64_t 
  * not change (parity tests).
  * tile_cost (may be NULL; [C*tiles][4] i32): receives, per tile and quadrant wave, the number of (Gaussian, quadrant)
  * visits + a staging term per batch -- the work predictor qed_composite_bwd orders its launch by. */
+/* get_outputs' post-processing (model.py:295-297, 304-306) folded into the compositing kernels -- the reference-shaped route
+ * then has no pass of its own over the image between the rasterizer and the loss, in either direction:
+ *   qed_post_t (forward, may be NULL): rgb[C,H,W,3] = clamp(render[..., :3] + (1 - alpha) background[3], 0, 1) is written by
+ *     the compositing kernel beside render; with a depth channel, depth[C,H,W] = alpha > 0 ? render[..., 3] : max render[..., 3]
+ *     (one extra pass over alpha that patches the empty pixels; tile_dmax: C * tiles * 4 floats of scratch);
+ *   qed_post_grad_t (backward, may be NULL): v_render / v_alpha are derived per pixel from v_rgb[C,H,W,3] and v_depth[C,H,W]
+ *     (either may be NULL = no gradient) in the tile prologue: pass NULL for v_render and v_alpha; render = the forward
+ *     pass's output.  Same arithmetic as qed_post_process_fwd / _bwd. */
+typedef struct {
+    const float* background;
+    float* rgb;
+    float* depth;
+    float* tile_dmax;
+} qed_post_t;
+typedef struct {
+    const float* background;
+    const float* render;
+    const float* v_rgb;
+    const float* v_depth;
+} qed_post_grad_t;
 #define QED_CL_TILE_WAVES 1
 #define QED_CL_QUADRANT_WAVES 2
 #define QED_CL_HALF_AND_HALF 3
@@ -200,7 +220,8 @@ int qed_tile_offsets(const uint64_t* sorted_keys, const int32_t* n_dev, int64_t 
 int qed_composite_fwd(int32_t C, int32_t N, const float* splats, const int32_t* flatten_ids,
                       const int32_t* offsets, int32_t width, int32_t height, int32_t tile_w,
                       int32_t tile_h, int32_t channels, const float* backgrounds, float* render,
-                      float* alpha, int32_t* last_ids, int32_t* tile_cost, int32_t launch_flags, void* stream);
+                      float* alpha, int32_t* last_ids, int32_t* tile_cost, const qed_post_t* post,
+                      int32_t launch_flags, void* stream);
 
 /* ---- K7: alpha compositing backward ------------------------------------------------------------
  * Back-to-front replay from last_ids; per-pixel gradients are reduced across each 64-wide wave
@@ -216,7 +237,7 @@ int qed_composite_bwd(int32_t C, int32_t N, const float* splats, const int32_t* 
                       int32_t tile_h, int32_t channels, const float* backgrounds,
                       const float* render_alpha, const int32_t* last_ids, const float* v_render,
                       const float* v_alpha, float* vsplat, const int32_t* tile_cost, int32_t* order_ws,
-                      int32_t launch_flags, void* stream);
+                      const qed_post_grad_t* post, int32_t launch_flags, void* stream);
 
 /* ---- K8: fused image-space loss + gradient ------------------------------------------------------
  * Collapses model.py:295-297 (background composite + clamp), :304-306 (depth fix-up), :87-116

@@ -37,8 +37,8 @@ SIGNATURES = {
     "qed_tile_offsets": (C.c_int, [_P, _P, _L, _I, _I, _I, _P, _P]),
     "qed_bin_workspace_bytes": (_L, [_L, _L]),
     "qed_bin_tiles": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P, _P, _P, _P, _L, _P, _P]),
-    "qed_composite_fwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
-    "qed_composite_bwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "qed_composite_fwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "qed_composite_bwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "qed_loss_reduce": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qed_loss_grad": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _I, _F, _F, _P]),
     "qed_sh_grad_from_views": (C.c_int, [_I, _I, _P, _P, _L, _P, _L, _I, _F, _P, _I, _P, _I, _P]),
@@ -69,6 +69,16 @@ SIGNATURES = {
     "qed_adam_step_sh": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _P, _D, _D, _F, _I, _P, _I, _F, _F, _I, _I, _I, _P, _I,
                                    _P, _L, _P, _L, _F, _I, _P, _P]),
 }
+
+class Post(C.Structure):
+    """qed_post_t (include/qed_splat.h): get_outputs' post-processing outputs of qed_composite_fwd."""
+    _fields_ = [("background", C.c_void_p), ("rgb", C.c_void_p), ("depth", C.c_void_p), ("tile_dmax", C.c_void_p)]
+
+
+class PostGrad(C.Structure):
+    """qed_post_grad_t: the gradients of those outputs, consumed by qed_composite_bwd."""
+    _fields_ = [("background", C.c_void_p), ("render", C.c_void_p), ("v_rgb", C.c_void_p), ("v_depth", C.c_void_p)]
+
 
 class AdamTick(C.Structure):
     """qed_adam_tick_t (include/qed_splat.h): the optimiser's device step state, advanced by qed_loss_grad_ssim."""

@@ -165,6 +165,7 @@ __device__ __forceinline__ void quadrant_masks(bool present, const float4& r0, c
 // arithmetic is written on 2-vectors: (dx, dy), colour pairs, gradient pairs.  Wave-uniform Gaussian
 // data arrive as SGPR pairs.
 typedef float f2 __attribute__((ext_vector_type(2)));
+struct __attribute__((packed, aligned(4))) Float3 { float a, b, c; };
 
 __device__ __forceinline__ u64 uniform_u64(u64 v) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
@@ -179,6 +180,23 @@ __device__ __forceinline__ float neg_sigma_log2e(f2 d, f2 AC, float B) {
     const f2 m = d * (f2){u, t.y};                      // (dx (A dx + B dy), C dy^2)
     return m.x + m.y;
 }
+
+// get_outputs' post-processing folded into the compositing kernels (model.py:295-297, 304-306; the reference-shaped route):
+//   forward:  rgb = clamp(render[:3] + (1 - alpha) background, 0, 1) written beside render, the depth channel copied to its own
+//             image, and every wave's largest depth parked for the fix-up pass that follows (depth = alpha > 0 ? d : max d);
+//   backward: v_render / v_alpha derived per pixel from v_rgb / v_depth in the tile prologue -- no separate pass over the image.
+struct FwdPost {
+    const float* bg;        // [3]; NULL: no post-processing outputs
+    float* rgb;             // [C,H,W,3]
+    float* depth;           // [C,H,W] (NULL with 3 channels)
+    float* tile_dmax;       // [C*tiles][4]
+};
+struct BwdPost {
+    const float* bg;        // [3]; NULL: v_render / v_alpha are given
+    const float* render;    // [C,H,W,CH] the forward pass's render
+    const float* v_rgb;     // [C,H,W,3] (may be NULL: no gradient)
+    const float* v_depth;   // [C,H,W]   (may be NULL)
+};
 
 struct FwdPixel {
     float T;
@@ -218,7 +236,7 @@ __device__ __forceinline__ void fwd_tile(int tile, int qf, float (*s_rec)[kRecFl
                                          const int* __restrict__ flatten_ids, const int* __restrict__ offsets, int width,
                                          int height, int tile_w, int tile_h, const float* __restrict__ backgrounds,
                                          float* __restrict__ render, float* __restrict__ alpha_out,
-                                         int* __restrict__ last_ids, int* __restrict__ tile_cost) {
+                                         int* __restrict__ last_ids, int* __restrict__ tile_cost, const FwdPost& post) {
     const int q0 = qf & 3;                               // bit 2 of qf: culling off (test hook)
     int n_vis = 0;                                       // quadrant visits of this wave (wave-uniform): K7's work predictor
     const int n_tiles = tile_w * tile_h;
@@ -307,7 +325,7 @@ __device__ __forceinline__ void fwd_tile(int tile, int qf, float (*s_rec)[kRecFl
             for (int q = 0; q < NQ; ++q) {
                 if (!(mq[q] & bit)) continue;           // wave-uniform: this quadrant cannot see Gaussian t
                 QED_STAT(3, 1);
-                ++n_vis;
+                asm volatile("s_add_u32 %0, %0, 1" : "+s"(n_vis));      // (a scalar counter: as `++n_vis` it took a VGPR and spilled)
                 fwd_quadrant<CH>(pq[q], XY, AC, B, op, col01, col23, idx_v, done[q], px[q]);
                 if (done[q] == ~0ull) {                 // quadrant finished: drop it from the masks
                     mq[q] = 0;
@@ -339,6 +357,7 @@ __device__ __forceinline__ void fwd_tile(int tile, int qf, float (*s_rec)[kRecFl
         rid_n = rid_nn;
         present = start + (b + 1) * kBatch + lane < end;
     }
+    float post_dmax = -3.0e38f;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         if (inside[q]) {
@@ -355,9 +374,24 @@ __device__ __forceinline__ void fwd_tile(int tile, int qf, float (*s_rec)[kRecFl
             } else {
                 render[3 * pix] = out[0]; render[3 * pix + 1] = out[1]; render[3 * pix + 2] = out[2];
             }
-            alpha_out[pix] = 1.f - px[q].T;
+            const float a_out = 1.f - px[q].T;
+            alpha_out[pix] = a_out;
             last_ids[pix] = px[q].cur;
+            if (post.bg != nullptr) {
+                const float om = 1.f - a_out;            // (as the separate pass forms it from the stored alpha)
+                Float3 c;
+                c.a = fminf(fmaxf(out[0] + om * post.bg[0], 0.f), 1.f);
+                c.b = fminf(fmaxf(out[1] + om * post.bg[1], 0.f), 1.f);
+                c.c = fminf(fmaxf(out[2] + om * post.bg[2], 0.f), 1.f);
+                *reinterpret_cast<Float3*>(post.rgb + 3 * pix) = c;
+                if constexpr (CH == 4) { post.depth[pix] = out[3]; post_dmax = fmaxf(post_dmax, out[3]); }
+            }
         }
+    }
+    if (post.bg != nullptr && CH == 4) {
+        post_dmax = wave_max(post_dmax);
+        if constexpr (NQ == 4) { if (lane < 4) post.tile_dmax[4 * tile + lane] = lane == 0 ? post_dmax : -3.0e38f; }
+        else { if (lane == 0) post.tile_dmax[4 * tile + q0] = post_dmax; }
     }
     // What the backward pass will cost on this tile: its quadrant visits are (within a per cent) the forward pass's, plus a
     // staging term per batch.  [tile][quadrant] so that whole-tile and quadrant waves both write without initialisation.
@@ -415,7 +449,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QED_K6_
 composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __restrict__ flatten_ids,
                      const int* __restrict__ offsets, int width, int height, int tile_w, int tile_h,
                      const float* __restrict__ backgrounds, float* __restrict__ render, float* __restrict__ alpha_out,
-                     int* __restrict__ last_ids, int* __restrict__ tile_cost, int n_big_flags) {
+                     int* __restrict__ last_ids, int* __restrict__ tile_cost, int n_big_flags, FwdPost post) {
     __shared__ __attribute__((aligned(16))) float s_rec[kBatch][kRecFloats];
     const int n_total = C * tile_w * tile_h;
     const int b = blockIdx.x;
@@ -423,12 +457,12 @@ composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
     const int n_big = n_big_flags & 0x3fffffff;
     if (b < n_big) {
         fwd_tile<CH, 4>(xcd_remap(b, n_total), keep_all, s_rec, C, splats, flatten_ids, offsets, width, height, tile_w,
-                        tile_h, backgrounds, render, alpha_out, last_ids, tile_cost);
+                        tile_h, backgrounds, render, alpha_out, last_ids, tile_cost, post);
     } else {
         int t, q;
         small_wave(b - n_big, n_total - n_big, t, q);
         fwd_tile<CH, 1>(xcd_remap(n_big + t, n_total), q | keep_all, s_rec, C, splats, flatten_ids, offsets, width, height,
-                        tile_w, tile_h, backgrounds, render, alpha_out, last_ids, tile_cost);
+                        tile_w, tile_h, backgrounds, render, alpha_out, last_ids, tile_cost, post);
     }
 }
 
@@ -557,7 +591,7 @@ __device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_acc)[12], f
                                          int height, int tile_w, int tile_h, const float* __restrict__ backgrounds,
                                          const float* __restrict__ render_alpha, const int* __restrict__ last_ids,
                                          const float* __restrict__ v_render, const float* __restrict__ v_alpha,
-                                         float* __restrict__ vsplat) {
+                                         float* __restrict__ vsplat, const BwdPost& post) {
     const int q0 = qf & 3;                               // bit 2 of qf: culling off (test hook)
     const int n_tiles = tile_w * tile_h;
     const int cam = tile / n_tiles;
@@ -585,14 +619,40 @@ __device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_acc)[12], f
         px[q].bin_final = -1;
         if (inside) {
             const size_t pix = ((size_t)cam * height + iy) * width + ix;
-            T_final = 1.f - render_alpha[pix];
+            const float a_px = render_alpha[pix];
+            T_final = 1.f - a_px;
             px[q].bin_final = last_ids[pix];
-            vra = v_alpha[pix];
-            if constexpr (CH == 4) {
-                const float4 t4 = *reinterpret_cast<const float4*>(v_render + 4 * pix);
-                vr[0] = t4.x; vr[1] = t4.y; vr[2] = t4.z; vr[3] = t4.w;
+            if (post.bg == nullptr) {
+                vra = v_alpha[pix];
+                if constexpr (CH == 4) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(v_render + 4 * pix);
+                    vr[0] = t4.x; vr[1] = t4.y; vr[2] = t4.z; vr[3] = t4.w;
+                } else {
+                    vr[0] = v_render[3 * pix]; vr[1] = v_render[3 * pix + 1]; vr[2] = v_render[3 * pix + 2];
+                }
             } else {
-                vr[0] = v_render[3 * pix]; vr[1] = v_render[3 * pix + 1]; vr[2] = v_render[3 * pix + 2];
+                // the backward of rgb = clamp(render + (1 - alpha) bg, 0, 1) and depth = alpha > 0 ? d : max d (detached), here
+                // instead of in a pass of its own (qed_post_process_bwd's arithmetic)
+                float c[3];
+                if constexpr (CH == 4) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(post.render + 4 * pix);
+                    c[0] = t4.x; c[1] = t4.y; c[2] = t4.z;
+                } else {
+                    c[0] = post.render[3 * pix]; c[1] = post.render[3 * pix + 1]; c[2] = post.render[3 * pix + 2];
+                }
+                if (post.v_rgb != nullptr) {
+                    const Float3 g3 = *reinterpret_cast<const Float3*>(post.v_rgb + 3 * pix);
+                    const float g[3] = {g3.a, g3.b, g3.c};
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const float pre = c[k] + (1.f - a_px) * post.bg[k];
+                        vr[k] = (pre >= 0.f && pre <= 1.f) ? g[k] : 0.f;               // torch.clamp backward (inclusive)
+                        vra -= vr[k] * post.bg[k];
+                    }
+                }
+                if constexpr (CH == 4) {
+                    if (post.v_depth != nullptr && a_px > 0.f) vr[3] = post.v_depth[pix];
+                }
             }
             if (backgrounds != nullptr) {
                 // render = sum + T_final * bg  ->  d render / d T_final folds into the alpha gradient
@@ -823,7 +883,7 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
                      const float* __restrict__ backgrounds, const float* __restrict__ render_alpha,
                      const int* __restrict__ last_ids, const float* __restrict__ v_render,
                      const float* __restrict__ v_alpha, float* __restrict__ vsplat, int n_big_flags,
-                     const int* __restrict__ tile_order, const int* __restrict__ n_split_dev) {
+                     const int* __restrict__ tile_order, const int* __restrict__ n_split_dev, BwdPost post) {
 #ifdef QED_K7_LDS_REDUCE
     float (*s_acc)[12] = nullptr;
     __shared__ __attribute__((aligned(16))) float s_part[kParkSlots * kParkSlot];
@@ -844,24 +904,46 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
         const int n_split = n_split_dev[0];
         if (b < 4 * n_split) {
             bwd_tile<CH, 1>(tile_order[b >> 2], (b & 3) | keep_all, s_acc, s_rec, s_part, C, splats, flatten_ids, offsets,
-                            width, height, tile_w, tile_h, backgrounds, render_alpha, last_ids, v_render, v_alpha, vsplat);
+                            width, height, tile_w, tile_h, backgrounds, render_alpha, last_ids, v_render, v_alpha, vsplat, post);
         } else {
             const int i = b - 3 * n_split;
             if (i >= n_total) return;                    // (the grid is sized for the largest n_split the host allows)
             bwd_tile<CH, 4>(tile_order[i], keep_all, s_acc, s_rec, s_part, C, splats, flatten_ids, offsets, width, height,
-                            tile_w, tile_h, backgrounds, render_alpha, last_ids, v_render, v_alpha, vsplat);
+                            tile_w, tile_h, backgrounds, render_alpha, last_ids, v_render, v_alpha, vsplat, post);
         }
         return;
     }
     if (b < n_big) {
         bwd_tile<CH, 4>(xcd_remap(b, n_total), keep_all, s_acc, s_rec, s_part, C, splats, flatten_ids, offsets, width, height, tile_w, tile_h,
-                        backgrounds, render_alpha, last_ids, v_render, v_alpha, vsplat);
+                        backgrounds, render_alpha, last_ids, v_render, v_alpha, vsplat, post);
     } else {
         int t, q;
         small_wave(b - n_big, n_total - n_big, t, q);
         bwd_tile<CH, 1>(xcd_remap(n_big + t, n_total), q | keep_all, s_acc, s_rec, s_part, C, splats, flatten_ids, offsets, width, height,
-                        tile_w, tile_h, backgrounds, render_alpha, last_ids, v_render, v_alpha, vsplat);
+                        tile_w, tile_h, backgrounds, render_alpha, last_ids, v_render, v_alpha, vsplat, post);
     }
+}
+
+// depth = alpha > 0 ? depth : max depth (model.py:304-306; the max is detached), in place on the depth image the forward
+// kernel wrote, with the max folded from its per-wave partials by every workgroup (a few thousand L2-resident floats)
+__global__ void __launch_bounds__(256)
+depth_fixup_kernel(int n_pix, const float* __restrict__ alpha, float* __restrict__ depth,
+                   const float* __restrict__ part, int n_part) {
+    __shared__ float s[4];
+    float dm = -3.0e38f;
+    for (int b0 = threadIdx.x; b0 < n_part; b0 += 8 * 256) {          // eight partials in flight per trip
+        float e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = part[b0 + 256 * j < n_part ? b0 + 256 * j : 0];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dm = fmaxf(dm, b0 + 256 * j < n_part ? e[j] : -3.0e38f);
+    }
+    dm = wave_max(dm);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = dm;
+    __syncthreads();
+    const float dmax = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n_pix; i += (size_t)gridDim.x * 256)
+        if (!(alpha[i] > 0.f)) depth[i] = dmax;
 }
 
 // ---- costliest-first tile order for the backward launch ---------------------------------------------------------
@@ -983,8 +1065,8 @@ static int no_cull_flag(int launch_flags) { return (launch_flags & QED_CL_NO_CUL
 extern "C" int qed_composite_fwd(int32_t C, int32_t N, const float* splats, const int32_t* flatten_ids,
                                  const int32_t* offsets, int32_t width, int32_t height, int32_t tile_w,
                                  int32_t tile_h, int32_t channels, const float* backgrounds, float* render,
-                                 float* alpha, int32_t* last_ids, int32_t* tile_cost, int32_t launch_flags,
-                                 void* stream) {
+                                 float* alpha, int32_t* last_ids, int32_t* tile_cost, const qed_post_t* post,
+                                 int32_t launch_flags, void* stream) {
     QED_REQUIRE(C >= 1 && N >= 0 && width > 0 && height > 0, "bad extents");
     QED_REQUIRE(channels == 3 || channels == 4, "channels must be 3 (RGB) or 4 (RGB+D)");
     QED_REQUIRE(tile_w == (width + QED_TILE - 1) / QED_TILE && tile_h == (height + QED_TILE - 1) / QED_TILE,
@@ -993,18 +1075,31 @@ extern "C" int qed_composite_fwd(int32_t C, int32_t N, const float* splats, cons
     // flatten_ids may be NULL when the sorted list is empty (offsets are then all zero)
     QED_REQUIRE(N == 0 || splats, "null splat buffer");
     const long long grid = (long long)C * tile_w * tile_h;
-    QED_REQUIRE(grid < (1ll << 31), "too many tiles");
+    QED_REQUIRE(grid < (1ll << 29), "too many tiles");
+    FwdPost fp{nullptr, nullptr, nullptr, nullptr};
+    if (post != nullptr) {
+        QED_REQUIRE(post->background && post->rgb, "post: background and rgb required");
+        QED_REQUIRE(channels == 3 || (post->depth && post->tile_dmax), "post: depth image and tile_dmax required with a depth channel");
+        fp = FwdPost{post->background, post->rgb, post->depth, post->tile_dmax};
+    }
     hipStream_t st = (hipStream_t)stream;
     const long long n_big = big_tiles(grid, QED_K6_SMALL, QED_K6_WAVES, launch_flags);
     const unsigned blocks = (unsigned)(n_big + 4 * (grid - n_big));
     if (channels == 4)
         hipLaunchKernelGGL(composite_fwd_kernel<4>, dim3(blocks), dim3(64), 0, st, C, (const float4*)splats,
                            flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render, alpha, last_ids,
-                           tile_cost, (int)n_big | no_cull_flag(launch_flags));
+                           tile_cost, (int)n_big | no_cull_flag(launch_flags), fp);
     else
         hipLaunchKernelGGL(composite_fwd_kernel<3>, dim3(blocks), dim3(64), 0, st, C, (const float4*)splats,
                            flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render, alpha, last_ids,
-                           tile_cost, (int)n_big | no_cull_flag(launch_flags));
+                           tile_cost, (int)n_big | no_cull_flag(launch_flags), fp);
+    if (post != nullptr && channels == 4) {
+        const long long n_pix = (long long)C * width * height;
+        long long g = (n_pix + 255) / 256;
+        if (g > 1024) g = 1024;
+        hipLaunchKernelGGL(depth_fixup_kernel, dim3((unsigned)g), dim3(256), 0, st, (int)n_pix, (const float*)alpha, post->depth,
+                           (const float*)post->tile_dmax, (int)(4 * grid));
+    }
     return check_launch("qed_composite_fwd");
 }
 
@@ -1013,12 +1108,19 @@ extern "C" int qed_composite_bwd(int32_t C, int32_t N, const float* splats, cons
                                  int32_t tile_h, int32_t channels, const float* backgrounds,
                                  const float* render_alpha, const int32_t* last_ids, const float* v_render,
                                  const float* v_alpha, float* vsplat, const int32_t* tile_cost,
-                                 int32_t* order_ws, int32_t launch_flags, void* stream) {
+                                 int32_t* order_ws, const qed_post_grad_t* post, int32_t launch_flags, void* stream) {
     QED_REQUIRE(C >= 1 && N >= 0 && width > 0 && height > 0, "bad extents");
     QED_REQUIRE(channels == 3 || channels == 4, "channels must be 3 (RGB) or 4 (RGB+D)");
     QED_REQUIRE(tile_w == (width + QED_TILE - 1) / QED_TILE && tile_h == (height + QED_TILE - 1) / QED_TILE,
                 "tile grid does not match the image (tile size is 16)");
-    QED_REQUIRE(offsets && render_alpha && last_ids && v_render && v_alpha, "null buffers");
+    QED_REQUIRE(offsets && render_alpha && last_ids, "null buffers");
+    QED_REQUIRE(post != nullptr || (v_render && v_alpha), "v_render and v_alpha, or the post-processing gradients");
+    BwdPost bp{nullptr, nullptr, nullptr, nullptr};
+    if (post != nullptr) {
+        QED_REQUIRE(post->background && post->render, "post: background and the forward pass's render required");
+        QED_REQUIRE(v_render == nullptr && v_alpha == nullptr, "post gradients replace v_render / v_alpha");
+        bp = BwdPost{post->background, post->render, post->v_rgb, post->v_depth};
+    }
     QED_REQUIRE((tile_cost == nullptr) == (order_ws == nullptr), "tile_cost and order_ws go together");
     QED_REQUIRE(((uintptr_t)tile_cost & 15) == 0, "tile_cost must be 16-byte aligned");
     if (N == 0) return QED_OK;
@@ -1046,11 +1148,11 @@ extern "C" int qed_composite_bwd(int32_t C, int32_t N, const float* splats, cons
         hipLaunchKernelGGL(composite_bwd_kernel<4>, dim3(blocks), dim3(64), 0, st, C, (const float4*)splats,
                            flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render_alpha, last_ids,
                            v_render, v_alpha, vsplat, (int)n_big | no_cull_flag(launch_flags), tile_order,
-                           tile_order ? tile_order + grid : nullptr);
+                           tile_order ? tile_order + grid : nullptr, bp);
     else
         hipLaunchKernelGGL(composite_bwd_kernel<3>, dim3(blocks), dim3(64), 0, st, C, (const float4*)splats,
                            flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render_alpha, last_ids,
                            v_render, v_alpha, vsplat, (int)n_big | no_cull_flag(launch_flags), tile_order,
-                           tile_order ? tile_order + grid : nullptr);
+                           tile_order ? tile_order + grid : nullptr, bp);
     return check_launch("qed_composite_bwd");
 }

@@ -656,6 +656,7 @@ class QEDSplatterModel(nn.Module):
             colors, sh_rest = features_dc_crop, None
             flags |= L.F_SIGMOID_COLORS                                       # torch.sigmoid(colors) fused
 
+        background = self._get_background_color()
         render, alpha, info = rasterization(
             means=means_crop,
             quats=quats_crop,                       # normalised inside the projection kernel (model.py:269)
@@ -679,6 +680,7 @@ class QEDSplatterModel(nn.Module):
             _sh_rest=sh_rest,
             _sync=not (self.config.async_intersection_count and self.training),
             _c2w=cam_c2w,
+            _post_background=background,
         )
         attrs["info"] = info
         attrs["last_compact"] = False
@@ -687,13 +689,13 @@ class QEDSplatterModel(nn.Module):
         attrs["xys"] = info["means2d"]                                        # [1,N,2]
         attrs["radii"] = info["radii"][0]                                     # [N]
 
-        background = self._get_background_color()
-        # model.py:296-297 (composite + clamp) and :304-308 (depth fix-up) as one node with a fused backward
-        if render_mode == "RGB+D":
-            rgb, depth_im = _PostProcess.apply(render, alpha, background)
+        # model.py:296-297 (composite + clamp) and :304-308 (depth fix-up) ran inside the compositing kernel, and their
+        # backward runs inside the compositing backward (rasterization(_post_background=...)): no pass of its own over the
+        # image in either direction (_PostProcess below is the stand-alone form of the same statements)
+        rgb = info.pop("post_rgb")
+        depth_im = info.pop("post_depth")
+        if depth_im is not None:
             depth_im = depth_im.squeeze(0)
-        else:
-            rgb, depth_im = _PostProcess.apply(render, alpha, background), None
 
         if self.config.use_bilateral_grid and self.training:                  # model.py:300-302 (not built: raises)
             if getattr(camera, "metadata", None) is not None and "cam_idx" in camera.metadata:

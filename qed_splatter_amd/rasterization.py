@@ -367,7 +367,7 @@ def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, til
 class _Composite(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means2d, conics, rgb, opac, depths, splats, flatten_ids, offsets, backgrounds, width, height,
-                tile_w, tile_h, channels, absgrad, vsplat_holder=None):
+                tile_w, tile_h, channels, absgrad, vsplat_holder=None, post_background=None):
         lib = L.load()
         ctx.set_materialize_grads(False)
         ctx.vsplat_holder = vsplat_holder
@@ -381,26 +381,61 @@ class _Composite(torch.autograd.Function):
         tile_cost = None
         if any(ctx.needs_input_grad[:5]):
             tile_cost = torch.empty(C * tile_w * tile_h, 4, dtype=torch.int32, device=dev)
+        # get_outputs' post-processing (model.py:295-297, 304-306) inside the same launch: rgb, depth as extra outputs
+        post, post_rgb, post_depth, pbg = None, None, None, None
+        if post_background is not None:
+            pbg = _f32c(post_background, "background").reshape(3)
+            post_rgb = torch.empty(C, height, width, 3, dtype=torch.float32, device=dev)
+            post = L.Post()
+            post.background, post.rgb = pbg.data_ptr(), post_rgb.data_ptr()
+            if channels == 4:
+                post_depth = torch.empty(C, height, width, 1, dtype=torch.float32, device=dev)
+                dmax = torch.empty(C * tile_w * tile_h * 4, dtype=torch.float32, device=dev)
+                post.depth, post.tile_dmax = post_depth.data_ptr(), dmax.data_ptr()
         L.check(lib.qed_composite_fwd(C, N, L.ptr(splats), L.ptr(flatten_ids), L.ptr(offsets), width, height, tile_w,
                                       tile_h, channels, L.ptr(bg), L.ptr(render), L.ptr(alpha), L.ptr(last_ids),
-                                      L.ptr(tile_cost), L.composite_launch_flags(), _stream()), "qed_composite_fwd")
+                                      L.ptr(tile_cost), C_byref(post), L.composite_launch_flags(), _stream()),
+                "qed_composite_fwd")
         ctx.tile_cost = tile_cost
-        ctx.save_for_backward(splats, flatten_ids, offsets, alpha, last_ids, bg)
+        ctx.save_for_backward(splats, flatten_ids, offsets, alpha, last_ids, bg, render if post is not None else None, pbg)
         ctx.meta = (C, N, width, height, tile_w, tile_h, channels, absgrad)
         ctx.means2d_ref = means2d
         ctx.mark_non_differentiable(last_ids)
-        return render, alpha, last_ids
+        if post is None:
+            return render, alpha, last_ids
+        if post_depth is None:
+            return render, alpha, last_ids, post_rgb
+        return render, alpha, last_ids, post_rgb, post_depth
 
     @staticmethod
-    def backward(ctx, v_render, v_alpha, _v_last):
+    def backward(ctx, v_render, v_alpha, _v_last, v_rgb=None, v_depth=None):
         lib = L.load()
-        splats, flatten_ids, offsets, alpha, last_ids, bg = ctx.saved_tensors
+        splats, flatten_ids, offsets, alpha, last_ids, bg, render, pbg = ctx.saved_tensors
         C, N, width, height, tile_w, tile_h, channels, absgrad = ctx.meta
         dev = splats.device
-        v_render = _f32c(v_render, "v_render") if v_render is not None else torch.zeros(
-            C, height, width, channels, dtype=torch.float32, device=dev)
-        v_alpha = _f32c(v_alpha, "v_alpha") if v_alpha is not None else torch.zeros(
-            C, height, width, 1, dtype=torch.float32, device=dev)
+        post = None
+        if v_rgb is not None or v_depth is not None:
+            v_rgb = _f32c(v_rgb, "v_rgb") if v_rgb is not None else None
+            v_depth = _f32c(v_depth, "v_depth") if v_depth is not None else None
+            if v_render is None and v_alpha is None:
+                # the usual case on the reference-shaped route: only rgb / depth were used downstream -- their gradients go
+                # straight into the compositing backward, which derives v_render / v_alpha per pixel in its tile prologue
+                post = L.PostGrad()
+                post.background, post.render = pbg.data_ptr(), render.data_ptr()
+                post.v_rgb, post.v_depth = L.ptr(v_rgb), L.ptr(v_depth)
+            else:
+                # render / alpha were used as well: convert with the stand-alone pass and add
+                vr2, va2 = torch.empty_like(render), torch.empty_like(alpha)
+                L.check(lib.qed_post_process_bwd(C * height * width, channels, L.ptr(render), L.ptr(alpha), L.ptr(pbg),
+                                                 L.ptr(v_rgb), L.ptr(v_depth), L.ptr(vr2), L.ptr(va2), _stream()),
+                        "qed_post_process_bwd")
+                v_render = vr2 if v_render is None else v_render + vr2
+                v_alpha = va2 if v_alpha is None else v_alpha + va2
+        if post is None:
+            v_render = _f32c(v_render, "v_render") if v_render is not None else torch.zeros(
+                C, height, width, channels, dtype=torch.float32, device=dev)
+            v_alpha = _f32c(v_alpha, "v_alpha") if v_alpha is not None else torch.zeros(
+                C, height, width, 1, dtype=torch.float32, device=dev)
         R = L.VSPLAT_FLOATS
         # the fused loss launch may already have zeroed an accumulator for this backward pass (model.fused_loss hands it
         # over through the holder; taken once -- a second backward through a retained graph makes its own)
@@ -411,21 +446,28 @@ class _Composite(torch.autograd.Function):
         tile_cost = ctx.tile_cost
         order_ws = torch.empty(C * tile_w * tile_h + 1, dtype=torch.int32, device=dev) if tile_cost is not None else None
         L.check(lib.qed_composite_bwd(C, N, L.ptr(splats), L.ptr(flatten_ids), L.ptr(offsets), width, height, tile_w,
-                                      tile_h, channels, L.ptr(bg), L.ptr(alpha), L.ptr(last_ids), L.ptr(v_render),
-                                      L.ptr(v_alpha), L.ptr(vsplat), L.ptr(tile_cost), L.ptr(order_ws),
+                                      tile_h, channels, L.ptr(bg), L.ptr(alpha), L.ptr(last_ids),
+                                      L.ptr(v_render) if post is None else None, L.ptr(v_alpha) if post is None else None,
+                                      L.ptr(vsplat), L.ptr(tile_cost), L.ptr(order_ws), C_byref(post),
                                       L.composite_launch_flags(), _stream()),
                 "qed_composite_bwd")
         v3 = vsplat.view(C, N, R)
         v_means2d = v3[..., 0:2]
         v_conics = v3[..., 4:7]
         v_opac = v3[..., 7]
-        v_rgb = v3[..., 8:11]
+        v_rgb_g = v3[..., 8:11]
         v_depths = v3[..., 11] if channels == 4 else None
         _VSPLAT_REGISTRY[vsplat.untyped_storage().data_ptr()] = vsplat
         if absgrad:
             # gsplat convention (absgrad=True at model.py:284): the densifier reads means2d.absgrad
             ctx.means2d_ref.absgrad = v3[..., 2:4]
-        return (v_means2d, v_conics, v_rgb, v_opac, v_depths) + (None,) * 11
+        return (v_means2d, v_conics, v_rgb_g, v_opac, v_depths) + (None,) * 12
+
+
+def C_byref(struct):
+    """ctypes pointer to a structure argument (None -> NULL)."""
+    import ctypes
+    return None if struct is None else ctypes.cast(ctypes.pointer(struct), ctypes.c_void_p)
 
 
 # ==================================================================================================
@@ -438,13 +480,16 @@ def rasterization(
     absgrad: bool = False, rasterize_mode: str = "classic", radius_clip: float = 0.0, eps2d: float = 0.3,
     backgrounds: Optional[Tensor] = None, _flags: int = 0, _sh_rest: Optional[Tensor] = None,
     _sync: bool = True, _vsplat_holder: Optional[list] = None, _c2w: Optional[Tuple[Tensor, Tensor]] = None,
+    _post_background: Optional[Tensor] = None,
 ) -> Tuple[Tensor, Tensor, Dict]:
     """Same call surface as the reference's call (model.py:267-288).
 
     ``_flags`` / ``_sh_rest`` are the fused entry used by ``qed_splatter_amd.model``: with them
     ``scales`` / ``opacities`` may be raw log-scales / logits (QED_F_LOG_SCALES / QED_F_LOGIT_OPAC)
     and ``colors`` / ``_sh_rest`` may be features_dc / features_rest without the torch.cat of
-    model.py:241.
+    model.py:241.  ``_post_background`` [3]: the statements that follow the call in get_outputs (model.py:295-297,
+    304-306) run inside the compositing kernels; ``info["post_rgb"]`` [C,H,W,3] and ``info["post_depth"]`` [C,H,W,1]
+    (RGB+D) are their results, differentiable like ``render`` / ``alpha``.
     """
     if packed or sparse_grad:
         raise NotImplementedError("packed=True / sparse_grad=True are not used by the reference (model.py:278,283)")
@@ -500,9 +545,10 @@ def rasterization(
     isect_ids, flatten_ids, offsets, M = _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums,
                                                        tile_w, tile_h, sync=_sync, splats=splats if use_packed else None,
                                                        size=(int(width), int(height)))
-    render, alpha, last_ids = _Composite.apply(means2d, conics, rgb, opac, depths if channels == 4 else None, splats,
-                                               flatten_ids, offsets, backgrounds, int(width), int(height), tile_w,
-                                               tile_h, channels, bool(absgrad), _vsplat_holder)
+    outs = _Composite.apply(means2d, conics, rgb, opac, depths if channels == 4 else None, splats, flatten_ids, offsets,
+                            backgrounds, int(width), int(height), tile_w, tile_h, channels, bool(absgrad), _vsplat_holder,
+                            _post_background)
+    render, alpha, last_ids = outs[:3]
     info = {
         "camera_ids": None, "gaussian_ids": None,
         "radii": radii, "means2d": means2d, "depths": depths, "conics": conics, "opacities": opac,
@@ -512,4 +558,7 @@ def rasterization(
         "width": width, "height": height, "tile_size": tile_size, "n_cameras": C,
         "last_ids": last_ids, "colors": rgb, "n_isects": M,
     }
+    if _post_background is not None:
+        info["post_rgb"] = outs[3]
+        info["post_depth"] = outs[4] if channels == 4 else None
     return render, alpha, info

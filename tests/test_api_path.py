@@ -672,3 +672,65 @@ def test_optimizer_tick_riding_on_the_loss_launch(cuda):
     m.backward_fused(m.fused_loss(cam, batch, compact_sh_grad=True, optimizer=opt))
     with pytest.raises(RuntimeError, match="device_state=True"):
         opt.step(fused_sh=True)
+
+
+# ---- get_outputs' post-processing inside the compositing kernels (rasterization(_post_background=...)) ---------------------
+@pytest.mark.parametrize("mode", ["RGB+D", "RGB"])
+def test_post_processing_inside_the_compositing_kernels_equals_the_standalone_node(cuda, mode):
+    """model.py:295-297 / 304-306 folded into the compositing forward (rgb, depth written beside render; one fix-up pass
+    for the empty pixels' depth) and backward (v_render / v_alpha derived from v_rgb / v_depth in the tile prologue) against
+    the stand-alone node _PostProcess on the plain operator's outputs: images equal, gradients equal up to the order of the
+    atomics -- with saturated colours on both sides of the clamp, a coloured background and empty pixels."""
+    from qed_splatter_amd.model import _PostProcess, get_viewmat
+    from qed_splatter_amd.rasterization import rasterization
+    w, h, n = 176, 120, 2500
+    sc = scene(n, w, h, seed=12)
+    sc["features_dc"] = sc["features_dc"] * 3.0                       # many colours beyond [0, 1] before the clamp
+    sc["scales"] = sc["scales"] + 1.5                                 # (large, fairly opaque splats: most covered pixels saturate)
+    sc["opacities"] = sc["opacities"] + 2.0
+    sc["means"][:, 0] = sc["means"][:, 0].abs()                       # the left half of the image stays empty (alpha = 0)
+    bg = torch.tensor([0.9, 0.2, 0.6], device=cuda)
+    g = torch.Generator().manual_seed(8)
+    w_rgb = torch.randn(1, h, w, 3, generator=g).to(cuda)
+    w_d = torch.randn(1, h, w, 1, generator=g).to(cuda)
+    w_r = torch.randn(1, h, w, 4 if mode == "RGB+D" else 3, generator=g).to(cuda)
+    vm = get_viewmat(sc["camera_to_worlds"][:1].to(cuda))
+
+    def run(fused, also_render=False):
+        ps = {k: sc[k].to(cuda).requires_grad_(True) for k in PARAM_NAMES}
+        render, alpha, info = rasterization(
+            means=ps["means"], quats=torch.nn.functional.normalize(ps["quats"], dim=-1), scales=ps["scales"].exp(),
+            opacities=torch.sigmoid(ps["opacities"]).squeeze(-1),
+            colors=torch.cat([ps["features_dc"][:, None, :], ps["features_rest"]], dim=1), viewmats=vm,
+            Ks=sc["Ks"][:1].to(cuda), width=w, height=h, render_mode=mode, sh_degree=3, absgrad=True,
+            _post_background=bg if fused else None)
+        if fused:
+            rgb, depth = info["post_rgb"], info["post_depth"]
+        elif mode == "RGB+D":
+            rgb, depth = _PostProcess.apply(render, alpha, bg)
+        else:
+            rgb, depth = _PostProcess.apply(render, alpha, bg), None
+        loss = (rgb * w_rgb).sum()
+        if depth is not None:
+            loss = loss + (depth * w_d).sum()
+        if also_render:
+            loss = loss + (render * w_r).sum() + alpha.sum()
+        grads = torch.autograd.grad(loss, [ps[k] for k in PARAM_NAMES])
+        return rgb.detach(), None if depth is None else depth.detach(), alpha.detach(), grads
+
+    rgb0, d0, a0, g0 = run(False)
+    rgb1, d1, a1, g1 = run(True)
+    assert float((a0 == 0).float().mean()) > 0.2                       # empty pixels exist: they show the max depth
+    assert float(((rgb0 == 0) | (rgb0 == 1)).float().mean()) > 0.05    # ... and saturated colours the clamp mask
+    assert torch.equal(a1, a0) and torch.equal(rgb1, rgb0)
+    if mode == "RGB+D":
+        assert torch.equal(d1, d0) and float(d1[a1 == 0].min()) == float(d1.max())
+    else:
+        assert d1 is None
+    for k, x, y in zip(PARAM_NAMES, g1, g0):
+        assert_close(x, y, 2e-5, f"fused vs stand-alone post-processing: grad {k}")
+    # rgb / depth AND render / alpha used downstream: both gradient routes are added
+    _, _, _, g2 = run(False, also_render=True)
+    _, _, _, g3 = run(True, also_render=True)
+    for k, x, y in zip(PARAM_NAMES, g3, g2):
+        assert_close(x, y, 2e-5, f"mixed use: grad {k}")

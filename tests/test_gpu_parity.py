@@ -1193,7 +1193,7 @@ def test_backward_tile_order_is_costliest_first_and_changes_no_gradient(cuda, li
     cost = torch.full((T, 4), -7, dtype=torch.int32, device=cuda)
     st = _stream()
     L.check(lib.qed_composite_fwd(1, n, L.ptr(splats), L.ptr(fid), L.ptr(offs), w, h, tw, th, 4, None, L.ptr(render),
-                                  L.ptr(alpha), L.ptr(last), L.ptr(cost), 0, st), "fwd")
+                                  L.ptr(alpha), L.ptr(last), L.ptr(cost), None, 0, st), "fwd")
     c = cost.sum(dim=1).cpu()
     assert int(cost.min()) >= 0 and int(c.sum()) > 0                  # every tile's entry was written
     lens = (offs[1:] - offs[:-1]).cpu()
@@ -1201,7 +1201,7 @@ def test_backward_tile_order_is_costliest_first_and_changes_no_gradient(cuda, li
     # the same image with and without the cost output
     r2 = torch.empty_like(render)
     L.check(lib.qed_composite_fwd(1, n, L.ptr(splats), L.ptr(fid), L.ptr(offs), w, h, tw, th, 4, None, L.ptr(r2),
-                                  L.ptr(alpha), L.ptr(last), None, 0, st), "fwd")
+                                  L.ptr(alpha), L.ptr(last), None, None, 0, st), "fwd")
     assert torch.equal(r2, render)
     g = torch.Generator().manual_seed(4)
     v_r = torch.randn(1, h, w, 4, generator=g).to(cuda)
@@ -1212,7 +1212,7 @@ def test_backward_tile_order_is_costliest_first_and_changes_no_gradient(cuda, li
         vs = torch.zeros(n, L.VSPLAT_FLOATS, device=cuda)
         L.check(lib.qed_composite_bwd(1, n, L.ptr(splats), L.ptr(fid), L.ptr(offs), w, h, tw, th, 4, None, L.ptr(alpha),
                                       L.ptr(last), L.ptr(v_r), L.ptr(v_a), L.ptr(vs), L.ptr(cost) if with_order else None,
-                                      L.ptr(order_ws) if with_order else None, 0, st), "bwd")
+                                      L.ptr(order_ws) if with_order else None, None, 0, st), "bwd")
         outs.append(vs)
     torch.cuda.synchronize()
     order, n_split = order_ws[:T].cpu().long(), int(order_ws[T])
@@ -1227,4 +1227,4 @@ def test_backward_tile_order_is_costliest_first_and_changes_no_gradient(cuda, li
     assert scale > 0 and float((outs[0] - outs[1]).abs().max()) <= 2e-5 * scale
     with pytest.raises(L.QedSplatError):                               # the two buffers go together
         L.check(lib.qed_composite_bwd(1, n, L.ptr(splats), L.ptr(fid), L.ptr(offs), w, h, tw, th, 4, None, L.ptr(alpha),
-                                      L.ptr(last), L.ptr(v_r), L.ptr(v_a), L.ptr(outs[0]), L.ptr(cost), None, 0, st), "bwd")
+                                      L.ptr(last), L.ptr(v_r), L.ptr(v_a), L.ptr(outs[0]), L.ptr(cost), None, None, 0, st), "bwd")
