@@ -314,12 +314,13 @@ int qed_loss_grad_ssim(int32_t height, int32_t width, int32_t channels, const fl
 /* qed_ssim_bwd and qed_image_losses_bwd in ONE launch (get_loss_dict's backward): v_rgb[H,W,3] = g_main[0] * d main_loss /
  * d rgb (the L1 term joins the SSIM term inside the SSIM backward pass, which has the pixel's colours at hand) and
  * v_depth[H,W] (may be NULL) = g_depth[0] * d depth_loss / d depth.  sums: qed_image_losses_fwd's; maps: qed_ssim_fwd's;
- * ssim_scale = -ssim_lambda / (3 (H-10)(W-10)); g_depth may be NULL (no upstream gradient: zeros). */
+ * ssim_scale = -ssim_lambda / (3 (H-10)(W-10)); g_depth may be NULL (no upstream gradient: zeros).  zero_buf (may be
+ * NULL): as qed_loss_grad_ssim's -- the accumulator the compositing backward that follows adds into. */
 int qed_image_losses_ssim_bwd(int32_t height, int32_t width, const float* rgb, const float* depth,
                               const float* gt_rgb, const float* gt_depth, const float* mask, const float* maps,
                               const float* sums, float rgb_weight, float depth_lambda, float ssim_scale,
                               const float* g_main, const float* g_depth, float* v_rgb, float* v_depth,
-                              void* stream);
+                              float* zero_buf, int64_t zero_floats, void* stream);
 
 /* ---- the same arithmetic behind the reference's OWN call sequence --------------------------------
  * get_outputs() returns images and get_loss_dict() turns them into a dict of scalar losses that the

@@ -63,7 +63,7 @@ SIGNATURES = {
     "qed_image_losses_bwd": (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _I, _P, _P, _P]),
     "qed_loss_grad_ssim": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _P, _P, _P, _I, _F, _P, _L,
                                      _P, _P]),
-    "qed_image_losses_ssim_bwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _P, _P, _P, _P]),
+    "qed_image_losses_ssim_bwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _P, _P, _P, _P, _L, _P]),
     "qed_adam_step": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _D, _D, _F, _I, _P, _P]),
     "qed_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _D, _D, _F, _P, _P, _P]),
     "qed_adam_step_sh": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _P, _D, _D, _F, _I, _P, _I, _F, _F, _I, _I, _I, _P, _I,

@@ -931,19 +931,37 @@ depth_fixup_kernel(int n_pix, const float* __restrict__ alpha, float* __restrict
                    const float* __restrict__ part, int n_part) {
     __shared__ float s[4];
     float dm = -3.0e38f;
-    for (int b0 = threadIdx.x; b0 < n_part; b0 += 8 * 256) {          // eight partials in flight per trip
-        float e[8];
+    // n_part is a multiple of 4 (four slots per tile) and the array 16-byte aligned: float4, eight vectors in flight per
+    // trip.  Every workgroup folds all partials itself, so the grid is kept to one workgroup per CU (1 024 workgroups
+    // re-read 130 KB each at 1080p: 12 us for this kernel instead of 4).
+    const float4* p4 = reinterpret_cast<const float4*>(part);
+    const int n4 = n_part >> 2;
+    for (int b0 = threadIdx.x; b0 < n4; b0 += 8 * 256) {
+        float4 e[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = part[b0 + 256 * j < n_part ? b0 + 256 * j : 0];
+        for (int j = 0; j < 8; ++j) e[j] = p4[b0 + 256 * j < n4 ? b0 + 256 * j : 0];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dm = fmaxf(dm, b0 + 256 * j < n_part ? e[j] : -3.0e38f);
+        for (int j = 0; j < 8; ++j)
+            if (b0 + 256 * j < n4) dm = fmaxf(fmaxf(dm, fmaxf(e[j].x, e[j].y)), fmaxf(e[j].z, e[j].w));
     }
     dm = wave_max(dm);
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = dm;
     __syncthreads();
     const float dmax = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n_pix; i += (size_t)gridDim.x * 256)
+    // four pixels per thread and trip: the alphas as one 16-byte load (n_pix need not be a multiple of 4: scalar tail)
+    const size_t n_vec = (size_t)n_pix >> 2;
+    const float4* a4 = reinterpret_cast<const float4*>(alpha);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (size_t)gridDim.x * 256) {
+        const float4 a = a4[i];
+        if (!(a.x > 0.f)) depth[4 * i] = dmax;
+        if (!(a.y > 0.f)) depth[4 * i + 1] = dmax;
+        if (!(a.z > 0.f)) depth[4 * i + 2] = dmax;
+        if (!(a.w > 0.f)) depth[4 * i + 3] = dmax;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n_pix & 3)) {
+        const size_t i = (n_vec << 2) + threadIdx.x;
         if (!(alpha[i] > 0.f)) depth[i] = dmax;
+    }
 }
 
 // ---- costliest-first tile order for the backward launch ---------------------------------------------------------
@@ -1095,8 +1113,9 @@ extern "C" int qed_composite_fwd(int32_t C, int32_t N, const float* splats, cons
                            tile_cost, (int)n_big | no_cull_flag(launch_flags), fp);
     if (post != nullptr && channels == 4) {
         const long long n_pix = (long long)C * width * height;
-        long long g = (n_pix + 255) / 256;
-        if (g > 1024) g = 1024;
+        long long g = (n_pix / 4 + 255) / 256;
+        if (g > 256) g = 256;
+        if (g < 1) g = 1;
         hipLaunchKernelGGL(depth_fixup_kernel, dim3((unsigned)g), dim3(256), 0, st, (int)n_pix, (const float*)alpha, post->depth,
                            (const float*)post->tile_dmax, (int)(4 * grid));
     }

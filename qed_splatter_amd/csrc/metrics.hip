@@ -258,28 +258,30 @@ step_metrics_kernel(int n_pix, const float* __restrict__ pred_rgb, const float* 
     }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 step_metrics_finalize_kernel(int n_pix, int n_blocks, int has_depth, const double* __restrict__ partials,
                              const float* __restrict__ ssim_sum, int ssim_n, float ssim_norm, int has_scales,
                              float rgb_weight, float depth_lambda, float ssim_lambda, float* __restrict__ loss_sums,
                              float* __restrict__ losses, float* __restrict__ out) {
-    __shared__ double s_w[kStepCols + 1][4];
+    // 1 024 threads, one row of partials each: all fifteen columns (and this thread's share of the SSIM partials) are
+    // requested before anything is added -- one memory round trip for the whole fold (as a 256-thread loop: 10.7 us)
+    __shared__ double s_w[kStepCols + 1][16];
     __shared__ double s[kStepCols + 1];
     double v[kStepCols + 1];
+    const int b = threadIdx.x;
+    const bool live = b < n_blocks;
 #pragma unroll
-    for (int c = 0; c <= kStepCols; ++c) v[c] = 0.0;
-    for (int b = threadIdx.x; b < n_blocks; b += 256) {       // (all columns of a row of partials requested together)
+    for (int c = 0; c < kStepCols; ++c) v[c] = partials[(size_t)c * kStepMaxGrid + (live ? b : 0)];
+    float e[4];
 #pragma unroll
-        for (int c = 0; c < kStepCols; ++c) v[c] += partials[(size_t)c * kStepMaxGrid + b];
-    }
+    for (int j = 0; j < 4; ++j) e[j] = ssim_sum != nullptr ? ssim_sum[b + 1024 * j < ssim_n ? b + 1024 * j : 0] : 0.f;
+#pragma unroll
+    for (int c = 0; c < kStepCols; ++c) v[c] = live ? v[c] : 0.0;
+    v[kStepCols] = 0.0;
     if (ssim_sum != nullptr) {
-        for (int b0 = threadIdx.x; b0 < ssim_n; b0 += 8 * 256) {
-            float e[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) e[j] = ssim_sum[b0 + 256 * j < ssim_n ? b0 + 256 * j : 0];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[kStepCols] += b0 + 256 * j < ssim_n ? (double)e[j] : 0.0;
-        }
+        for (int j = 0; j < 4; ++j) v[kStepCols] += b + 1024 * j < ssim_n ? (double)e[j] : 0.0;
+        for (int b0 = b + 4096; b0 < ssim_n; b0 += 1024) v[kStepCols] += (double)ssim_sum[b0];
     }
 #pragma unroll
     for (int c = 0; c <= kStepCols; ++c) {
@@ -288,7 +290,12 @@ step_metrics_finalize_kernel(int n_pix, int n_blocks, int has_depth, const doubl
         if ((threadIdx.x & 63) == 0) s_w[c][threadIdx.x >> 6] = v[c];
     }
     __syncthreads();
-    if (threadIdx.x <= kStepCols) s[threadIdx.x] = s_w[threadIdx.x][0] + s_w[threadIdx.x][1] + s_w[threadIdx.x][2] + s_w[threadIdx.x][3];
+    if (threadIdx.x <= kStepCols) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += s_w[threadIdx.x][w];
+        s[threadIdx.x] = t;
+    }
     __syncthreads();
     if (threadIdx.x != 0) return;
     const float nanv = __builtin_nanf("");
@@ -370,7 +377,7 @@ extern "C" int qed_step_metrics(int32_t n_pix, const float* pred_rgb, const floa
     if (g > 1024) g = 1024;
     hipLaunchKernelGGL(step_metrics_kernel, dim3((unsigned)g), dim3(256), 0, st, n_pix, pred_rgb, gt_rgb, pred_depth,
                        gt_depth, tolerance, loss_mask, losses != nullptr ? 1 : 0, scales, n_scales, scale_stride, workspace);
-    hipLaunchKernelGGL(step_metrics_finalize_kernel, dim3(1), dim3(256), 0, st, n_pix, (int)g, pred_depth != nullptr ? 1 : 0,
+    hipLaunchKernelGGL(step_metrics_finalize_kernel, dim3(1), dim3(1024), 0, st, n_pix, (int)g, pred_depth != nullptr ? 1 : 0,
                        (const double*)workspace, ssim_sum, ssim_n, ssim_norm, scales != nullptr ? 1 : 0, rgb_weight,
                        depth_lambda, ssim_lambda, loss_sums, losses, out);
     return check_launch("qed_step_metrics");

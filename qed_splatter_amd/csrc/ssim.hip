@@ -283,7 +283,7 @@ struct LossFuse {
     float* v_render;        // FUSE 3/4 outputs
     float* v_alpha;
     float* v_depth;         // FUSE 1 output (may be NULL)
-    float4* zero_buf;       // FUSE 3/4: a buffer this launch also zeroes (the compositing backward's per-Gaussian
+    float4* zero_buf;       // FUSE != 0: a buffer this launch also zeroes (the compositing backward's per-Gaussian
     long long zero_vec;     //   accumulator: saves the fill launch in front of it), as 16-byte vectors; may be NULL
 };
 
@@ -371,7 +371,7 @@ ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
             w_d = nvalid > 0.f ? (lf.g_depth != nullptr ? lf.g_depth[0] : 0.f) * lf.depth_lambda / nvalid : 0.f;
         }
     }
-    if constexpr (FUSE >= 3) {
+    if constexpr (FUSE != 0) {
         // this workgroup's slice of the buffer to zero: stores only, issued beside the loads of the first pass
         if (lf.zero_buf != nullptr) {
             const long long per = (lf.zero_vec + gridDim.x - 1) / gridDim.x;
@@ -620,14 +620,17 @@ extern "C" int qed_image_losses_ssim_bwd(int32_t height, int32_t width, const fl
                                          const float* gt_rgb, const float* gt_depth, const float* mask, const float* maps,
                                          const float* sums, float rgb_weight, float depth_lambda, float ssim_scale,
                                          const float* g_main, const float* g_depth, float* v_rgb, float* v_depth,
-                                         void* stream) {
+                                         float* zero_buf, int64_t zero_floats, void* stream) {
     QED_REQUIRE(height > kHalo && width > kHalo, "image smaller than the 11 x 11 SSIM window");
     QED_REQUIRE(rgb && gt_rgb && maps && sums && g_main && v_rgb, "null buffers");
     QED_REQUIRE(v_depth == nullptr || (depth && gt_depth), "depth images required for a depth gradient");
+    QED_REQUIRE(zero_buf == nullptr || (zero_floats >= 0 && zero_floats % 4 == 0 && ((uintptr_t)zero_buf & 15) == 0),
+                "zero_buf must be 16-byte aligned and a multiple of 4 floats long");
     hipStream_t st = (hipStream_t)stream;
     const int n_pix = height * width;
     const LossFuse lf{depth, gt_depth, const_cast<float*>(sums), 0, rgb_weight / (3.f * (float)n_pix), depth_lambda, g_main,
-                      g_depth, nullptr, nullptr, v_depth, nullptr, 0};
+                      g_depth, nullptr, nullptr, v_depth, reinterpret_cast<float4*>(zero_buf),
+                      zero_buf ? (long long)(zero_floats / 4) : 0};
     const dim3 grid(((width + TileB::TW - 1) / TileB::TW) * ((height + TileB::TH - 1) / TileB::TH));
     if (mask)
         hipLaunchKernelGGL((ssim_bwd_kernel<false, true, TileB, 1>), grid, dim3(256), 0, st, height, width, 3, rgb,

@@ -254,9 +254,11 @@ class _ImageLosses(torch.autograd.Function):
     multiplies each term's gradient by its upstream gradient, read from device memory."""
 
     @staticmethod
-    def forward(ctx, rgb, depth, gt_rgb, gt_depth, mask, ssim_lambda, depth_lambda, ssim_shared=None, loss_shared=None):
+    def forward(ctx, rgb, depth, gt_rgb, gt_depth, mask, ssim_lambda, depth_lambda, ssim_shared=None, loss_shared=None,
+                vsplat=None):
         lib = L.load()
         ctx.set_materialize_grads(False)
+        ctx.vsplat = vsplat       # (holder, rows): the compositing backward's accumulator, zeroed by this node's backward launch
         if not rgb.is_cuda:
             raise L.QedSplatError("get_loss_dict needs GPU tensors: there is no CPU path in the product")
         H, W, _ = rgb.shape
@@ -315,15 +317,23 @@ class _ImageLosses(torch.autograd.Function):
         if v_rgb is not None and ssim_lambda > 0.0:
             # ONE launch: the L1 term joins the SSIM term inside the SSIM backward pass, the depth term rides along
             n_out = 3.0 * (H - 10) * (W - 10)
+            zero = None
+            if ctx.vsplat is not None:
+                holder, rows = ctx.vsplat
+                zero = torch.empty(rows, L.VSPLAT_FLOATS, dtype=torch.float32, device=rgb.device)
             L.check(lib.qed_image_losses_ssim_bwd(H, W, L.ptr(rgb), L.ptr(depth), L.ptr(gt_rgb), L.ptr(gt_depth),
                                                   L.ptr(mask), L.ptr(maps), L.ptr(sums), 1.0 - ssim_lambda, depth_lambda,
                                                   -ssim_lambda / n_out, L.ptr(g_main), L.ptr(g_depth), L.ptr(v_rgb),
-                                                  L.ptr(v_depth), st), "qed_image_losses_ssim_bwd")
+                                                  L.ptr(v_depth), L.ptr(zero), zero.numel() if zero is not None else 0, st),
+                    "qed_image_losses_ssim_bwd")
+            if zero is not None:
+                del holder[:]
+                holder.append(zero)
         else:
             L.check(lib.qed_image_losses_bwd(H * W, L.ptr(rgb), L.ptr(depth), L.ptr(gt_rgb), L.ptr(gt_depth), L.ptr(mask),
                                              L.ptr(sums), 1.0 - ssim_lambda, depth_lambda, L.ptr(g_main), L.ptr(g_depth), 0,
                                              L.ptr(v_rgb), L.ptr(v_depth), st), "qed_image_losses_bwd")
-        return v_rgb, v_depth, None, None, None, None, None, None, None
+        return v_rgb, v_depth, None, None, None, None, None, None, None, None
 
 
 class _FusedImageLoss(torch.autograd.Function):
@@ -657,6 +667,7 @@ class QEDSplatterModel(nn.Module):
             flags |= L.F_SIGMOID_COLORS                                       # torch.sigmoid(colors) fused
 
         background = self._get_background_color()
+        holder: list = []         # (get_loss_dict's backward launch leaves the compositing backward's zeroed accumulator here)
         render, alpha, info = rasterization(
             means=means_crop,
             quats=quats_crop,                       # normalised inside the projection kernel (model.py:269)
@@ -681,7 +692,9 @@ class QEDSplatterModel(nn.Module):
             _sync=not (self.config.async_intersection_count and self.training),
             _c2w=cam_c2w,
             _post_background=background,
+            _vsplat_holder=holder,
         )
+        attrs["_vsplat_pair"] = (holder, info["radii"].numel())
         attrs["info"] = info
         attrs["last_compact"] = False
         if self.training and info["means2d"].requires_grad:                   # model.py:289-290
@@ -707,8 +720,10 @@ class QEDSplatterModel(nn.Module):
 
         if background.shape[0] == 3 and not self.training:                    # model.py:313-314
             background = background.expand(H, W, 3)
+        rgb = rgb.squeeze(0)
+        attrs["_last_out_rgb"] = rgb
         return {
-            "rgb": rgb.squeeze(0),
+            "rgb": rgb,
             "depth": depth_im,
             "accumulation": alpha.squeeze(0),
             "background": background,
@@ -771,8 +786,12 @@ class QEDSplatterModel(nn.Module):
             if shared["depth_key"] == (dc.data_ptr(), dc._version, depth_batch.data_ptr(), depth_batch._version) \
                     and shared["lambdas"] == (float(cfg.ssim_lambda), float(cfg.depth_lambda)):
                 loss_shared = shared["loss"]
+        # the accumulator of the compositing backward behind THESE outputs is zeroed by this loss's backward launch
+        pair = self.__dict__.get("_vsplat_pair")
+        if pair is not None and (self.__dict__.get("_last_out_rgb") is not pred_img or not torch.is_grad_enabled()):
+            pair = None
         main, depth = _ImageLosses.apply(pred_img, depth_out, gt_img, depth_batch, mask, float(cfg.ssim_lambda),
-                                         float(cfg.depth_lambda), shared["maps_sum"] if shared else None, loss_shared)
+                                         float(cfg.depth_lambda), shared["maps_sum"] if shared else None, loss_shared, pair)
         return {"main_loss": main, "scale_reg": self._scale_reg(), "depth_loss": depth}
 
     # ---- get_metrics_dict (model.py:120-197) ----

@@ -624,10 +624,12 @@ def test_fused_image_losses_backward_equals_the_two_passes(cuda, lib, masked, wi
     L.check(lib.qed_image_losses_bwd(H * W, L.ptr(rgb), L.ptr(depth), L.ptr(gt), L.ptr(gd), L.ptr(mask), L.ptr(sums),
                                      1.0 - lam, dl, L.ptr(g_main), L.ptr(g_depth), 1, L.ptr(a_rgb), L.ptr(a_d), st), "bwd")
     b_rgb, b_d = torch.full_like(rgb, 5.0), torch.full_like(depth, 5.0)
+    zbuf = torch.full((1000, 16), 3.0, device=cuda)
     L.check(lib.qed_image_losses_ssim_bwd(H, W, L.ptr(rgb), L.ptr(depth), L.ptr(gt), L.ptr(gd), L.ptr(mask), L.ptr(maps),
                                           L.ptr(sums), 1.0 - lam, dl, -lam / n_out, L.ptr(g_main), L.ptr(g_depth),
-                                          L.ptr(b_rgb), L.ptr(b_d) if with_depth else None, st), "fused")
+                                          L.ptr(b_rgb), L.ptr(b_d) if with_depth else None, L.ptr(zbuf), zbuf.numel(), st), "fused")
     torch.cuda.synchronize()
+    assert float(zbuf.abs().max()) == 0.0                              # the launch also zeroes the buffer it is handed
     assert float((b_rgb - a_rgb).abs().max()) <= 1e-9 + 2e-7 * float(a_rgb.abs().max())
     if with_depth:
         assert torch.equal(b_d, a_d) and float(a_d.abs().max()) > 0.0
