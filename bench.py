@@ -101,9 +101,28 @@ def cpu_baseline(args):
         iters += 1
         dt = time.perf_counter() - t0
     sample_it_s = iters / dt
+    # BASELINE.json configs[0] -- 10 k Gaussians, one camera @ 256 x 256, the plumbing case -- timed IN FULL ("config
+    # A timed in full (fwd+bwd, 10 iterations)"): the only configuration the CPU runs at its real size
+    na, wa, ha = 10_000, 256, 256
+    sa = O.synthetic_scene(na, wa, ha, seed=1234)
+
+    def one_a():
+        ps = {k: sa[k].clone().requires_grad_(True) for k in names}
+        out = O.splatfacto_outputs(ps["means"], ps["scales"], ps["quats"], ps["opacities"], ps["features_dc"],
+                                   ps["features_rest"], sa["camera_to_worlds"], sa["Ks"], wa, ha, sa["background"])
+        (O.main_loss(out["rgb"], sa["gt_rgb"], 0.2) + O.depth_l1_loss(out["depth"], sa["gt_depth"])).backward()
+        return out["info"]["flatten_ids"].numel()
+
+    ma = one_a()                                    # (untimed: first-call allocations)
+    ta = time.perf_counter()
+    for _ in range(10):
+        one_a()
+    dta = time.perf_counter() - ta
+    config_a = {"workload": f"{na} Gaussians, 1 cam @ {wa}x{ha} (BASELINE configs[0]), fp32, fwd+loss+bwd, full size",
+                "iters": 10, "seconds": round(dta, 3), "iters_per_s": 10 / dta, "intersections": ma}
     return {
         "value": sample_it_s / (div * div), "unit": "train iters/s (full-workload equivalent)",
-        "cores": cores, "kind": "port",
+        "cores": cores, "kind": "port", "config_a": config_a,
         "sample": f"{n} Gaussians @ {w}x{h} (config / {div * div}, same density), fp32, fwd+loss+bwd, "
                   f"{iters} iters in {dt:.1f}s = {sample_it_s:.3f} sample-iters/s, M={m}; value = that / {div * div}",
     }
@@ -602,6 +621,29 @@ def main():
                 f"{api_sep:.3f} ms/step (QedAdam, separate Parameters)")
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
+            # the same full-size configs[0] step on the GPU (fused route, eager dispatch), beside the CPU figure
+            from qed_splatter_amd.scene import synthetic_scene
+            sa = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synthetic_scene(10_000, 256, 256, seed=1234).items()}
+            ma = QEDSplatterModel(QEDSplatterModelConfig.synthetic(sh_degree=3, sh_degree_interval=1),
+                                  **{k: sa[k] for k in ("means", "scales", "quats", "opacities", "features_dc", "features_rest")})
+            ma.step = 30000
+            Ka = sa["Ks"][0].cpu()
+            cam_a = PinholeCameras(sa["camera_to_worlds"], float(Ka[0, 0]), float(Ka[1, 1]), float(Ka[0, 2]), float(Ka[1, 2]), 256, 256)
+            batch_a = {"image": sa["gt_rgb"].contiguous(), "depth_image": sa["gt_depth"].contiguous()}
+
+            def step_a():
+                for p in ma.parameters():
+                    p.grad = None
+                ma.backward_fused(ma.fused_loss(cam_a, batch_a, sync=False))
+
+            for _ in range(10):
+                step_a()
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            for _ in range(100):
+                step_a()
+            torch.cuda.synchronize()
+            out["cpu_baseline"]["config_a"]["gpu_iters_per_s_same_workload"] = 100 / (time.perf_counter() - ta)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

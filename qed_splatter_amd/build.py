@@ -1,4 +1,4 @@
-"""In-tree build of libqed_splat.so (hipcc, gfx950 only) and of the oracle's C helpers.
+"""In-tree build of libqed_splat.so (hipcc, gfx950 only).  (The oracle is pure Python / PyTorch: nothing of it is compiled.)
 
 `python -m qed_splatter_amd.build` or `build_lib()`; called by `__graft_entry__.build()`.
 hipcc cross-compiles without a GPU.  The .so stays in-tree (git-ignored) so it travels to the GPU

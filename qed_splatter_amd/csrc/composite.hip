@@ -11,8 +11,9 @@
 //   * The tile's run of the depth-sorted list is streamed in batches of 64 through a two-deep
 //     software pipeline: while batch b is composited, the 48-byte records (three 16-byte loads per
 //     lane) of b+1 and the ids of b+2 are in flight, every prefetch an unconditional load from a
-//     clamped index.  Records never go through LDS: the current Gaussian's ten scalars are
-//     broadcast with v_readlane into SGPRs and enter the VALU as scalar operands.
+//     clamped index.  After culling each lane parks its (pre-scaled) record in LDS and the loop fetches
+//     the current Gaussian with broadcast reads (every lane the same address): a v_readlane costs 11-12
+//     issue cycles of the vector pipe, ten of them more than the forward pass's arithmetic per Gaussian.
 //   * Exact-conservative cull by ballot, per 8x8 quadrant: each lane bounds the minimum of its
 //     Gaussian's quadratic form sigma over the quadrant's pixel-centre rectangle (convex: 0 if the
 //     mean is inside, else attained on an edge).  alpha >= 1/255 needs sigma <= ln(255 o), so a
@@ -24,10 +25,12 @@
 //     "accepted", "valid") is a 64-bit scalar mask fed straight to v_cndmask.  The conic is
 //     pre-scaled by -log2(e) at staging so the exponent is a bare v_exp_f32 of a 5-instruction
 //     polynomial.
-//   * Backward: the per-pixel gradients of one Gaussian are summed over the lane's four pixels,
-//     reduced over the 64 lanes with v_permlane32_swap / v_permlane16_swap (the number of live
-//     values halves per level) + one DPP row reduction, parked in LDS and flushed with ONE
-//     64-byte-row atomic request per (tile, Gaussian) that actually contributed.
+//   * Backward: the per-pixel gradients of one Gaussian are summed over the lane's four pixels; ONE
+//     halving level runs in the wave (v_permlane16_swap), the 32 partials per value of up to three
+//     Gaussians are parked in LDS and the flush -- one lane per (Gaussian, value) -- adds them in a
+//     fixed order and issues ONE 64-byte-row atomic request per (tile, Gaussian) that contributed.
+//     The launch hands its tiles out costliest first (tile_order_kernel), from the forward pass's own
+//     per-tile visit counts.
 #include "qed_common.h"
 
 namespace qed {
@@ -42,10 +45,8 @@ constexpr float kLog2e = 1.4426950408889634f;
 // Gaussian were 115 cycles -- more than the forward pass's arithmetic for that Gaussian.  Parking the batch's records
 // in LDS once (three 16-byte stores per lane) and fetching the current one with broadcast reads (every lane the same
 // address: two ds_read_b128 + one ds_read_b64) costs ~45 cycles of LDS time per Gaussian, which runs beside the
-// vector pipe instead of on it.  -DQED_READLANE_BCAST restores the v_readlane form (A/B builds).
-#ifndef QED_READLANE_BCAST
-#define QED_LDS_BCAST 1
-#endif
+// vector pipe instead of on it.  (The v_readlane form and the fully in-wave reduction it was measured against live on
+// in scripts/ubench/xlane_cycles.hip and DESIGN.md section 4, not in the product source.)
 constexpr int kRecFloats = 12;      // LDS record stride (floats): 10 used + the list id (backward) + 1 pad
 
 // Backward: how the 12 per-Gaussian gradient sums leave the wave.  Cross-lane instructions are the expensive ones
@@ -53,11 +54,7 @@ constexpr int kRecFloats = 12;      // LDS record stride (floats): 10 used + the
 // is 9 swaps + 9 adds + 12 DPP adds = ~150 cycles per (tile, Gaussian).  So only ONE halving level runs in the wave
 // (6 v_permlane16_swap + 6 adds: 32 partial sums per value); the partials of up to four Gaussians are parked in LDS
 // (stores are issued beside the vector pipe, not on it) and the flush -- one lane per (Gaussian, value) -- adds the 32
-// partials with plain adds before its atomic: ~87 cycles per Gaussian.  -DQED_K7_WAVE_REDUCE restores the in-wave
-// reduction (A/B builds).
-#if defined(QED_LDS_BCAST) && !defined(QED_K7_WAVE_REDUCE)
-#define QED_K7_LDS_REDUCE 1
-#endif
+// partials with plain adds before its atomic: ~87 cycles per Gaussian.
 #ifndef QED_PARK_SLOTS
 #define QED_PARK_SLOTS 3
 #endif
@@ -90,11 +87,6 @@ __device__ __forceinline__ int sel(u64 m, int a, int b) {
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(a), "s"(m));
     return d;
 }
-// broadcast lane `t` (wave-uniform) of v into an SGPR
-__device__ __forceinline__ float bcast(float v, int t) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), t));
-}
-
 // ---- exact-conservative culling of (Gaussian, 8x8 quadrant) pairs -----------------------------------------------
 // alpha >= 1/255  <=>  sigma(d) = (a dx^2 + c dy^2)/2 + b dx dy <= tau = ln(255 o).  sigma is convex, so over the
 // rectangle of a quadrant's pixel centres its minimum is 0 if the mean lies inside and otherwise sits on one of the
@@ -303,14 +295,12 @@ __device__ __forceinline__ void fwd_tile(int tile, int qf, float (*s_rec)[kRecFl
         const float gx = r0.x, gy = r0.y;
         const float gA = -0.5f * kLog2e * r0.z, gB = -kLog2e * r0.w, gC = -0.5f * kLog2e * r1.x;
         const float gop = r1.y, gr = r1.z, gg = r1.w, gb = r2.x, gd = r2.y;
-#ifdef QED_LDS_BCAST
         if (km) {                                       // park this lane's (pre-scaled) Gaussian for the broadcast reads
             *reinterpret_cast<float4*>(&s_rec[lane][0]) = make_float4(gx, gy, gA, gC);
             *reinterpret_cast<float4*>(&s_rec[lane][4]) = make_float4(gB, gop, gr, gg);
             *reinterpret_cast<float2*>(&s_rec[lane][8]) = make_float2(gb, gd);
         }
         __syncthreads();                                // single wave: orders the stores before the reads below
-#endif
         // issue the gather of the next batch (its ids arrived a batch ago) and the id load of the one after
         const size_t g_n = (size_t)rid_n;
         const float4 n0 = splats[3 * g_n], n1 = splats[3 * g_n + 1], n2 = splats[3 * g_n + 2];
@@ -340,17 +330,11 @@ __device__ __forceinline__ void fwd_tile(int tile, int qf, float (*s_rec)[kRecFl
             const int t = __builtin_ctzll(km);
             const u64 bit = 1ull << t;
             km &= ~bit;
-#ifdef QED_LDS_BCAST
             // broadcast Gaussian t: every lane reads the same LDS record
             const float4 q0 = *reinterpret_cast<const float4*>(&s_rec[t][0]);
             const float4 q1 = *reinterpret_cast<const float4*>(&s_rec[t][4]);
             const float2 q2 = *reinterpret_cast<const float2*>(&s_rec[t][8]);
             visit(t, bit, (f2){q0.x, q0.y}, (f2){q0.z, q0.w}, q1.x, q1.y, (f2){q1.z, q1.w}, (f2){q2.x, CH == 4 ? q2.y : 0.f});
-#else
-            // broadcast Gaussian t: ten v_readlane -> SGPRs
-            visit(t, bit, (f2){bcast(gx, t), bcast(gy, t)}, (f2){bcast(gA, t), bcast(gC, t)}, bcast(gB, t), bcast(gop, t),
-                  (f2){bcast(gr, t), bcast(gg, t)}, (f2){bcast(gb, t), CH == 4 ? bcast(gd, t) : 0.f});
-#endif
         }
         all_done = and_done() == ~0ull;                 // (a finished quadrant empties its mask, so km ran out by itself)
         r0 = n0; r1 = n1; r2 = n2;                      // rotate the pipeline (the wave waits HERE, not above)
@@ -469,32 +453,9 @@ composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
 // ================================================================================================
 // backward
 // ================================================================================================
-__device__ __forceinline__ void swap32(float& a, float& b) {
-    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
-}
 __device__ __forceinline__ void swap16(float& a, float& b) {
     auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
-}
-
-// Reduce 12 per-lane values over the 64 lanes.  On return w[j] (j = 0..2) holds, in EVERY lane of
-// DPP row r (lanes 16r .. 16r+15), the wave total of value index kRowValue[r] + 4 j, with
-// kRowValue = {0, 2, 1, 3}.
-__device__ __forceinline__ void wave_reduce12(const float* v, float* w) {
-    float u[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        float a = v[2 * i], b = v[2 * i + 1];
-        swap32(a, b);              // a = [a.lo | b.lo], b = [a.hi | b.hi]
-        u[i] = a + b;              // lanes 0-31: value 2i ; lanes 32-63: value 2i+1
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        float a = u[2 * j], b = u[2 * j + 1];
-        swap16(a, b);              // a = [a.r0, b.r0, a.r2, b.r2], b = [a.r1, b.r1, a.r3, b.r3]
-        w[j] = row16_sum(a + b);   // row0: 4j, row1: 4j+2, row2: 4j+1, row3: 4j+3
-    }
 }
 
 // per-Gaussian gradient accumulators of one lane (summed over its four pixels)
@@ -552,7 +513,7 @@ __device__ __forceinline__ void bwd_quadrant(f2 pq, f2 XY, f2 AC, float B, float
     g.s0 += vs;
 }
 
-// Flush of the parked Gaussians (QED_K7_LDS_REDUCE): one lane per (parked Gaussian, value) adds its 32 partials in a
+// Flush of the parked Gaussians: one lane per (parked Gaussian, value) adds its 32 partials in a
 // fixed order, scales, and the wave issues one 64-byte row per Gaussian in a single atomic request.
 __device__ __forceinline__ void flush_parked(int n_parked, int pt0, int pt1, int pt2, int pt3,
                                              const float* __restrict__ s_part, const float (*s_rec)[kRecFloats],
@@ -584,7 +545,7 @@ __device__ __forceinline__ void flush_parked(int n_parked, int pt0, int pt1, int
 // Values 4, 6 and 7 are accumulated un-scaled (sum v_sigma dx^2, sum v_sigma dy^2, sum v_sigma) and
 // scaled by 0.5, 0.5 and -1/opacity once per (tile, Gaussian) at flush time.
 template <int CH, int NQ>
-__device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_acc)[12], float (*s_rec)[kRecFloats],
+__device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_rec)[kRecFloats],
                                          float* __restrict__ s_part, int C,
                                          const float4* __restrict__ splats,
                                          const int* __restrict__ flatten_ids, const int* __restrict__ offsets, int width,
@@ -708,22 +669,18 @@ __device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_acc)[12], f
         const float gx = r0.x, gy = r0.y, gca = r0.z, gcb = r0.w, gcc = r1.x;
         const float gop = r1.y, gr = r1.z, gg = r1.w, gb = r2.x, gd = r2.y;
         const int gid = rid;
-#ifdef QED_LDS_BCAST
         if (km) {                                       // park this lane's Gaussian (+ its id, for the flush)
             *reinterpret_cast<float4*>(&s_rec[lane][0]) = make_float4(gx, gy, gca, gcb);
             *reinterpret_cast<float4*>(&s_rec[lane][4]) = make_float4(gcc, gop, gr, gg);
             *reinterpret_cast<float4*>(&s_rec[lane][8]) = make_float4(gb, gd, __int_as_float(gid), 0.f);
         }
         __syncthreads();
-#endif
         const float4 n0 = splats[3 * (size_t)rid_n], n1 = splats[3 * (size_t)rid_n + 1],
                      n2 = splats[3 * (size_t)rid_n + 2];
         const int rid_nn = id_at(batch_hi - 2 * kBatch - lane);
-#ifdef QED_K7_LDS_REDUCE
         int n_parked = 0, pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0;      // parked Gaussians (lane indices of this batch)
         // this lane's slot in a parked Gaussian's partials: [value = 2 i + (row & 1)][half = row >> 1][lane & 15]
         float* const park_lane = s_part + ((lane >> 4) & 1) * kParkStride + (lane >> 5) * 16 + (lane & 15);
-#ifdef QED_LDS_BCAST
         // The record of the NEXT surviving Gaussian is requested right after the current one's pixels are done, into
         // the very registers they were read from: the LDS latency (~130 cycles) then runs beside the reduction of the
         // current Gaussian instead of in front of the next one's arithmetic.
@@ -735,22 +692,14 @@ __device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_acc)[12], f
             q2 = *reinterpret_cast<const float2*>(&s_rec[tt][8]);
         };
         if (km) fetch(__builtin_ctzll(km));
-#endif
         while (km) {
             const int t = __builtin_ctzll(km);
             const u64 bit = 1ull << t;
             km &= ~bit;
-#ifdef QED_LDS_BCAST
             const f2 XY = {q0.x, q0.y};
             const float ca = q0.z, cb = q0.w, cc = q1.x, op = q1.y;
             const f2 col01 = {q1.z, q1.w};
             const f2 col23 = {q2.x, CH == 4 ? q2.y : 0.f};
-#else
-            const f2 XY = {bcast(gx, t), bcast(gy, t)};
-            const float ca = bcast(gca, t), cb = bcast(gcb, t), cc = bcast(gcc, t), op = bcast(gop, t);
-            const f2 col01 = {bcast(gr, t), bcast(gg, t)};
-            const f2 col23 = {bcast(gb, t), CH == 4 ? bcast(gd, t) : 0.f};
-#endif
             const f2 AC = {-0.5f * kLog2e * ca, -0.5f * kLog2e * cc};
             const float B = -kLog2e * cb;
             const f2 cab = {ca, cb}, cbc = {cb, cc};
@@ -765,9 +714,7 @@ __device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_acc)[12], f
                 QED_STAT(11, 1);
                 bwd_quadrant<CH>(pq[q], XY, AC, B, op, cab, cbc, col01, col23, idx, px[q], any_valid, g);
             }
-#ifdef QED_LDS_BCAST
             if (km) fetch(__builtin_ctzll(km));
-#endif
             if (any_valid == 0) continue;
             QED_STAT(12, 1);
             {
@@ -790,85 +737,6 @@ __device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_acc)[12], f
         }
         if (n_parked)                                   // before the next batch overwrites s_rec (ids, opacities)
             flush_parked(n_parked, pt0, pt1, pt2, pt3, s_part, s_rec, vsplat, lane);
-#else
-        u64 touched = 0;
-        while (km) {
-            const int t = __builtin_ctzll(km);
-            const u64 bit = 1ull << t;
-            km &= ~bit;
-#ifdef QED_LDS_BCAST
-            const float4 q0 = *reinterpret_cast<const float4*>(&s_rec[t][0]);
-            const float4 q1 = *reinterpret_cast<const float4*>(&s_rec[t][4]);
-            const float2 q2 = *reinterpret_cast<const float2*>(&s_rec[t][8]);
-            const f2 XY = {q0.x, q0.y};
-            const float ca = q0.z, cb = q0.w, cc = q1.x, op = q1.y;
-            const f2 col01 = {q1.z, q1.w};
-            const f2 col23 = {q2.x, CH == 4 ? q2.y : 0.f};
-#else
-            const f2 XY = {bcast(gx, t), bcast(gy, t)};
-            const float ca = bcast(gca, t), cb = bcast(gcb, t), cc = bcast(gcc, t), op = bcast(gop, t);
-            const f2 col01 = {bcast(gr, t), bcast(gg, t)};
-            const f2 col23 = {bcast(gb, t), CH == 4 ? bcast(gd, t) : 0.f};
-#endif
-            const f2 AC = {-0.5f * kLog2e * ca, -0.5f * kLog2e * cc};
-            const float B = -kLog2e * cb;
-            const f2 cab = {ca, cb}, cbc = {cb, cc};
-            const int idx = batch_hi - t;
-            GradAcc g;
-            g.vxy = g.c01 = g.rg = g.bd = (f2){0.f, 0.f};
-            g.ax = g.ay = g.c2 = g.s0 = 0.f;
-            u64 any_valid = 0;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                if (!(mq[q] & bit)) continue;           // wave-uniform: this quadrant cannot see Gaussian t
-                QED_STAT(11, 1);
-                bwd_quadrant<CH>(pq[q], XY, AC, B, op, cab, cbc, col01, col23, idx, px[q], any_valid, g);
-            }
-            if (any_valid == 0) continue;
-            QED_STAT(12, 1);
-            const float gv[12] = {g.vxy.x, g.vxy.y, g.ax, g.ay, g.c01.x, g.c01.y, g.c2, g.s0,
-                                  g.rg.x, g.rg.y, g.bd.x, g.bd.y};
-            float w[3];
-            wave_reduce12(gv, w);
-            // lanes 0,16,32,48 park the totals: row r holds value (r==0?0 : r==1?2 : r==2?1 : 3) + 4j
-            if ((lane & 15) == 0) {
-                const int r = lane >> 4;
-                const int vbase = ((r & 1) << 1) | (r >> 1);
-                s_acc[t][vbase] = w[0];
-                s_acc[t][vbase + 4] = w[1];
-                s_acc[t][vbase + 8] = w[2];
-            }
-            touched |= bit;
-        }
-        __syncthreads();                                // single wave: orders the LDS parking vs the flush
-        // flush: 16 lanes per Gaussian, 4 Gaussians per instruction -> one 64-byte row per request
-        while (touched) {
-            QED_STAT(13, 1);
-            int ts[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                ts[j] = touched ? __builtin_ctzll(touched) : -1;
-                touched &= touched - 1;                 // no-op when already zero
-            }
-            const int grp = lane >> 4, k = lane & 15;
-            const int t = grp == 0 ? ts[0] : grp == 1 ? ts[1] : grp == 2 ? ts[2] : ts[3];
-#ifdef QED_LDS_BCAST
-            const int id = __float_as_int(s_rec[max(t, 0)][10]);
-            const float opac = s_rec[max(t, 0)][5];
-#else
-            // all lanes take part in the shuffles (the source lane must be active)
-            const int id = __shfl(gid, max(t, 0), 64);
-            const float opac = __shfl(gop, max(t, 0), 64);
-#endif
-            if (t >= 0 && k < 12) {
-                float v = s_acc[t][k];
-                if (k == 4 || k == 6) v *= 0.5f;
-                if (k == 7) v = -v * __builtin_amdgcn_rcpf(opac);   // (an IEEE division is 11 instructions for the whole wave)
-                if (v != 0.f) atomicAdd(&vsplat[(size_t)id * QED_VSPLAT_FLOATS + k], v);
-            }
-        }
-        __syncthreads();
-#endif
         r0 = n0; r1 = n1; r2 = n2;                      // rotate the pipeline
         rid = rid_n; rid_n = rid_nn;
         present = batch_hi - kBatch - lane >= start;
@@ -884,13 +752,7 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
                      const int* __restrict__ last_ids, const float* __restrict__ v_render,
                      const float* __restrict__ v_alpha, float* __restrict__ vsplat, int n_big_flags,
                      const int* __restrict__ tile_order, const int* __restrict__ n_split_dev, BwdPost post) {
-#ifdef QED_K7_LDS_REDUCE
-    float (*s_acc)[12] = nullptr;
     __shared__ __attribute__((aligned(16))) float s_part[kParkSlots * kParkSlot];
-#else
-    __shared__ float s_acc[kBatch][12];
-    float* s_part = nullptr;
-#endif
     __shared__ __attribute__((aligned(16))) float s_rec[kBatch][kRecFloats];
     const int n_total = C * tile_w * tile_h;
     const int b = blockIdx.x;
@@ -903,23 +765,23 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
         // waves each, ahead of everything else.
         const int n_split = n_split_dev[0];
         if (b < 4 * n_split) {
-            bwd_tile<CH, 1>(tile_order[b >> 2], (b & 3) | keep_all, s_acc, s_rec, s_part, C, splats, flatten_ids, offsets,
+            bwd_tile<CH, 1>(tile_order[b >> 2], (b & 3) | keep_all, s_rec, s_part, C, splats, flatten_ids, offsets,
                             width, height, tile_w, tile_h, backgrounds, render_alpha, last_ids, v_render, v_alpha, vsplat, post);
         } else {
             const int i = b - 3 * n_split;
             if (i >= n_total) return;                    // (the grid is sized for the largest n_split the host allows)
-            bwd_tile<CH, 4>(tile_order[i], keep_all, s_acc, s_rec, s_part, C, splats, flatten_ids, offsets, width, height,
+            bwd_tile<CH, 4>(tile_order[i], keep_all, s_rec, s_part, C, splats, flatten_ids, offsets, width, height,
                             tile_w, tile_h, backgrounds, render_alpha, last_ids, v_render, v_alpha, vsplat, post);
         }
         return;
     }
     if (b < n_big) {
-        bwd_tile<CH, 4>(xcd_remap(b, n_total), keep_all, s_acc, s_rec, s_part, C, splats, flatten_ids, offsets, width, height, tile_w, tile_h,
+        bwd_tile<CH, 4>(xcd_remap(b, n_total), keep_all, s_rec, s_part, C, splats, flatten_ids, offsets, width, height, tile_w, tile_h,
                         backgrounds, render_alpha, last_ids, v_render, v_alpha, vsplat, post);
     } else {
         int t, q;
         small_wave(b - n_big, n_total - n_big, t, q);
-        bwd_tile<CH, 1>(xcd_remap(n_big + t, n_total), q | keep_all, s_acc, s_rec, s_part, C, splats, flatten_ids, offsets, width, height,
+        bwd_tile<CH, 1>(xcd_remap(n_big + t, n_total), q | keep_all, s_rec, s_part, C, splats, flatten_ids, offsets, width, height,
                         tile_w, tile_h, backgrounds, render_alpha, last_ids, v_render, v_alpha, vsplat, post);
     }
 }

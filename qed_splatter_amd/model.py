@@ -4,7 +4,7 @@ Mirrors /root/reference/qed_splatter/model.py:
   * ``get_viewmat``                    model.py:22-38
   * ``QEDSplatterModelConfig``         model.py:41-47 (fields depth_lambda, output_depth_during_training)
   * ``QEDSplatterModel.get_outputs``   model.py:199-321
-  * ``QEDSplatterModel.get_loss_dict`` model.py:73-118 (depth-L1 term; parent's L1 RGB term)
+  * ``QEDSplatterModel.get_loss_dict`` model.py:73-118 (depth-L1 term; the parent's main loss (1 - l) L1 + l (1 - SSIM))
 
 The reference class inherits Nerfstudio's ``SplatfactoModel`` (not installed here, SURVEY F10);
 this mirror is a plain ``nn.Module`` holding the same six parameter groups under the same names
@@ -14,10 +14,12 @@ interchange, and it accepts any camera object with the few attributes model.py:1
 that makes the real ``QEDSplatterModel`` call this package instead of gsplat.
 
 Two ways to run a training step:
-  * API-compatible: ``get_outputs`` -> ``get_loss_dict`` -> ``backward`` (eager torch post-ops with
-    autograd exactly as model.py:295-306 / 87-116; the rasterization itself is the HIP operator);
-  * fused: ``fused_step`` = rasterization + K8 fused loss/gradient kernel + backward, with the
-    exp / sigmoid / cat of model.py:241,269-271 folded into the projection kernel.
+  * the reference's own call sequence: ``get_outputs`` -> ``get_metrics_dict`` -> ``get_loss_dict`` -> sum ->
+    ``backward`` -> one optimiser per group (``QedAdam``).  The statements around the operator (model.py:295-306,
+    87-116 and the parent's main loss) run inside the compositing kernels and in two fused autograd nodes
+    (``rasterization(_post_background=...)``, ``_ImageLosses``);
+  * fused: ``fused_loss`` = rasterization + the K8 loss / gradient kernels, ``backward_fused`` and ``FlatAdam`` -- one
+    hipGraph-replayable step with the exp / sigmoid / cat of model.py:241,269-271 folded into the projection kernel.
 """
 from __future__ import annotations
 
@@ -645,6 +647,10 @@ class QEDSplatterModel(nn.Module):
         W, H = int(camera.width.item()), int(camera.height.item())
         attrs = self.__dict__            # (plain attributes: nn.Module.__setattr__ costs ~5 us apiece, a dozen per step)
         attrs["last_size"] = (H, W)
+        # what get_metrics_dict / get_loss_dict share about the batch lives for ONE step: a loader that refills its batch
+        # tensors in place without bumping their version counter must not be served last step's conversion
+        attrs["_gt_memo"] = None
+        attrs["_ssim_shared"] = None
         if camera_scale_fac != 1:
             camera.rescale_output_resolution(camera_scale_fac)
 
@@ -854,6 +860,7 @@ class QEDSplatterModel(nn.Module):
         same quantities as get_outputs + get_loss_dict."""
         assert camera.shape[0] == 1, "Only one camera at a time"
         cfg = self.config
+        self.__dict__["_gt_memo"] = None      # (conversions of the batch are shared within a step, never across steps)
         # the coarse-to-fine schedule of get_outputs (model.py:244-250): render at 1/d of the camera's resolution
         d = self._get_downscale_factor()
         if d > 1:

@@ -736,3 +736,47 @@ def test_post_processing_inside_the_compositing_kernels_equals_the_standalone_no
     _, _, _, g3 = run(True, also_render=True)
     for k, x, y in zip(PARAM_NAMES, g3, g2):
         assert_close(x, y, 2e-5, f"mixed use: grad {k}")
+
+
+def test_flat_adam_state_dict_round_trip(cuda, tmp_path):
+    """The fused route's optimiser checkpoints like any other (config.py:29 steps_per_save): state_dict -> torch.save ->
+    a fresh model + optimiser -> load_state_dict continues exactly where the first left off (moments, step counts, the
+    device-resident step state and rates a captured graph replays against, the scheduled rate)."""
+    from qed_splatter_amd.model import FlatAdam
+    sc = scene(1500, 96, 64, seed=6)
+
+    def step(m, cam, batch, opt, device_state):
+        for p in m.parameters():
+            p.grad = None
+        m.backward_fused(m.fused_loss(cam, batch, compact_sh_grad=True))
+        opt.step(device_state=device_state, fused_sh=True)
+
+    for device_state in (False, True):
+        m1, cam, batch = _model(sc, cuda)
+        o1 = FlatAdam(m1, means_schedule=(1.6e-6, 50))
+        for _ in range(3):
+            step(m1, cam, batch, o1, device_state)
+        path = tmp_path / f"ckpt{int(device_state)}.pt"
+        torch.save({"model": m1.state_dict(), "optim": o1.state_dict()}, path)
+        ck = torch.load(path)
+        m2, cam2, batch2 = _model(sc, cuda)
+        m2.load_state_dict(ck["model"])
+        assert m2.gauss_params["means"].data_ptr() == m2.flat_params.data_ptr()      # still views of the flat buffer
+        o2 = FlatAdam(m2)
+        o2.load_state_dict(ck["optim"])
+        assert o2.t == 3 and o2.means_schedule == (1.6e-6, 50)
+        assert torch.equal(o2.exp_avg, o1.exp_avg) and torch.equal(o2.dev_state, o1.dev_state)
+        # the same gradients into both: the next update is bit-identical
+        g = torch.randn_like(m1.flat_params)
+        for m, o in ((m1, o1), (m2, o2)):
+            off = 0
+            for name in m.group_names:
+                p = m.gauss_params[name]
+                p.grad = g[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+            m.last_compact = False
+            o.step(device_state=device_state)
+        assert torch.equal(m1.flat_params, m2.flat_params) and torch.equal(o1.exp_avg_sq, o2.exp_avg_sq)
+    with pytest.raises(ValueError, match="load the model"):
+        m3, _, _ = _model(scene(700, 96, 64, seed=6), cuda)
+        FlatAdam(m3).load_state_dict(ck["optim"])
