@@ -798,27 +798,34 @@ depth_fixup_kernel(int n_pix, const float* __restrict__ alpha, float* __restrict
     // re-read 130 KB each at 1080p: 12 us for this kernel instead of 4).
     const float4* p4 = reinterpret_cast<const float4*>(part);
     const int n4 = n_part >> 2;
-    for (int b0 = threadIdx.x; b0 < n4; b0 += 8 * 256) {
-        float4 e[8];
+    for (int b0 = threadIdx.x; b0 < n4; b0 += 16 * 256) {             // sixteen vectors in flight per trip
+        float4 e[16];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = p4[b0 + 256 * j < n4 ? b0 + 256 * j : 0];
+        for (int j = 0; j < 16; ++j) e[j] = p4[b0 + 256 * j < n4 ? b0 + 256 * j : 0];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < 16; ++j)
             if (b0 + 256 * j < n4) dm = fmaxf(fmaxf(dm, fmaxf(e[j].x, e[j].y)), fmaxf(e[j].z, e[j].w));
     }
     dm = wave_max(dm);
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = dm;
     __syncthreads();
     const float dmax = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
-    // four pixels per thread and trip: the alphas as one 16-byte load (n_pix need not be a multiple of 4: scalar tail)
-    const size_t n_vec = (size_t)n_pix >> 2;
+    // four pixels per 16-byte load, eight loads in flight per trip (n_pix need not be a multiple of 4: scalar tail)
+    const size_t n_vec = (size_t)n_pix >> 2, stride = (size_t)gridDim.x * 256;
     const float4* a4 = reinterpret_cast<const float4*>(alpha);
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (size_t)gridDim.x * 256) {
-        const float4 a = a4[i];
-        if (!(a.x > 0.f)) depth[4 * i] = dmax;
-        if (!(a.y > 0.f)) depth[4 * i + 1] = dmax;
-        if (!(a.z > 0.f)) depth[4 * i + 2] = dmax;
-        if (!(a.w > 0.f)) depth[4 * i + 3] = dmax;
+    for (size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x; i0 < n_vec; i0 += 8 * stride) {
+        float4 a[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = a4[i0 + j * stride < n_vec ? i0 + j * stride : i0];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const size_t i = i0 + j * stride;
+            if (i >= n_vec) break;
+            if (!(a[j].x > 0.f)) depth[4 * i] = dmax;
+            if (!(a[j].y > 0.f)) depth[4 * i + 1] = dmax;
+            if (!(a[j].z > 0.f)) depth[4 * i + 2] = dmax;
+            if (!(a[j].w > 0.f)) depth[4 * i + 3] = dmax;
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x < (n_pix & 3)) {
         const size_t i = (n_vec << 2) + threadIdx.x;

@@ -184,7 +184,6 @@ nanmean_exp_finalize_kernel(int n_blocks, const double* __restrict__ partials, f
 // terms of qed_image_losses_fwd, mask m); 13 sum exp(scale), 14 count of non-NaN.
 constexpr int kStepCols = 15;
 constexpr int kStepMaxGrid = QED_STEP_METRICS_WS_DOUBLES / 16;
-static_assert(kStepMaxGrid >= 1024, "one slot per workgroup");
 
 __global__ void __launch_bounds__(256)
 step_metrics_kernel(int n_pix, const float* __restrict__ pred_rgb, const float* __restrict__ gt_rgb,
@@ -254,34 +253,47 @@ step_metrics_kernel(int n_pix, const float* __restrict__ pred_rgb, const float* 
     __syncthreads();
     if (threadIdx.x < kStepCols) {
         const int i = threadIdx.x;
-        partials[(size_t)i * kStepMaxGrid + blockIdx.x] = s_tmp[4 * i] + s_tmp[4 * i + 1] + s_tmp[4 * i + 2] + s_tmp[4 * i + 3];
+        // (a workgroup's sum of <= 2 048 pixels' terms: exact enough as a float; the fold adds the 1 024 of them in double)
+        reinterpret_cast<float*>(partials)[(size_t)i * kStepMaxGrid + blockIdx.x] =
+            (float)(s_tmp[4 * i] + s_tmp[4 * i + 1] + s_tmp[4 * i + 2] + s_tmp[4 * i + 3]);
     }
 }
 
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(256)
 step_metrics_finalize_kernel(int n_pix, int n_blocks, int has_depth, const double* __restrict__ partials,
                              const float* __restrict__ ssim_sum, int ssim_n, float ssim_norm, int has_scales,
                              float rgb_weight, float depth_lambda, float ssim_lambda, float* __restrict__ loss_sums,
                              float* __restrict__ losses, float* __restrict__ out) {
-    // 1 024 threads, one row of partials each: all fifteen columns (and this thread's share of the SSIM partials) are
-    // requested before anything is added -- one memory round trip for the whole fold (as a 256-thread loop: 10.7 us)
-    __shared__ double s_w[kStepCols + 1][16];
+    // 256 threads x four rows of partials: all sixty values of a thread (and its share of the SSIM partials) are REQUESTED
+    // before anything is added -- one memory round trip for the whole fold.  (A loop of load / add rounds took 10.7 us;
+    // 1 024 threads with one row each 14 us: sixteen waves of double-precision shuffles.)
+    static_assert(kStepMaxGrid == 1024, "four rows per thread");
+    __shared__ double s_w[kStepCols + 1][4];
     __shared__ double s[kStepCols + 1];
+    const float* pf = reinterpret_cast<const float*>(partials);
+    float r[4][kStepCols];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int b = threadIdx.x + 256 * j;
+#pragma unroll
+        for (int c = 0; c < kStepCols; ++c) r[j][c] = pf[(size_t)c * kStepMaxGrid + (b < n_blocks ? b : 0)];
+    }
+    float e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        e[j] = ssim_sum != nullptr ? ssim_sum[(int)threadIdx.x + 256 * j < ssim_n ? threadIdx.x + 256 * j : 0] : 0.f;
     double v[kStepCols + 1];
-    const int b = threadIdx.x;
-    const bool live = b < n_blocks;
 #pragma unroll
-    for (int c = 0; c < kStepCols; ++c) v[c] = partials[(size_t)c * kStepMaxGrid + (live ? b : 0)];
-    float e[4];
+    for (int c = 0; c < kStepCols; ++c) {
+        v[c] = 0.0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) e[j] = ssim_sum != nullptr ? ssim_sum[b + 1024 * j < ssim_n ? b + 1024 * j : 0] : 0.f;
-#pragma unroll
-    for (int c = 0; c < kStepCols; ++c) v[c] = live ? v[c] : 0.0;
+        for (int j = 0; j < 4; ++j) v[c] += (int)threadIdx.x + 256 * j < n_blocks ? (double)r[j][c] : 0.0;
+    }
     v[kStepCols] = 0.0;
     if (ssim_sum != nullptr) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[kStepCols] += b + 1024 * j < ssim_n ? (double)e[j] : 0.0;
-        for (int b0 = b + 4096; b0 < ssim_n; b0 += 1024) v[kStepCols] += (double)ssim_sum[b0];
+        for (int j = 0; j < 8; ++j) v[kStepCols] += (int)threadIdx.x + 256 * j < ssim_n ? (double)e[j] : 0.0;
+        for (int b0 = threadIdx.x + 2048; b0 < ssim_n; b0 += 256) v[kStepCols] += (double)ssim_sum[b0];
     }
 #pragma unroll
     for (int c = 0; c <= kStepCols; ++c) {
@@ -290,12 +302,7 @@ step_metrics_finalize_kernel(int n_pix, int n_blocks, int has_depth, const doubl
         if ((threadIdx.x & 63) == 0) s_w[c][threadIdx.x >> 6] = v[c];
     }
     __syncthreads();
-    if (threadIdx.x <= kStepCols) {
-        double t = 0.0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) t += s_w[threadIdx.x][w];
-        s[threadIdx.x] = t;
-    }
+    if (threadIdx.x <= kStepCols) s[threadIdx.x] = s_w[threadIdx.x][0] + s_w[threadIdx.x][1] + s_w[threadIdx.x][2] + s_w[threadIdx.x][3];
     __syncthreads();
     if (threadIdx.x != 0) return;
     const float nanv = __builtin_nanf("");
@@ -377,7 +384,7 @@ extern "C" int qed_step_metrics(int32_t n_pix, const float* pred_rgb, const floa
     if (g > 1024) g = 1024;
     hipLaunchKernelGGL(step_metrics_kernel, dim3((unsigned)g), dim3(256), 0, st, n_pix, pred_rgb, gt_rgb, pred_depth,
                        gt_depth, tolerance, loss_mask, losses != nullptr ? 1 : 0, scales, n_scales, scale_stride, workspace);
-    hipLaunchKernelGGL(step_metrics_finalize_kernel, dim3(1), dim3(1024), 0, st, n_pix, (int)g, pred_depth != nullptr ? 1 : 0,
+    hipLaunchKernelGGL(step_metrics_finalize_kernel, dim3(1), dim3(256), 0, st, n_pix, (int)g, pred_depth != nullptr ? 1 : 0,
                        (const double*)workspace, ssim_sum, ssim_n, ssim_norm, scales != nullptr ? 1 : 0, rgb_weight,
                        depth_lambda, ssim_lambda, loss_sums, losses, out);
     return check_launch("qed_step_metrics");
