@@ -157,9 +157,35 @@ def _wrap(name, fn):
             rc = fn(*a)
             TIMER.end(tok)
             return rc
+        if MARKERS:                          # QED_ROCTX=1: a roctx range per entry point (rocprofv3 --marker-trace)
+            push, pop = MARKERS
+            push(name)
+            try:
+                return fn(*a)
+            finally:
+                pop()
         return fn(*a)
     call.__name__ = name
     return call
+
+
+def _roctx_markers():
+    """roctx ranges around the entry points K1-K8 are reached through, named after them, for
+    `rocprofv3 --marker-trace --kernel-trace`.  Off unless QED_ROCTX=1 (two extra host calls per entry point); through
+    torch.cuda.nvtx, which is roctx on a ROCm build of PyTorch."""
+    if os.environ.get("QED_ROCTX", "") != "1":
+        return None
+    try:
+        import torch
+        nv = torch.cuda.nvtx
+        nv.range_push("qed_splat")
+        nv.range_pop()
+        return (nv.range_push, nv.range_pop)
+    except Exception:                        # (a torch without the marker library: tracing is an aid, not a requirement)
+        return None
+
+
+MARKERS = _roctx_markers()
 
 
 class KernelTimer:
