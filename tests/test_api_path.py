@@ -780,3 +780,46 @@ def test_flat_adam_state_dict_round_trip(cuda, tmp_path):
     with pytest.raises(ValueError, match="load the model"):
         m3, _, _ = _model(scene(700, 96, 64, seed=6), cuda)
         FlatAdam(m3).load_state_dict(ck["optim"])
+
+
+def test_qedadam_group_without_a_gradient_does_not_delay_the_others(cuda):
+    """The six QedAdam instances of a flat buffer launch one fused update when the LAST of them is stepped.  A group whose
+    .grad is None in some iteration (or whose step a GradScaler skipped) must not hold the others' update back into the next
+    iteration's gradients: zero_grad() -- and state_dict(), flush() -- launch what is waiting, with THIS iteration's
+    gradients, exactly as six torch.optim.Adam would have stepped."""
+    from qed_splatter_amd.model import QedAdam, QEDSplatterModel, QEDSplatterModelConfig
+    n = 800
+    sc = scene(n, 64, 48, seed=13)
+    lrs = {"means": 1.6e-4, "scales": 0.005, "quats": 0.001, "opacities": 0.05, "features_dc": 0.0025, "features_rest": 1.25e-4}
+    cfg = QEDSplatterModelConfig.synthetic()
+    mq = QEDSplatterModel(cfg, **{k: sc[k].to(cuda) for k in PARAM_NAMES})
+    mt = QEDSplatterModel(cfg, separate_params=True, **{k: sc[k].to(cuda) for k in PARAM_NAMES})
+    oq = {k: QedAdam([mq.gauss_params[k]], lr=lrs[k], eps=1e-15) for k in mq.group_names}
+    ot = {k: torch.optim.Adam([mt.gauss_params[k]], lr=lrs[k], eps=1e-15) for k in mt.group_names}
+    g = torch.Generator().manual_seed(1)
+    for it in range(3):
+        grads = {k: torch.randn(mq.gauss_params[k].shape, generator=g).to(cuda) for k in PARAM_NAMES}
+        skip = "quats" if it == 1 else None                       # iteration 1: the quats group has no gradient
+        for m, opts in ((mq, oq), (mt, ot)):
+            for k in PARAM_NAMES:
+                m.gauss_params[k].grad = None if k == skip else grads[k].clone()
+            for k in PARAM_NAMES:
+                opts[k].step()
+        if it == 1:
+            # five groups are waiting for the sixth; the trainer's zero_grad() at the top of the next iteration launches them
+            assert len(oq["means"]._shared.pending) == 5
+        for opts in (oq, ot):
+            for o in opts.values():
+                o.zero_grad()
+        assert len(oq["means"]._shared.pending) == 0
+    for k in PARAM_NAMES:
+        assert_close_elem(mq.gauss_params[k], mt.gauss_params[k], f"{k} after an iteration without a quats gradient", atol_frac=1e-6)
+    assert float(oq["quats"].state[mq.gauss_params["quats"]]["step"]) == 2.0 == float(ot["quats"].state[mt.gauss_params["quats"]]["step"])
+    # state_dict() flushes as well
+    for k in PARAM_NAMES:
+        mq.gauss_params[k].grad = torch.randn(mq.gauss_params[k].shape, generator=g).to(cuda)
+    for k in PARAM_NAMES[:3]:
+        oq[k].step()
+    assert len(oq["means"]._shared.pending) == 3
+    sd = oq["means"].state_dict()
+    assert len(oq["means"]._shared.pending) == 0 and float(sd["state"][0]["step"]) == 4.0
