@@ -165,7 +165,11 @@ int qed_sort_pairs(uint64_t* keys, int32_t* vals, uint64_t* keys_alt, int32_t* v
  * the 32 depth bits (stable, in LDS for runs of <= 2048 entries, through global scratch beyond) -- no global
  * sort of the C*N slots, 10 launches instead of 23, faster while the runs are short.  QED_BIN_AUTO picks by
  * capacity per tile.  block_sums (may be NULL): qed_project_fwd's per-256-slot sums of tiles_per_gauss, which
- * save the tile-sort pipeline one counting launch. */
+ * save the tile-sort pipeline one counting launch.
+ * host_words (may be NULL): int32[4], 16-byte aligned, in HOST-MAPPED memory (hipHostMalloc / a pinned torch tensor);
+ * the call's last list kernel stores {M, status[0], status[1], 0} there in ONE 16-byte store.  A caller that wants the
+ * count without blocking sets word 0 to -1 before the call and looks at it later (M >= 0 once the store has landed):
+ * neither a device-to-host copy nor an event enters the stream. */
 #define QED_BIN_AUTO 0
 #define QED_BIN_TWO_STAGE 1
 #define QED_BIN_TILE_SORT 2
@@ -174,7 +178,7 @@ int qed_bin_tiles(int32_t N, int32_t C, const float* means2d, const int32_t* rad
                   const int32_t* tiles_per_gauss, const float* splats, const int32_t* block_sums,
                   int32_t tile_w, int32_t tile_h, int64_t capacity, int32_t mode, int32_t* flatten_ids,
                   int32_t* offsets, int32_t* n_isect, uint64_t* isect_ids, void* workspace,
-                  int64_t workspace_bytes, int32_t* status, void* stream);
+                  int64_t workspace_bytes, int32_t* status, int32_t* host_words, void* stream);
 
 /* ---- K5: tile offsets --------------------------------------------------------------------------
  * offsets[C*T + 1]: offsets[t] = first sorted index whose (cam,tile) >= t; offsets[C*T] = M. */

@@ -569,41 +569,72 @@ __device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_rec)[kRecFl
     BwdPixel px[NQ];
     int quad_last[NQ];
     int tile_last = -1;
+    // Pixel state, in two steps: first every load of every quadrant from a CLAMPED pixel address (no branch, so all of
+    // them are in flight together: one memory round trip per wave instead of one per quadrant -- and, with the
+    // post-processing gradient, no load that waits for another's result), then the arithmetic, masked by `inside`.
+    bool inside[NQ];
+    float a_in[NQ], vra_in[NQ], vd_in[NQ];
+    int last_in[NQ];
+    float4 r4_in[NQ];                                          // v_render, or the render of the post-processing gradient
+    Float3 g3_in[NQ];
+    size_t pix_in[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int qq = NQ == 4 ? q : q0;
         const int ix = tx * QED_TILE + ((qq & 1) << 3) + lx, iy = ty * QED_TILE + ((qq >> 1) << 3) + ly;
         pq[q] = (f2){(float)ix + 0.5f, (float)iy + 0.5f};
-        const bool inside = ix < width && iy < height;
+        inside[q] = ix < width && iy < height;
+        const size_t pix = ((size_t)cam * height + min(iy, height - 1)) * width + min(ix, width - 1);
+        pix_in[q] = pix;
+        a_in[q] = render_alpha[pix];
+        last_in[q] = last_ids[pix];
+        vra_in[q] = 0.f; vd_in[q] = 0.f; g3_in[q] = Float3{0.f, 0.f, 0.f};
+    }
+    {
+        const float* rsrc = post.bg == nullptr ? v_render : post.render;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if constexpr (CH == 4) {
+                r4_in[q] = *reinterpret_cast<const float4*>(rsrc + 4 * pix_in[q]);
+            } else {
+                r4_in[q] = make_float4(rsrc[3 * pix_in[q]], rsrc[3 * pix_in[q] + 1], rsrc[3 * pix_in[q] + 2], 0.f);
+            }
+        }
+    }
+    if (post.bg == nullptr) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) vra_in[q] = v_alpha[pix_in[q]];
+    } else {
+        if (post.v_rgb != nullptr) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) g3_in[q] = *reinterpret_cast<const Float3*>(post.v_rgb + 3 * pix_in[q]);
+        }
+        if constexpr (CH == 4) {
+            if (post.v_depth != nullptr) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) vd_in[q] = post.v_depth[pix_in[q]];
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
         float T_final = 1.f, vra = 0.f;
         float vr[4] = {0.f, 0.f, 0.f, 0.f};
         px[q].bin_final = -1;
-        if (inside) {
-            const size_t pix = ((size_t)cam * height + iy) * width + ix;
-            const float a_px = render_alpha[pix];
+        if (inside[q]) {
+            const float a_px = a_in[q];
             T_final = 1.f - a_px;
-            px[q].bin_final = last_ids[pix];
+            px[q].bin_final = last_in[q];
             if (post.bg == nullptr) {
-                vra = v_alpha[pix];
-                if constexpr (CH == 4) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(v_render + 4 * pix);
-                    vr[0] = t4.x; vr[1] = t4.y; vr[2] = t4.z; vr[3] = t4.w;
-                } else {
-                    vr[0] = v_render[3 * pix]; vr[1] = v_render[3 * pix + 1]; vr[2] = v_render[3 * pix + 2];
-                }
+                vra = vra_in[q];
+                vr[0] = r4_in[q].x; vr[1] = r4_in[q].y; vr[2] = r4_in[q].z;
+                if constexpr (CH == 4) vr[3] = r4_in[q].w;
             } else {
                 // the backward of rgb = clamp(render + (1 - alpha) bg, 0, 1) and depth = alpha > 0 ? d : max d (detached), here
                 // instead of in a pass of its own (qed_post_process_bwd's arithmetic)
-                float c[3];
-                if constexpr (CH == 4) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(post.render + 4 * pix);
-                    c[0] = t4.x; c[1] = t4.y; c[2] = t4.z;
-                } else {
-                    c[0] = post.render[3 * pix]; c[1] = post.render[3 * pix + 1]; c[2] = post.render[3 * pix + 2];
-                }
+                const float c[3] = {r4_in[q].x, r4_in[q].y, r4_in[q].z};
                 if (post.v_rgb != nullptr) {
-                    const Float3 g3 = *reinterpret_cast<const Float3*>(post.v_rgb + 3 * pix);
-                    const float g[3] = {g3.a, g3.b, g3.c};
+                    const float g[3] = {g3_in[q].a, g3_in[q].b, g3_in[q].c};
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
                         const float pre = c[k] + (1.f - a_px) * post.bg[k];
@@ -612,7 +643,7 @@ __device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_rec)[kRecFl
                     }
                 }
                 if constexpr (CH == 4) {
-                    if (post.v_depth != nullptr && a_px > 0.f) vr[3] = post.v_depth[pix];
+                    if (a_px > 0.f) vr[3] = vd_in[q];
                 }
             }
             if (backgrounds != nullptr) {

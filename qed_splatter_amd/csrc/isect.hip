@@ -171,9 +171,16 @@ isect_emit_kernel(int N, int C, const float* __restrict__ means2d, const int* __
 template <typename KeyT>
 __global__ void __launch_bounds__(256)
 tile_offsets_kernel(const KeyT* __restrict__ keys, const int* __restrict__ n_dev, int n_tiles_total,
-                    int n_tiles, int tile_bits, int* __restrict__ offsets) {
+                    int n_tiles, int tile_bits, int* __restrict__ offsets, const int* __restrict__ status = nullptr,
+                    int* __restrict__ host_words = nullptr) {
     const int n = n_dev[0];
     const long long t0 = (long long)blockIdx.x * 256 + threadIdx.x, nt = (long long)gridDim.x * 256;
+    // qed_bin_tiles' host_words: {M, overflow word, sort watchdog word, 0} straight into host-mapped memory, as ONE
+    // 16-byte store (a reader that sees word 0 change sees all four) -- every kernel that sets one of them has retired
+    // by now, and the caller is spared a copy and an event in the stream (a blit kernel and two barriers: ~10 us
+    // between the binning and the compositing pass)
+    if (host_words != nullptr && t0 == 0)
+        *reinterpret_cast<int4*>(host_words) = make_int4(n, status[0], status[1], 0);
     if (n == 0) {
         for (long long i = t0; i <= n_tiles_total; i += nt) offsets[i] = 0;
         return;
@@ -679,11 +686,12 @@ extern "C" int qed_bin_tiles(int32_t N, int32_t C, const float* means2d, const i
                              const int32_t* tiles_per_gauss, const float* splats, const int32_t* block_sums_in,
                              int32_t tile_w, int32_t tile_h, int64_t capacity, int32_t mode, int32_t* flatten_ids,
                              int32_t* offsets, int32_t* n_isect, uint64_t* isect_ids, void* workspace,
-                             int64_t workspace_bytes, int32_t* status, void* stream) {
+                             int64_t workspace_bytes, int32_t* status, int32_t* host_words, void* stream) {
     QED_REQUIRE(N >= 0 && C >= 1 && tile_w > 0 && tile_h > 0, "bad extents");
     QED_REQUIRE(splats == nullptr || (tile_w <= 1023 && tile_h <= 2047), "packed tile rectangles need tile_w <= 1023");
     QED_REQUIRE(capacity >= 0 && capacity < (1ll << 30), "capacity out of range");
     QED_REQUIRE(offsets && n_isect && status && workspace, "null buffers");
+    QED_REQUIRE(((uintptr_t)host_words & 15) == 0, "host_words must be 16-byte aligned");
     const long long S = (long long)C * N;
     QED_REQUIRE(S < (1ll << 30), "too many (camera, Gaussian) slots");
     const long long n_tot = (long long)C * tile_w * tile_h;
@@ -709,6 +717,7 @@ extern "C" int qed_bin_tiles(int32_t N, int32_t C, const float* means2d, const i
     if (S == 0 || capacity == 0) {
         hipError_t e = hipMemsetAsync(offsets, 0, (size_t)(n_tot + 1) * 4, st);
         if (e == hipSuccess) e = hipMemsetAsync(n_isect, 0, 4, st);
+        if (e == hipSuccess && host_words) e = hipMemsetAsync(host_words, 0, 16, st);
         if (e != hipSuccess) { set_error("qed_bin_tiles: memset failed"); return QED_E_LAUNCH; }
         return QED_OK;
     }
@@ -760,7 +769,8 @@ extern "C" int qed_bin_tiles(int32_t N, int32_t C, const float* means2d, const i
         unsigned* k_spare = which ? kB0 : kB1;
         const long long work = capacity > n_tot + 1 ? capacity : n_tot + 1;
         hipLaunchKernelGGL(tile_offsets_kernel<unsigned>, dim3(tile_offsets_grid(work)), dim3(256), 0, st, tile_keys,
-                           (const int*)n_isect, (int)n_tot, tile_w * tile_h, tile_bits, offsets);
+                           (const int*)n_isect, (int)n_tot, tile_w * tile_h, tile_bits, offsets, (const int*)status,
+                       host_words);
         // (3) every tile's run into depth order (stable: ties stay in slot order)
         hipLaunchKernelGGL(tile_depth_sort_kernel, dim3((unsigned)((n_tot + 3) / 4)), dim3(256), 0, st,
                            (const int*)offsets, (const int*)vB, depths, flatten_ids, k_spare, (unsigned*)(w + L.tk1),
@@ -789,7 +799,8 @@ extern "C" int qed_bin_tiles(int32_t N, int32_t C, const float* means2d, const i
     const unsigned* tile_keys = which ? kB1 : kB0;
     const long long work = capacity > n_tot + 1 ? capacity : n_tot + 1;
     hipLaunchKernelGGL(tile_offsets_kernel<unsigned>, dim3(tile_offsets_grid(work)), dim3(256), 0, st, tile_keys,
-                       (const int*)n_isect, (int)n_tot, tile_w * tile_h, tile_bits, offsets);
+                       (const int*)n_isect, (int)n_tot, tile_w * tile_h, tile_bits, offsets, (const int*)status,
+                       host_words);
     if (isect_ids != nullptr)
         hipLaunchKernelGGL(isect_ids_kernel, dim3((unsigned)((capacity + 255) / 256)), dim3(256), 0, st, tile_keys,
                            (const int*)flatten_ids, depths, (const int*)n_isect, (unsigned long long*)isect_ids);

@@ -699,11 +699,12 @@ class QEDSplatterModel(nn.Module):
             _c2w=cam_c2w,
             _post_background=background,
             _vsplat_holder=holder,
+            _means2d_leaf=True,     # xys is only retained and read (below; densify.py): its gradient arrives as a view
         )
         attrs["_vsplat_pair"] = (holder, info["radii"].numel())
         attrs["info"] = info
         attrs["last_compact"] = False
-        if self.training and info["means2d"].requires_grad:                   # model.py:289-290
+        if self.training and info["means2d"].requires_grad:                   # model.py:289-290 (a no-op on the leaf)
             info["means2d"].retain_grad()
         attrs["xys"] = info["means2d"]                                        # [1,N,2]
         attrs["radii"] = info["radii"][0]                                     # [N]

@@ -21,6 +21,7 @@ gradient is ever repacked on the hot path.
 from __future__ import annotations
 
 import math
+import time
 import warnings
 import weakref
 from typing import Dict, Optional, Tuple
@@ -64,6 +65,7 @@ class _Workspace:
     """
 
     HEADROOM = 2.0          # capacity / longest list seen: grids are sized by it but only M entries are ever touched
+    POLL_TIMEOUT_S = 20.0   # how long poll_pending waits for a frame's count before it asks the device what happened
 
     def __init__(self, device):
         self.device = device
@@ -72,21 +74,27 @@ class _Workspace:
         self.words = torch.zeros(1 + L.STATUS_WORDS, dtype=torch.int32, device=device)
         self.n_isect = self.words[:1]
         self.status = self.words[1:]
-        self.words3 = self.words[:3]
-        self._ring, self._ring_at = [], 0     # pinned read-back buffers + events of the asynchronous calls, reused
-        self.pending = None          # (pinned host copy of [M, overflow, watchdog], event, shape key) of an async call
+        self._ring, self._ring_at = [], 0     # pinned read-back buffers of the asynchronous calls, reused
+        self.pending = None          # (pinned host words [M, overflow, watchdog, 0], shape key) of an async call
         self.m_seen: Dict[tuple, int] = {}   # shape key -> longest list read back for that shape
         self.force_sync = False      # the next call reads M back (an asynchronous frame overflowed)
         self.overflows = 0           # asynchronous frames that rendered empty (diagnostics / tests)
 
     def host_slot(self):
-        """A pinned 3-word buffer and an event for one asynchronous read-back.  At most one read-back is pending at a time
-        (the next call polls it before it records its own), so two slots used in turn are never overwritten in flight;
-        allocating pinned memory and an event per call cost ~30 us of host time per step."""
+        """A pinned 4-word buffer for one asynchronous read-back, as (numpy view, address): qed_bin_tiles' last list kernel
+        stores {M, overflow, watchdog, 0} into it (``host_words``: pinned memory is mapped into the device's address space)
+        and ``poll_pending`` watches word 0 turn from -1 into M.  Neither a copy nor an event enters the stream: the 12-byte
+        device-to-host copy and the event that used to sit behind the binning cost ~10 us between it and the compositing
+        pass (a blit kernel and two barrier packets).  At most one read-back is pending at a time (the next call polls it
+        before it arms its own), so two slots used in turn are never overwritten in flight."""
         if not self._ring:
-            self._ring = [(torch.empty(3, dtype=torch.int32, pin_memory=True), torch.cuda.Event()) for _ in range(2)]
+            for _ in range(2):
+                host = torch.zeros(4, dtype=torch.int32).pin_memory()
+                self._ring.append((host.numpy(), host.data_ptr(), host))     # (the tensor keeps the memory alive)
         self._ring_at ^= 1
-        return self._ring[self._ring_at]
+        words, ptr, _keep = self._ring[self._ring_at]
+        words[0] = -1
+        return words, ptr
 
     def reset(self) -> None:
         """Forget every calibration (the next call of any shape reads M back and sizes the buffer afresh)."""
@@ -109,10 +117,19 @@ class _Workspace:
     def poll_pending(self) -> None:
         if self.pending is None:
             return
-        host, ev, key = self.pending
-        ev.synchronize()
+        words, key = self.pending
         self.pending = None
-        M, overflow, watchdog = int(host[0]), int(host[1]), int(host[2])
+        if words[0] < 0:
+            # the host is a frame ahead of the device: wait for that frame's binning (yielding the GIL between looks)
+            deadline = time.monotonic() + self.POLL_TIMEOUT_S
+            while words[0] < 0:
+                time.sleep(0)
+                if time.monotonic() > deadline:
+                    torch.cuda.synchronize(self.device)             # surfaces a device fault as its own error
+                    if words[0] < 0:
+                        raise L.QedSplatError("the intersection count of the previous asynchronous rasterization never "
+                                              "arrived (qed_bin_tiles' host_words)")
+        M, overflow, watchdog = int(words[0]), int(words[1]), int(words[2])
         if watchdog:
             self.status.zero_()
             raise L.QedSplatError("the radix-sort look-back watchdog fired in the previous asynchronous rasterization: "
@@ -331,6 +348,9 @@ def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, til
     mode = L.bin_mode()
     if mode == L.BIN_AUTO and ws.m_seen.get(key, 0) > 0:
         mode = L.BIN_TILE_SORT if int(1.25 * ws.m_seen[key]) <= 1024 * C * n_tiles else L.BIN_TWO_STAGE
+    host = host_ptr = None
+    if not sync and not capturing:
+        host, host_ptr = ws.host_slot()
     for _attempt in range(2):
         cap = ws.capacity
         flatten_ids = torch.empty(cap, dtype=torch.int32, device=dev)
@@ -339,15 +359,12 @@ def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, til
         L.check(lib.qed_bin_tiles(N, C, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(tiles_per_gauss), L.ptr(splats),
                                   L.ptr(block_sums), tile_w, tile_h, cap, mode, L.ptr(flatten_ids), L.ptr(offsets),
                                   L.ptr(n_isect), L.ptr(isect_ids), L.ptr(scratch), scratch.numel(), L.ptr(ws.status),
-                                  _stream()), "qed_bin_tiles")
+                                  host_ptr, _stream()), "qed_bin_tiles")
         if capturing:
             ws.last_n_isect = n_isect                  # device tensor the replaying code polls
             return None, flatten_ids, offsets, None
         if not sync:
-            host, ev = ws.host_slot()
-            host.copy_(ws.words3, non_blocking=True)
-            ev.record()
-            ws.pending = (host, ev, key)
+            ws.pending = (host, key)
             return None, flatten_ids, offsets, None
         # one host read: M, the overflow word and the look-back watchdog word
         host = ws.words[:3].tolist()
@@ -367,10 +384,11 @@ def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, til
 class _Composite(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means2d, conics, rgb, opac, depths, splats, flatten_ids, offsets, backgrounds, width, height,
-                tile_w, tile_h, channels, absgrad, vsplat_holder=None, post_background=None):
+                tile_w, tile_h, channels, absgrad, vsplat_holder=None, post_background=None, grad_leaf=None):
         lib = L.load()
         ctx.set_materialize_grads(False)
         ctx.vsplat_holder = vsplat_holder
+        ctx.grad_leaf = grad_leaf[0] if grad_leaf else None      # (in a list: not an autograd input)
         C, N = opac.shape
         dev = opac.device
         render = torch.empty(C, height, width, channels, dtype=torch.float32, device=dev)
@@ -458,10 +476,15 @@ class _Composite(torch.autograd.Function):
         v_rgb_g = v3[..., 8:11]
         v_depths = v3[..., 11] if channels == 4 else None
         _VSPLAT_REGISTRY[vsplat.untyped_storage().data_ptr()] = vsplat
+        leaf = ctx.grad_leaf
+        if leaf is not None:
+            # rasterization(_means2d_leaf=True): info["means2d"] is a leaf that takes the gradient as a VIEW of the
+            # accumulator rows (what retain_grad() on the non-leaf clones: 4 MB through a strided copy kernel, ~9 us)
+            leaf.grad = v_means2d
         if absgrad:
             # gsplat convention (absgrad=True at model.py:284): the densifier reads means2d.absgrad
-            ctx.means2d_ref.absgrad = v3[..., 2:4]
-        return (v_means2d, v_conics, v_rgb_g, v_opac, v_depths) + (None,) * 12
+            (leaf if leaf is not None else ctx.means2d_ref).absgrad = v3[..., 2:4]
+        return (v_means2d, v_conics, v_rgb_g, v_opac, v_depths) + (None,) * 13
 
 
 def C_byref(struct):
@@ -480,7 +503,7 @@ def rasterization(
     absgrad: bool = False, rasterize_mode: str = "classic", radius_clip: float = 0.0, eps2d: float = 0.3,
     backgrounds: Optional[Tensor] = None, _flags: int = 0, _sh_rest: Optional[Tensor] = None,
     _sync: bool = True, _vsplat_holder: Optional[list] = None, _c2w: Optional[Tuple[Tensor, Tensor]] = None,
-    _post_background: Optional[Tensor] = None,
+    _post_background: Optional[Tensor] = None, _means2d_leaf: bool = False,
 ) -> Tuple[Tensor, Tensor, Dict]:
     """Same call surface as the reference's call (model.py:267-288).
 
@@ -489,7 +512,8 @@ def rasterization(
     and ``colors`` / ``_sh_rest`` may be features_dc / features_rest without the torch.cat of
     model.py:241.  ``_post_background`` [3]: the statements that follow the call in get_outputs (model.py:295-297,
     304-306) run inside the compositing kernels; ``info["post_rgb"]`` [C,H,W,3] and ``info["post_depth"]`` [C,H,W,1]
-    (RGB+D) are their results, differentiable like ``render`` / ``alpha``.
+    (RGB+D) are their results, differentiable like ``render`` / ``alpha``.  ``_means2d_leaf``: ``info["means2d"]`` is a
+    leaf that receives ``.grad`` / ``.absgrad`` as views (see below) instead of gsplat's non-leaf.
     """
     if packed or sparse_grad:
         raise NotImplementedError("packed=True / sparse_grad=True are not used by the reference (model.py:278,283)")
@@ -545,13 +569,21 @@ def rasterization(
     isect_ids, flatten_ids, offsets, M = _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums,
                                                        tile_w, tile_h, sync=_sync, splats=splats if use_packed else None,
                                                        size=(int(width), int(height)))
+    # _means2d_leaf: hand out info["means2d"] as a LEAF holding the same values, which receives .grad / .absgrad from
+    # the compositing backward without a copy.  For callers that only retain and read the gradient (the reference:
+    # model.py:289-290 and the densification strategy); a loss computed FROM info["means2d"] would not reach the
+    # Gaussians through the leaf, which is why it is not the default.
+    means2d_out, grad_leaf = means2d, None
+    if _means2d_leaf and means2d.requires_grad:
+        means2d_out = means2d.detach().requires_grad_(True)
+        grad_leaf = [means2d_out]
     outs = _Composite.apply(means2d, conics, rgb, opac, depths if channels == 4 else None, splats, flatten_ids, offsets,
                             backgrounds, int(width), int(height), tile_w, tile_h, channels, bool(absgrad), _vsplat_holder,
-                            _post_background)
+                            _post_background, grad_leaf)
     render, alpha, last_ids = outs[:3]
     info = {
         "camera_ids": None, "gaussian_ids": None,
-        "radii": radii, "means2d": means2d, "depths": depths, "conics": conics, "opacities": opac,
+        "radii": radii, "means2d": means2d_out, "depths": depths, "conics": conics, "opacities": opac,
         "tile_width": tile_w, "tile_height": tile_h, "tiles_per_gauss": tiles_per_gauss,
         "isect_ids": isect_ids, "flatten_ids": flatten_ids,
         "isect_offsets": offsets[: C * tile_w * tile_h].view(C, tile_h, tile_w),
