@@ -40,6 +40,7 @@ extern "C" {
 #define QED_STEP_METRICS_WS_DOUBLES (16 * 1024)  /* workspace of qed_step_metrics */
 #define QED_LOSS_SUMS_FLOATS (8 + 4 * 1024) /* sums workspace of qed_loss_reduce / qed_loss_grad */
 #define QED_VSPLAT_FLOATS 16    /* packed per-(camera,Gaussian) gradient row, see qed_composite_bwd */
+#define QED_SH_JAC_FLOATS 10    /* per-(camera,Gaussian) floats of qed_project_fwd's sh_jac hand-over */
 
 /* flags of qed_project_fwd / qed_project_bwd */
 #define QED_F_ANTIALIASED 1u    /* rasterize_mode == "antialiased": opacity *= compensation */
@@ -88,7 +89,12 @@ int qed_camera_setup(int32_t C, const float* c2w, const float* intrinsics, float
  *   {x, y, conic_a, conic_b | conic_c, opacity, r, g | b, depth, ln(255 opacity), 0} read by the
  *   compositing kernels; block_sums[ceil(C*N/256)] i32 = tile counts summed per 256
  *   consecutive (camera,Gaussian) slots (input of qed_isect_scan).
- * Culled Gaussians get radius 0 and zeros everywhere. */
+ * Culled Gaussians get radius 0 and zeros everywhere.
+ * sh_jac (may be NULL; used with sh_degree >= 0): QED_SH_JAC_FLOATS planes of C*N floats that the backward pass takes
+ *   instead of the coefficients -- planes 0..8 = d colour_ch / d unit direction_axis at [3 axis + ch] (sum over k of
+ *   d b_k / d axis * c_k,ch, before the clamp), plane 9 = the clamp mask as an integer (bit ch: colour_ch + 0.5 >= 0).
+ *   Written for visible (camera, Gaussian) slots only.  With it qed_project_bwd reads 40 B per slot where it would
+ *   re-read all 3 K coefficients (192 B at degree 3) and rebuild the basis derivatives beside the projection state. */
 int qed_project_fwd(int32_t N, int32_t C, const float* means, const float* quats, const float* scales,
                     const float* opacities, const float* sh0, int32_t sh0_stride, const float* shN,
                     int32_t shN_stride, int32_t sh_degree, const float* viewmats, const float* Ks,
@@ -96,7 +102,7 @@ int qed_project_fwd(int32_t N, int32_t C, const float* means, const float* quats
                     float near_plane, float far_plane, float radius_clip, uint32_t flags,
                     int32_t* radii, float* means2d, float* depths, float* conics, float* opac_out,
                     float* colors_out, float* splats, int32_t* tiles_per_gauss, int32_t* block_sums,
-                    float* viewmats_out, float* Ks_out, void* stream);
+                    float* viewmats_out, float* Ks_out, float* sh_jac, void* stream);
 
 /* Backward of qed_project_fwd (autograd backward of the projection + SH part of model.py:267-288).
  * vsplat[C*N][16] = packed gradient row written by qed_composite_bwd:
@@ -105,14 +111,16 @@ int qed_project_fwd(int32_t N, int32_t C, const float* means, const float* quats
  * v_opacities[N] v_sh0 (stride v_sh0_stride) v_shN (stride v_shN_stride); with
  * QED_F_LOG_SCALES / QED_F_LOGIT_OPAC / QED_F_SIGMOID_COLORS the exp / sigmoid Jacobians are
  * applied so the gradients are w.r.t. the raw parameters.  v_viewmats[C,4,4] (nullable) is
- * accumulated with atomics and must be zeroed by the caller (camera optimiser, model.py:212). */
+ * accumulated with atomics and must be zeroed by the caller (camera optimiser, model.py:212).
+ * sh_jac (may be NULL): the planes qed_project_fwd wrote for the SAME inputs; when given (and sh_degree >= 0) sh0 / shN
+ * are not read and may be NULL.  Same gradients either way (the sums run in the same order). */
 int qed_project_bwd(int32_t N, int32_t C, const float* means, const float* quats, const float* scales,
                     const float* opacities, const float* sh0, int32_t sh0_stride, const float* shN,
                     int32_t shN_stride, int32_t sh_degree, const float* viewmats, const float* Ks,
                     int32_t width, int32_t height, float eps2d, uint32_t flags, const int32_t* radii,
                     const float* vsplat, float* v_means, float* v_quats, float* v_scales,
                     float* v_opacities, float* v_sh0, int32_t v_sh0_stride, float* v_shN,
-                    int32_t v_shN_stride, float* v_viewmats, void* stream);
+                    int32_t v_shN_stride, float* v_viewmats, const float* sh_jac, void* stream);
 
 /* ---- data-parallel exchange of the SH gradients -----------------------------------------
  * d L / d sh_k = sum over views of b_k(dir_view) * v_view (b_k the real SH basis, dir = mean - camera

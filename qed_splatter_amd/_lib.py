@@ -27,9 +27,9 @@ SIGNATURES = {
     "qed_last_error": (C.c_char_p, []),
     "qed_camera_setup": (C.c_int, [_I, _P, _P, _P, _P, _P]),
     "qed_project_fwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _F, _F, _F,
-                                  _F, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+                                  _F, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qed_project_bwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _I, _F, _U, _P, _P, _P,
-                                  _P, _P, _P, _P, _I, _P, _I, _P, _P]),
+                                  _P, _P, _P, _P, _I, _P, _I, _P, _P, _P]),
     "qed_isect_scan": (C.c_int, [_P, _I, _P, _P, _L, _P, _P]),
     "qed_isect_emit": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _L, _P, _P, _P]),
     "qed_sort_workspace_bytes": (_L, [_L]),
@@ -100,6 +100,7 @@ F_CAMERA_C2W = 128
 F_SH_GRAD_COMPACT = 64
 SPLAT_FLOATS = 12
 VSPLAT_FLOATS = 16
+SH_JAC_FLOATS = 10            # QED_SH_JAC_FLOATS
 STATUS_WORDS = 4
 TILE = 16
 CL_TILE_WAVES, CL_QUADRANT_WAVES, CL_HALF_AND_HALF, CL_NO_CULL = 1, 2, 3, 4

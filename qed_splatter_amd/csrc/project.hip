@@ -222,29 +222,48 @@ __device__ __forceinline__ void load_sh(const float* __restrict__ sh0, const flo
     }
 }
 
+// SH colour (+0.5, clamp) that also hands the backward pass what it would otherwise re-derive from all 3 K coefficients
+// (96 MB of reads at config B, and the basis-derivative tables beside the projection state: 256 registers, 22 of them
+// spilled): J[axis][ch] = sum_k d b_k / d axis * c_k,ch -- the colour's derivative with respect to the unit direction --
+// and the clamp mask (bit ch: colour_ch + 0.5 >= 0).  Ten floats per (camera, Gaussian) instead of 48 coefficients; the
+// sums run in the order sh_bwd_stream uses.
 template <int DEG>
-__device__ __forceinline__ void sh_color(const float* __restrict__ sh0, const float* __restrict__ shN,
-                                         const float* dir, float* rgb) {
+__device__ __forceinline__ void sh_color_jac(const float* __restrict__ sh0, const float* __restrict__ shN,
+                                             const float* dir, float* rgb, float* J /*9: [axis][ch]*/, unsigned& mask) {
     constexpr int K = (DEG + 1) * (DEG + 1);
     const float inorm = rsqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
-    float b[K];
-    sh_basis<DEG>(dir[0] * inorm, dir[1] * inorm, dir[2] * inorm, b);
-    float c[3 * K];
-    load_sh<K>(sh0, shN, c);
-    float r = 0.f, g = 0.f, bl = 0.f;
+    const float x = dir[0] * inorm, y = dir[1] * inorm, z = dir[2] * inorm;
+    float b[K], bx[K], by[K], bz[K];
+    sh_basis<DEG>(x, y, z, b);
+    sh_basis_grad<DEG>(x, y, z, bx, by, bz);
+    float col[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) J[i] = 0.f;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        r += b[k] * c[3 * k]; g += b[k] * c[3 * k + 1]; bl += b[k] * c[3 * k + 2];
+        const float* ck = k == 0 ? sh0 : shN + 3 * (k - 1);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float c = ck[ch];
+            col[ch] += b[k] * c;
+            if (k > 0) { J[ch] += bx[k] * c; J[3 + ch] += by[k] * c; J[6 + ch] += bz[k] * c; }
+        }
     }
-    rgb[0] = fmaxf(r + 0.5f, 0.f); rgb[1] = fmaxf(g + 0.5f, 0.f); rgb[2] = fmaxf(bl + 0.5f, 0.f);
+    mask = 0u;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        if (col[ch] + 0.5f >= 0.f) mask |= 1u << ch;
+        rgb[ch] = fmaxf(col[ch] + 0.5f, 0.f);
+    }
 }
 
-__device__ __forceinline__ void sh_color_dyn(int deg, const float* sh0, const float* shN, const float* dir, float* rgb) {
+__device__ __forceinline__ void sh_color_jac_dyn(int deg, const float* sh0, const float* shN, const float* dir, float* rgb,
+                                                 float* J, unsigned& mask) {
     switch (deg) {
-        case 0: sh_color<0>(sh0, shN, dir, rgb); break;
-        case 1: sh_color<1>(sh0, shN, dir, rgb); break;
-        case 2: sh_color<2>(sh0, shN, dir, rgb); break;
-        default: sh_color<3>(sh0, shN, dir, rgb); break;
+        case 0: sh_color_jac<0>(sh0, shN, dir, rgb, J, mask); break;
+        case 1: sh_color_jac<1>(sh0, shN, dir, rgb, J, mask); break;
+        case 2: sh_color_jac<2>(sh0, shN, dir, rgb, J, mask); break;
+        default: sh_color_jac<3>(sh0, shN, dir, rgb, J, mask); break;
     }
 }
 
@@ -263,7 +282,8 @@ project_fwd_kernel(int N, int C, const float* __restrict__ means, const float* _
                    float radius_clip, unsigned flags, int* __restrict__ radii, float* __restrict__ means2d,
                    float* __restrict__ depths, float* __restrict__ conics, float* __restrict__ opac_out,
                    float* __restrict__ colors_out, float4* __restrict__ splats, int* __restrict__ tiles_per_gauss,
-                   int* __restrict__ block_sums, float* __restrict__ viewmats_out, float* __restrict__ Ks_out) {
+                   int* __restrict__ block_sums, float* __restrict__ viewmats_out, float* __restrict__ Ks_out,
+                   float* __restrict__ sh_jac) {
     // slot = c * N + n ; 256 consecutive slots per block (block_sums granularity)
     const long long slot = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long total = (long long)C * N;
@@ -301,7 +321,17 @@ project_fwd_kernel(int N, int C, const float* __restrict__ means, const float* _
             if (flags & QED_F_ANTIALIASED) op *= p.comp;
             if (sh_degree >= 0) {
                 const float dir[3] = {mean[0] - cam.campos[0], mean[1] - cam.campos[1], mean[2] - cam.campos[2]};
-                sh_color_dyn(sh_degree, sh0 + (size_t)n * sh0_stride, shN + (size_t)n * shN_stride, dir, rgb);
+                // ONE evaluation whether or not the hand-over is wanted: a render with gradients and one without are
+                // the same image bit for bit (planes of C N floats: every store of a wave is 256 contiguous bytes,
+                // and so is every load of the backward pass)
+                float J[9];
+                unsigned mask;
+                sh_color_jac_dyn(sh_degree, sh0 + (size_t)n * sh0_stride, shN + (size_t)n * shN_stride, dir, rgb, J, mask);
+                if (sh_jac != nullptr) {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) sh_jac[(size_t)i * total + slot] = J[i];
+                    sh_jac[(size_t)9 * total + slot] = __uint_as_float(mask);
+                }
             } else {
                 const float* cptr = sh0 + (size_t)n * sh0_stride;
                 rgb[0] = cptr[0]; rgb[1] = cptr[1]; rgb[2] = cptr[2];
@@ -384,6 +414,52 @@ __device__ __forceinline__ void sh_bwd(const float* __restrict__ sh0, const floa
     }
 }
 
+// The SH backward from the forward pass's hand-over (sh_color_jac): no coefficient is read.  STREAM: the coefficient
+// gradients go straight to memory (one camera); otherwise they are accumulated in v_coef.
+template <int DEG, bool STREAM>
+__device__ __forceinline__ void sh_bwd_jac(const float* __restrict__ jac /* this slot's first plane entry */, size_t plane,
+                                           const float* dir, const float* v_rgb_in, float* __restrict__ o0,
+                                           float* __restrict__ oN, float* v_coef, float* v_dir /*3, +=*/, bool compact) {
+    constexpr int K = (DEG + 1) * (DEG + 1);
+    float J[9];
+#pragma unroll
+    for (int i = 0; i < (DEG > 0 ? 9 : 0); ++i) J[i] = jac[(size_t)i * plane];
+    const unsigned mask = __float_as_uint(jac[(size_t)9 * plane]);
+    const float n2 = dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2];
+    const float inorm = rsqrtf(n2);
+    const float x = dir[0] * inorm, y = dir[1] * inorm, z = dir[2] * inorm;
+    float v[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) v[ch] = (mask >> ch & 1u) ? v_rgb_in[ch] : 0.f;
+    if (STREAM && compact) {
+        o0[0] = v[0]; o0[1] = v[1]; o0[2] = v[2];
+    } else {
+        float b[K];
+        sh_basis<DEG>(x, y, z, b);
+        if constexpr (STREAM) {
+            o0[0] = b[0] * v[0]; o0[1] = b[0] * v[1]; o0[2] = b[0] * v[2];
+#pragma unroll
+            for (int k = 1; k < K; ++k) {
+                oN[3 * (k - 1)] = b[k] * v[0]; oN[3 * (k - 1) + 1] = b[k] * v[1]; oN[3 * (k - 1) + 2] = b[k] * v[2];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                v_coef[3 * k] += b[k] * v[0]; v_coef[3 * k + 1] += b[k] * v[1]; v_coef[3 * k + 2] += b[k] * v[2];
+            }
+        }
+    }
+    if constexpr (DEG > 0) {
+        const float vx = J[0] * v[0] + J[1] * v[1] + J[2] * v[2];
+        const float vy = J[3] * v[0] + J[4] * v[1] + J[5] * v[2];
+        const float vz = J[6] * v[0] + J[7] * v[1] + J[8] * v[2];
+        const float dot = vx * x + vy * y + vz * z;
+        v_dir[0] += (vx - dot * x) * inorm;
+        v_dir[1] += (vy - dot * y) * inorm;
+        v_dir[2] += (vz - dot * z) * inorm;
+    }
+}
+
 // Single-camera variant of sh_bwd: the coefficient gradients are final after one camera, so they go
 // straight to memory instead of through a 48-register accumulator that stays live across the whole kernel
 // (with it the degree-3 kernel needed 256 VGPRs + 82 AGPRs = one wave per SIMD).
@@ -441,7 +517,9 @@ __device__ __forceinline__ void sh_bwd_stream(const float* __restrict__ sh0, con
     }
 }
 
-template <int DEG, bool ONE_CAM>
+// JAC: the SH part works from qed_project_fwd's sh_jac hand-over (sh_bwd_jac) instead of the coefficients: no basis-
+// derivative tables beside the projection state (183 registers without spills where the degree-3 kernel spills 22 of 256).
+template <int DEG, bool ONE_CAM, bool JAC = false>
 #ifndef QED_PBWD_WAVES
 #define QED_PBWD_WAVES 2
 #endif
@@ -453,7 +531,8 @@ project_bwd_kernel(int N, int C, const float* __restrict__ means, const float* _
                    float eps2d, unsigned flags, const int* __restrict__ radii, const float4* __restrict__ vsplat,
                    float* __restrict__ v_means, float* __restrict__ v_quats, float* __restrict__ v_scales,
                    float* __restrict__ v_opacities, float* __restrict__ v_sh0, int v_sh0_stride,
-                   float* __restrict__ v_shN, int v_shN_stride, float* __restrict__ v_viewmats) {
+                   float* __restrict__ v_shN, int v_shN_stride, float* __restrict__ v_viewmats,
+                   const float* __restrict__ sh_jac) {
     // DEG = -1: colours pass through (sh_degree None)
     constexpr int K = DEG < 0 ? 1 : (DEG + 1) * (DEG + 1);
     const int n = blockIdx.x * 256 + threadIdx.x;
@@ -578,7 +657,14 @@ project_bwd_kernel(int N, int C, const float* __restrict__ means, const float* _
             float vdir[3] = {0.f, 0.f, 0.f};
             if constexpr (DEG >= 0) {
                 const float dir[3] = {mean[0] - cam.campos[0], mean[1] - cam.campos[1], mean[2] - cam.campos[2]};
-                if constexpr (kStreamSH) {
+                if constexpr (JAC) {
+                    const size_t plane = (size_t)C * N;
+                    sh_bwd_jac<(DEG < 0 ? 0 : DEG), kStreamSH>(sh_jac + slot, plane, dir, v_rgb,
+                                                                v_sh0 + (size_t)n * v_sh0_stride,
+                                                                v_shN + (size_t)n * v_shN_stride, vcoef, vdir,
+                                                                (flags & QED_F_SH_GRAD_COMPACT) != 0);
+                    sh_written = true;
+                } else if constexpr (kStreamSH) {
                     sh_bwd_stream<(DEG < 0 ? 0 : DEG)>(sh0 + (size_t)n * sh0_stride, shN + (size_t)n * shN_stride, dir,
                                                        v_rgb, v_sh0 + (size_t)n * v_sh0_stride,
                                                        v_shN + (size_t)n * v_shN_stride, vdir,
@@ -782,7 +868,7 @@ extern "C" int qed_project_fwd(int32_t N, int32_t C, const float* means, const f
                                float near_plane, float far_plane, float radius_clip, uint32_t flags, int32_t* radii,
                                float* means2d, float* depths, float* conics, float* opac_out, float* colors_out,
                                float* splats, int32_t* tiles_per_gauss, int32_t* block_sums, float* viewmats_out,
-                               float* Ks_out, void* stream) {
+                               float* Ks_out, float* sh_jac, void* stream) {
     QED_REQUIRE(N >= 0 && C >= 1, "N >= 0 and C >= 1 required");
     QED_REQUIRE(sh_degree <= 3, "SH degree > 3 unsupported (reference config uses sh_degree = 3)");
     QED_REQUIRE(width > 0 && height > 0 && tile_w > 0 && tile_h > 0, "bad image / tile extents");
@@ -799,7 +885,8 @@ extern "C" int qed_project_fwd(int32_t N, int32_t C, const float* means, const f
     hipLaunchKernelGGL(project_fwd_kernel<ONE>, dim3(grid), dim3(256), 0, (hipStream_t)stream, N, C, means, quats,   \
                        scales, opacities, sh0, sh0_stride, shN, shN_stride, sh_degree, viewmats, Ks, width, height,  \
                        tile_w, tile_h, eps2d, near_plane, far_plane, radius_clip, flags, radii, means2d, depths,     \
-                       conics, opac_out, colors_out, (float4*)splats, tiles_per_gauss, block_sums, viewmats_out, Ks_out)
+                       conics, opac_out, colors_out, (float4*)splats, tiles_per_gauss, block_sums, viewmats_out, Ks_out,    \
+                       sh_degree >= 0 ? sh_jac : nullptr)
     if (C == 1) QED_LAUNCH_PF(true);
     else QED_LAUNCH_PF(false);
 #undef QED_LAUNCH_PF
@@ -812,24 +899,28 @@ extern "C" int qed_project_bwd(int32_t N, int32_t C, const float* means, const f
                                int32_t width, int32_t height, float eps2d, uint32_t flags, const int32_t* radii,
                                const float* vsplat, float* v_means, float* v_quats, float* v_scales,
                                float* v_opacities, float* v_sh0, int32_t v_sh0_stride, float* v_shN,
-                               int32_t v_shN_stride, float* v_viewmats, void* stream) {
+                               int32_t v_shN_stride, float* v_viewmats, const float* sh_jac, void* stream) {
     QED_REQUIRE(N >= 0 && C >= 1, "N >= 0 and C >= 1 required");
     QED_REQUIRE(sh_degree <= 3, "SH degree > 3 unsupported");
     if (N == 0) return QED_OK;
-    QED_REQUIRE(means && quats && scales && opacities && sh0 && viewmats && Ks && radii && vsplat, "null input");
+    const bool jac = sh_jac != nullptr && sh_degree >= 0;      // (the coefficients are not read then)
+    QED_REQUIRE(means && quats && scales && opacities && (sh0 || jac) && viewmats && Ks && radii && vsplat, "null input");
     QED_REQUIRE(v_means && v_quats && v_scales && v_opacities && v_sh0, "null output");
-    QED_REQUIRE(sh_degree <= 0 || (shN && v_shN), "shN / v_shN required for sh_degree > 0");
+    QED_REQUIRE(sh_degree <= 0 || ((shN || jac) && v_shN), "shN / v_shN required for sh_degree > 0");
     const unsigned grid = (unsigned)((N + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
-#define QED_LAUNCH_BWD_(D, ONE)                                                                                    \
-    hipLaunchKernelGGL((project_bwd_kernel<D, ONE>), dim3(grid), dim3(256), 0, st, N, C, means, quats, scales,     \
+#define QED_LAUNCH_BWD_(D, ONE, J)                                                                                 \
+    hipLaunchKernelGGL((project_bwd_kernel<D, ONE, J>), dim3(grid), dim3(256), 0, st, N, C, means, quats, scales,  \
                        opacities, sh0, sh0_stride, shN, shN_stride, viewmats, Ks, width, height, eps2d, flags,     \
                        radii, (const float4*)vsplat, v_means, v_quats, v_scales, v_opacities, v_sh0, v_sh0_stride, \
-                       v_shN, v_shN_stride, v_viewmats)
-#define QED_LAUNCH_BWD(D)                \
-    do {                                 \
-        if (C == 1) QED_LAUNCH_BWD_(D, true); \
-        else QED_LAUNCH_BWD_(D, false);  \
+                       v_shN, v_shN_stride, v_viewmats, sh_jac)
+#define QED_LAUNCH_BWD(D)                                  \
+    do {                                                   \
+        if (jac && D >= 0) {                               \
+            if (C == 1) QED_LAUNCH_BWD_(D, true, (D >= 0)); \
+            else QED_LAUNCH_BWD_(D, false, (D >= 0));      \
+        } else if (C == 1) QED_LAUNCH_BWD_(D, true, false); \
+        else QED_LAUNCH_BWD_(D, false, false);             \
     } while (0)
     switch (sh_degree) {
         case 0: QED_LAUNCH_BWD(0); break;

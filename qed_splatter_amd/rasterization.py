@@ -210,15 +210,20 @@ class _ProjectSH(torch.autograd.Function):
         tiles_per_gauss = torch.empty(C, N, dtype=torch.int32, device=dev)
         n_blocks = (C * N + 255) // 256
         block_sums = torch.empty(max(n_blocks, 1), dtype=torch.int32, device=dev)
+        # what the backward pass needs of the SH part (direction Jacobian + clamp mask, 40 B per slot) instead of
+        # re-reading the 3 K coefficients and rebuilding the basis derivatives: qed_project_fwd's sh_jac
+        sh_jac = None
+        if sh_degree >= 0 and any(ctx.needs_input_grad[:7]):
+            sh_jac = torch.empty(L.SH_JAC_FLOATS, C * N, dtype=torch.float32, device=dev)
         L.check(lib.qed_project_fwd(
             N, C, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opacities), L.ptr(sh0_flat), sh0_stride,
             shN_ptr, shN_stride, sh_degree, L.ptr(cam_in[0]), L.ptr(cam_in[1]), width, height, tile_w, tile_h, eps2d,
             near_plane, far_plane, radius_clip, flags, L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics),
             L.ptr(opac), L.ptr(rgb), L.ptr(splats), L.ptr(tiles_per_gauss), L.ptr(block_sums),
-            L.ptr(viewmats) if c2w is not None else None, L.ptr(Ks) if c2w is not None else None, _stream()),
-            "qed_project_fwd")
+            L.ptr(viewmats) if c2w is not None else None, L.ptr(Ks) if c2w is not None else None, L.ptr(sh_jac),
+            _stream()), "qed_project_fwd")
         flags &= ~L.F_CAMERA_C2W                  # (the backward pass reads the view matrices the kernel wrote)
-        ctx.save_for_backward(means, quats, scales, opacities, sh0, shN, viewmats, Ks, radii)
+        ctx.save_for_backward(means, quats, scales, opacities, sh0, shN, viewmats, Ks, radii, sh_jac)
         ctx.meta = (N, C, width, height, sh_degree, flags, eps2d, sh0_stride, shN_stride)
         ctx.opac_shape = opac_shape
         ctx.mark_non_differentiable(radii, splats, tiles_per_gauss, block_sums)
@@ -227,7 +232,7 @@ class _ProjectSH(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_means2d, v_depths, v_conics, v_opac, v_rgb, *_unused):
         lib = L.load()
-        means, quats, scales, opacities, sh0, shN, viewmats, Ks, radii = ctx.saved_tensors
+        means, quats, scales, opacities, sh0, shN, viewmats, Ks, radii, sh_jac = ctx.saved_tensors
         N, C, width, height, sh_degree, flags, eps2d, sh0_stride, shN_stride = ctx.meta
         dev = means.device
         vsplat = _packed_vsplat(C, N, v_means2d, v_depths, v_conics, v_opac, v_rgb, dev)
@@ -267,7 +272,7 @@ class _ProjectSH(torch.autograd.Function):
             N, C, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opacities), L.ptr(sh0), sh0_stride, shN_ptr,
             shN_stride, sh_degree, L.ptr(viewmats), L.ptr(Ks), width, height, eps2d, flags, L.ptr(radii),
             L.ptr(vsplat), L.ptr(v_means), L.ptr(v_quats), L.ptr(v_scales), L.ptr(v_opacities), v_sh0_ptr,
-            v_sh0_stride, v_shN_ptr, v_shN_stride, L.ptr(v_viewmats), _stream()), "qed_project_bwd")
+            v_sh0_stride, v_shN_ptr, v_shN_stride, L.ptr(v_viewmats), L.ptr(sh_jac), _stream()), "qed_project_bwd")
         v_opacities = v_opacities.view(ctx.opac_shape)
         return (v_means, v_quats, v_scales, v_opacities, v_sh0, v_shN, v_viewmats, None) + (None,) * 12
 

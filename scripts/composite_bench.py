@@ -2,7 +2,7 @@
 """Median / min HIP-event time of every entry point over repeated forward+backward passes of the SAME scene (no
 optimiser step, so the workload does not drift): the A/B tool for kernel variants (QED_SPLAT_LIB=... selects one).
 
-    python scripts/composite_bench.py [iters] [gaussians width height]
+    python scripts/composite_bench.py [iters] [gaussians width height [step]]   (step < 3: SH degree = step)
 """
 import os
 import statistics
@@ -22,7 +22,7 @@ L.load()
 sc = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synthetic_scene(n, w, h, seed=1235).items()}
 model = QEDSplatterModel(QEDSplatterModelConfig.synthetic(sh_degree_interval=1), **{k: sc[k] for k in
                          ("means", "scales", "quats", "opacities", "features_dc", "features_rest")})
-model.step = 30000
+model.step = int(sys.argv[5]) if len(sys.argv) > 5 else 30000
 K = sc["Ks"][0].cpu()
 cam = PinholeCameras(sc["camera_to_worlds"], float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), w, h)
 batch = {"image": sc["gt_rgb"].contiguous(), "depth_image": sc["gt_depth"].contiguous()}
