@@ -419,7 +419,9 @@ __device__ __forceinline__ void sh_bwd(const float* __restrict__ sh0, const floa
 template <int DEG, bool STREAM>
 __device__ __forceinline__ void sh_bwd_jac(const float* __restrict__ jac /* this slot's first plane entry */, size_t plane,
                                            const float* dir, const float* v_rgb_in, float* __restrict__ o0,
-                                           float* __restrict__ oN, float* v_coef, float* v_dir /*3, +=*/, bool compact) {
+                                           float* __restrict__ oN, float* v_coef, float* v_dir /*3, +=*/, bool compact,
+                                           float* stage_b = nullptr /*LDS: this lane's basis row*/,
+                                           float* stage_v = nullptr) {
     constexpr int K = (DEG + 1) * (DEG + 1);
     float J[9];
 #pragma unroll
@@ -438,9 +440,20 @@ __device__ __forceinline__ void sh_bwd_jac(const float* __restrict__ jac /* this
         sh_basis<DEG>(x, y, z, b);
         if constexpr (STREAM) {
             o0[0] = b[0] * v[0]; o0[1] = b[0] * v[1]; o0[2] = b[0] * v[2];
+            if (stage_b != nullptr) {
+                // the 3 (K - 1) higher-order gradients leave through LDS, a wave's rows at a time (sh_grad_store_staged)
+                constexpr int KS = (K + 3) & ~3;
 #pragma unroll
-            for (int k = 1; k < K; ++k) {
-                oN[3 * (k - 1)] = b[k] * v[0]; oN[3 * (k - 1) + 1] = b[k] * v[1]; oN[3 * (k - 1) + 2] = b[k] * v[2];
+                for (int k4 = 0; k4 < KS / 4; ++k4)
+                    reinterpret_cast<float4*>(stage_b)[k4] =
+                        make_float4(b[4 * k4], 4 * k4 + 1 < K ? b[4 * k4 + 1] : 0.f, 4 * k4 + 2 < K ? b[4 * k4 + 2] : 0.f,
+                                    4 * k4 + 3 < K ? b[4 * k4 + 3] : 0.f);
+                *reinterpret_cast<float4*>(stage_v) = make_float4(v[0], v[1], v[2], 0.f);
+            } else {
+#pragma unroll
+                for (int k = 1; k < K; ++k) {
+                    oN[3 * (k - 1)] = b[k] * v[0]; oN[3 * (k - 1) + 1] = b[k] * v[1]; oN[3 * (k - 1) + 2] = b[k] * v[2];
+                }
             }
         } else {
 #pragma unroll
@@ -517,6 +530,28 @@ __device__ __forceinline__ void sh_bwd_stream(const float* __restrict__ sh0, con
     }
 }
 
+// The higher-order coefficient gradients b_k(dir) v of a wave's 64 Gaussians, written as the wave's 64 x 3 (K - 1) floats
+// in address order (rows `stride` floats apart): every lane storing its own row is 45 store instructions of 64 addresses
+// 180 B apart, 16 partial writes to every cache line spread over as many instructions; through LDS each instruction
+// covers 256 contiguous bytes.  Lanes whose Gaussian is culled (or beyond N) stage v = 0 and their rows come out as the
+// zeros the optimiser expects.  A wave reads only what its own lanes staged.
+template <int K>
+__device__ __forceinline__ void sh_grad_store_staged(const float* __restrict__ stage /* this wave's 64 (KS + 4) floats */,
+                                                     int lane, float* __restrict__ out /* row of the wave's first Gaussian */,
+                                                     int stride, int n_rows) {
+    constexpr int KS = (K + 3) & ~3, FP = 3 * (K - 1);
+    const float* sv = stage + 64 * KS;
+    int g = lane / FP, j = lane - g * FP;                        // element `lane` of the wave's 64 FP floats
+#pragma unroll 5
+    for (int it = 0; it < FP; ++it) {
+        const int k = (j * 171) >> 9;                            // j / 3 (j < 384)
+        const int ch = j - 3 * k;
+        if (g < n_rows) out[(size_t)g * stride + j] = stage[g * KS + k + 1] * sv[4 * g + ch];
+        g += 64 / FP; j += 64 % FP;
+        if (j >= FP) { j -= FP; ++g; }
+    }
+}
+
 // JAC: the SH part works from qed_project_fwd's sh_jac hand-over (sh_bwd_jac) instead of the coefficients: no basis-
 // derivative tables beside the projection state (183 registers without spills where the degree-3 kernel spills 22 of 256).
 template <int DEG, bool ONE_CAM, bool JAC = false>
@@ -545,6 +580,15 @@ project_bwd_kernel(int N, int C, const float* __restrict__ means, const float* _
 #pragma unroll
     for (int i = 0; i < (kStreamSH ? 1 : 3 * K); ++i) vcoef[i] = 0.f;
     bool sh_written = false;
+    // (hand-over kernel, one camera, all coefficient gradients wanted) they leave through LDS: sh_grad_store_staged
+    constexpr bool kStageSH = JAC && kStreamSH && K > 1;
+    constexpr int kKS = (K + 3) & ~3;
+    constexpr int kStageFloats = kStageSH ? 64 * (kKS + 4) : 1;
+    __shared__ __attribute__((aligned(16))) float s_stage[4 * kStageFloats];
+    float* const stage_wave = s_stage + (threadIdx.x >> 6) * kStageFloats;
+    const bool staged = kStageSH && !(flags & QED_F_SH_GRAD_COMPACT);
+    float* const stage_b = staged ? stage_wave + (threadIdx.x & 63) * kKS : nullptr;
+    float* const stage_v = staged ? stage_wave + 64 * kKS + 4 * (threadIdx.x & 63) : nullptr;
 
     float mean[3] = {0.f, 0.f, 0.f}, qraw[4] = {1.f, 0.f, 0.f, 0.f}, q[4], sraw[3] = {0.f, 0.f, 0.f}, s[3];
     float qin = 1.f, oraw = 0.f, oact = 0.f;
@@ -566,6 +610,13 @@ project_bwd_kernel(int N, int C, const float* __restrict__ means, const float* _
         const size_t slot = (size_t)c * N + n;
         const bool vis = active && radii[slot] > 0;
         float vR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, vt[3] = {0.f, 0.f, 0.f};
+        if constexpr (kStageSH) {
+            if (staged && !vis) {                               // culled (or beyond N): a row of zeros
+#pragma unroll
+                for (int k4 = 0; k4 < kKS / 4; ++k4) reinterpret_cast<float4*>(stage_b)[k4] = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(stage_v) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
         if (vis) {
             Proj p;
             // radius_clip / near / far already decided in the forward pass (radii > 0)
@@ -662,7 +713,7 @@ project_bwd_kernel(int N, int C, const float* __restrict__ means, const float* _
                     sh_bwd_jac<(DEG < 0 ? 0 : DEG), kStreamSH>(sh_jac + slot, plane, dir, v_rgb,
                                                                 v_sh0 + (size_t)n * v_sh0_stride,
                                                                 v_shN + (size_t)n * v_shN_stride, vcoef, vdir,
-                                                                (flags & QED_F_SH_GRAD_COMPACT) != 0);
+                                                                (flags & QED_F_SH_GRAD_COMPACT) != 0, stage_b, stage_v);
                     sh_written = true;
                 } else if constexpr (kStreamSH) {
                     sh_bwd_stream<(DEG < 0 ? 0 : DEG)>(sh0 + (size_t)n * sh0_stride, shN + (size_t)n * shN_stride, dir,
@@ -732,6 +783,16 @@ project_bwd_kernel(int N, int C, const float* __restrict__ means, const float* _
                 }
             }
         }
+        if constexpr (kStageSH) {
+            if (staged) {                                       // (uniform over the launch)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int n0 = blockIdx.x * 256 + (threadIdx.x & ~63);
+                sh_grad_store_staged<K>(stage_wave, threadIdx.x & 63, v_shN + (size_t)n0 * v_shN_stride, v_shN_stride,
+                                        N - n0);
+            }
+        }
         if (v_viewmats != nullptr) {
             // block reduction -> 12 atomics per block per camera
 #pragma unroll
@@ -760,7 +821,7 @@ project_bwd_kernel(int N, int C, const float* __restrict__ means, const float* _
     if constexpr (kStreamSH) {
         if (!sh_written) {                              // not visible: zero gradient
             o0[0] = 0.f; o0[1] = 0.f; o0[2] = 0.f;
-            if (K > 1 && !(flags & QED_F_SH_GRAD_COMPACT)) {
+            if (K > 1 && !(flags & QED_F_SH_GRAD_COMPACT) && !staged) {
                 float* oN = v_shN + (size_t)n * v_shN_stride;
 #pragma unroll
                 for (int i = 0; i < 3 * (K - 1); ++i) oN[i] = 0.f;
