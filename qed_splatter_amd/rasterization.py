@@ -151,6 +151,10 @@ class _Workspace:
 
 _WORKSPACES: Dict[int, _Workspace] = {}
 
+# qed_project_fwd's sh_jac hand-over to qed_project_bwd (tests switch it off to keep the coefficient-reading backward
+# kernels, which direct C-ABI callers without the planes still get, under the same parity checks)
+SH_HANDOVER = True
+
 
 def _workspace(device) -> _Workspace:
     idx = device.index if device.index is not None else torch.cuda.current_device()
@@ -213,7 +217,7 @@ class _ProjectSH(torch.autograd.Function):
         # what the backward pass needs of the SH part (direction Jacobian + clamp mask, 40 B per slot) instead of
         # re-reading the 3 K coefficients and rebuilding the basis derivatives: qed_project_fwd's sh_jac
         sh_jac = None
-        if sh_degree >= 0 and any(ctx.needs_input_grad[:7]):
+        if SH_HANDOVER and sh_degree >= 0 and any(ctx.needs_input_grad[:7]):
             sh_jac = torch.empty(L.SH_JAC_FLOATS, C * N, dtype=torch.float32, device=dev)
         L.check(lib.qed_project_fwd(
             N, C, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opacities), L.ptr(sh0_flat), sh0_stride,

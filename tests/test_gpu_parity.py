@@ -389,6 +389,31 @@ def test_projection_sh_backward(cuda, mode, deg):
         assert_close(got, ad[name].grad, tol, f"v_{name} ({mode}, deg={deg})")
 
 
+@pytest.mark.parametrize("deg", [3, 1])
+@pytest.mark.parametrize("n_cam", [1, 2])
+def test_project_bwd_without_handover_matches(cuda, deg, n_cam, monkeypatch):
+    """qed_project_bwd with the forward pass's sh_jac planes (what every other test runs) against the kernels that re-read
+    the SH coefficients (sh_jac = NULL: what a direct C-ABI caller without the planes gets): same gradients, and the same
+    forward outputs bit for bit."""
+    from qed_splatter_amd import rasterization as R
+    w, h, n = 200, 136, 3000
+    sc = scene(n, w, h, seed=23, n_cameras=n_cam)
+    g = torch.Generator().manual_seed(4)
+    ups = dict(means2d=torch.randn(n_cam, n, 2, generator=g), depths=torch.randn(n_cam, n, generator=g),
+               conics=torch.randn(n_cam, n, 3, generator=g) * 1e-2, opacities=torch.randn(n_cam, n, generator=g),
+               colors=torch.randn(n_cam, n, 3, generator=g))
+    out = []
+    for handover in (True, False):
+        monkeypatch.setattr(R, "SH_HANDOVER", handover)
+        a, render, alpha, info = _raster_gpu(sc, cuda, w, h, sh_degree=deg, grad=True)
+        loss = sum((info[k] * v.to(cuda)).sum() for k, v in ups.items())
+        grads = torch.autograd.grad(loss, [a["means"], a["quats"], a["scales"], a["opacities"], a["colors"]])
+        out.append((render.detach(), info["colors"].detach(), grads))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    for g1, g0, name in zip(out[0][2], out[1][2], ("means", "quats", "scales", "opacities", "colors")):
+        assert_close(g1, g0.double().cpu(), 2e-6, f"v_{name} with / without the hand-over (deg={deg}, C={n_cam})")
+
+
 def test_viewmat_gradient(cuda):
     """Camera-optimiser path (model.py:212): d loss / d viewmats."""
     w, h, n = 96, 64, 1500
