@@ -681,6 +681,21 @@ def test_empty_and_degenerate_inputs(cuda):
     render, alpha, info = rasterization(**a, width=w, height=h, render_mode="RGB+D", sh_degree=3, absgrad=True)
     assert info["n_isects"] == 0 and float(render.abs().max()) == 0.0 and float(alpha.max()) == 0.0
     assert int(info["radii"].max()) == 0
+    # the same frame with the count left on the device (it arrives through qed_bin_tiles' host_words, one call late), and
+    # no Gaussians at all: the words still arrive (M = 0), nothing overflows, the next synchronous call is unaffected
+    from qed_splatter_amd.rasterization import _workspace
+    ws = _workspace(cuda)
+    for _ in range(2):
+        r2, a2, i2 = rasterization(**a, width=w, height=h, render_mode="RGB+D", sh_degree=3, absgrad=True, _sync=False)
+        assert i2["n_isects"] is None and float(r2.abs().max()) == 0.0
+    ws.poll_pending()
+    assert ws.pending is None and ws.overflows == 0
+    e = {k: (v[:0] if torch.is_tensor(v) and v.shape[:1] == (64,) else v) for k, v in a.items()}
+    for sync in (True, False, False):
+        r0, a0, i0 = rasterization(**e, width=w, height=h, render_mode="RGB+D", sh_degree=3, _sync=sync)
+        assert float(r0.abs().max()) == 0.0 and float(a0.max()) == 0.0
+    ws.poll_pending()
+    assert ws.pending is None and ws.overflows == 0
     # loss on an empty render: depth loss falls back to 0-valid handling (model.py:111-114)
     m, cam, batch = _model(sc, cuda)
     batch["depth_image"] = torch.zeros_like(batch["depth_image"])        # no valid ground truth
