@@ -208,7 +208,7 @@ __device__ __forceinline__ void fwd_quadrant(f2 pq, f2 XY, f2 AC, float B, float
     const u64 m_term = m_ok & __ballot(nT <= kTMin);
     done |= m_term;
     const u64 m_acc = m_ok & ~m_term;
-    QED_STAT(5, __builtin_popcountll(m_acc));
+    QED_STAT(5, __builtin_popcountll(m_acc)); QED_STAT(6, m_acc == 0 ? 1 : 0);
     const float w = sel(m_acc, at, 0.f);
     const f2 ww = {w, w};
     s.out01 += col01 * ww;
@@ -484,7 +484,7 @@ __device__ __forceinline__ void bwd_quadrant(f2 pq, f2 XY, f2 AC, float B, float
     const float a = fminf(kAlphaMax, opv);
     const u64 m_valid = __ballot(s.bin_final >= idx) & __ballot(p <= 0.f) & __ballot(a >= kAlphaMin);
     any_valid |= m_valid;
-    QED_STAT(14, __builtin_popcountll(m_valid));
+    QED_STAT(14, __builtin_popcountll(m_valid)); QED_STAT(15, m_valid == 0 ? 1 : 0);
     // branch-free: an invalid pixel contributes zeros and keeps its state
     const float ra = __builtin_amdgcn_rcpf(1.f - a);
     const float Tn = sel(m_valid, s.T * ra, s.T);

@@ -40,9 +40,9 @@ s = list(buf)
 M = int(model.info["n_isects"])
 print(f"N={n} {w}x{h} M={M} tiles={((w + 15) // 16) * ((h + 15) // 16)}")
 names = {0: "fwd batches", 1: "fwd entries staged", 2: "fwd entries surviving the cull (any quadrant)", 3: "fwd quadrant visits",
-         4: "fwd Gaussians visited", 5: "fwd accepted (pixel, Gaussian) pairs", 8: "bwd batches", 9: "bwd entries staged", 10: "bwd entries surviving the cull",
+         4: "fwd Gaussians visited", 5: "fwd accepted (pixel, Gaussian) pairs", 6: "fwd quadrant visits that accept no pixel", 8: "bwd batches", 9: "bwd entries staged", 10: "bwd entries surviving the cull",
          11: "bwd quadrant visits", 12: "bwd reductions (Gaussians with a valid pixel)", 13: "bwd flush groups (<= 4 rows each)",
-         14: "bwd valid (pixel, Gaussian) pairs", 16: "bwd whole-tile waves with work", 17: "bwd quadrant waves with work"}
+         14: "bwd valid (pixel, Gaussian) pairs", 15: "bwd quadrant visits without a valid pixel", 16: "bwd whole-tile waves with work", 17: "bwd quadrant waves with work"}
 for i, nm in names.items():
     print(f"  {nm:52s} {s[i]:12d}")
 if s[12]:
