@@ -255,7 +255,21 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # QED_BENCH_RCCL_SELF=1 (one rank only): the N > 1 path -- split graphs, the compact exchange overlapped with the
+    # optimiser, barriers, rank agreement -- through the real `nccl` (= RCCL) backend in a process group of ONE rank: what
+    # a one-GPU box can drive of it (the collectives are issued and waited for; there is no peer, so nothing is measured)
+    rccl_self = world == 1 and os.environ.get("QED_BENCH_RCCL_SELF") == "1"
+    if rccl_self:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            free_port = s.getsockname()[1]
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    multi = world > 1 or rccl_self
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         from datetime import timedelta
@@ -274,7 +288,9 @@ def main():
 
     from qed_splatter_amd import _lib as L
     from qed_splatter_amd.model import FlatAdam, PinholeCameras, QEDSplatterModel, QEDSplatterModelConfig
+    from qed_splatter_amd import parallel as P
     from qed_splatter_amd.parallel import allreduce_flat_grad, exchange_grads_compact_begin
+    P.FORCE_COLLECTIVES = rccl_self
     L.load()
 
     n, w, h = args.gaussians, args.width, args.height
@@ -327,7 +343,7 @@ def main():
             p.grad = None
         losses = model.fused_loss(cam, batch, background=bg, sync=sync, compact_sh_grad=dp_compact)
         model.backward_fused(losses)
-        if world > 1:
+        if multi:
             exchange_and_step(lambda: opt.step(fused_sh=True, part=1), lambda: opt.step(fused_sh=True, part=2),
                               lambda: opt.step(fused_sh=fused_sh))
         else:
@@ -390,7 +406,7 @@ def main():
     # flat gradient is issued between them (a collective is not captured: it stays an ordinary call on
     # the process group's stream).
     use_graph = args.graph if args.graph is not None else True
-    split = use_graph and (world > 1 or args.graph_split)
+    split = use_graph and (multi or args.graph_split)
     run = lambda: step(args.sync_m)
     dispatch = "eager"
     if use_graph:
@@ -429,7 +445,7 @@ def main():
                 g_fb = GraphedTrainStep(fwd_bwd, dev, warmup=3, check_every=0)
                 g_fb.replay()                          # fills the captured (static) .grad buffers before Adam's
                 graphed = g_fb                         # warm-up run reads them; keep the replicas identical
-                if world > 1 and dp_compact:
+                if multi and dp_compact:
                     ex = exchange_grads_compact_begin(model, world)
                     ex.wait_views()
                     ex.wait_geometry()
@@ -442,13 +458,13 @@ def main():
                     dispatch = ("three hipGraphs (fwd+bwd | Adam SH groups | Adam leading groups): all-gather, SH groups "
                                 "behind it while the geometry all-reduce is on the links, leading groups")
                 else:
-                    if world > 1:
+                    if multi:
                         allreduce_flat_grad(model, world)
                     g_adam = GraphedTrainStep(adam_only, dev, warmup=1, check_every=0)
 
                     def run():
                         g_fb.replay()
-                        if world > 1:
+                        if multi:
                             allreduce_flat_grad(model, world)
                         g_adam.replay()
                     dispatch = "two hipGraphs (fwd+bwd | Adam) around the gradient all-reduce"
@@ -573,7 +589,8 @@ def main():
                        "width": w, "height": h,
                        "parallelism": (f"dp{world} (camera-sharded; " + ("geometry all-reduce + all-gather of per-view colour gradients"
                                                                     if dp_compact else "flat-gradient all-reduce") + ")")
-                       if world > 1 else "single",
+                       if world > 1 else ("single (QED_BENCH_RCCL_SELF: the N > 1 exchange path through RCCL in a group of one rank)"
+                                          if rccl_self else "single"),
                        "async_intersection_count": not args.sync_m,
                        "dispatch": dispatch},
             "msplats_per_s": n_vis * world / (dt2 / args.steps) / 1e6,

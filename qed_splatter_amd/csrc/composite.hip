@@ -485,11 +485,14 @@ __device__ __forceinline__ void bwd_quadrant(f2 pq, f2 XY, f2 AC, float B, float
     const u64 m_valid = __ballot(s.bin_final >= idx) & __ballot(p <= 0.f) & __ballot(a >= kAlphaMin);
     any_valid |= m_valid;
     QED_STAT(14, __builtin_popcountll(m_valid)); QED_STAT(15, m_valid == 0 ? 1 : 0);
-    // branch-free: an invalid pixel contributes zeros and keeps its state
-    const float ra = __builtin_amdgcn_rcpf(1.f - a);
-    const float Tn = sel(m_valid, s.T * ra, s.T);
+    // branch-free: an invalid pixel contributes zeros and keeps its state -- through ONE select: with alpha = 0 the
+    // reciprocal is v_rcp_f32(1.0) = 1.0 exactly (scripts/ubench/rcp_one.hip checks it on the device), so T * 1 is T bit
+    // for bit and the weight is 0 * T = 0
+    const float a_eff = sel(m_valid, a, 0.f);
+    const float ra = __builtin_amdgcn_rcpf(1.f - a_eff);
+    const float Tn = s.T * ra;
     s.T = Tn;
-    const float fac = sel(m_valid, a * Tn, 0.f);
+    const float fac = a_eff * Tn;
     const f2 ff = {fac, fac};
     f2 cvv = col01 * s.vr01;
     if constexpr (CH == 4) cvv += col23 * s.vr23;

@@ -9,6 +9,15 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
+# Rehearsal hook (bench.py QED_BENCH_RCCL_SELF=1, tests): issue the collectives even in a process group of ONE rank, so
+# that a one-GPU box drives the real RCCL calls (AVG all-reduce, all_gather_into_tensor, async works waited on the
+# compute stream) of the N > 1 path.  Off in production: a single rank has nothing to exchange.
+FORCE_COLLECTIVES = False
+
+
+def _single(world_size: int) -> bool:
+    return world_size <= 1 and not FORCE_COLLECTIVES
+
 
 def allreduce_flat_grad(model, world_size: int, group=None) -> torch.Tensor:
     """Average the model's six parameter gradients across ranks with a single all-reduce.
@@ -20,13 +29,13 @@ def allreduce_flat_grad(model, world_size: int, group=None) -> torch.Tensor:
     if g is None:
         raise RuntimeError("no gradients to reduce: call backward() first")
     _refuse_compact(model, "allreduce_flat_grad")
-    if world_size <= 1:
+    if _single(world_size):
         return g
     if dist.get_backend(group) == "nccl":
         dist.all_reduce(g, op=dist.ReduceOp.AVG, group=group)      # ncclAvg: no extra scaling pass
     else:                                                            # gloo (CPU tests) has no AVG
         dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
-        g.mul_(1.0 / world_size)
+        g.mul_(1.0 / max(world_size, 1))
     return g
 
 
@@ -72,13 +81,13 @@ def exchange_grads_compact(model, world_size: int, group=None, views=None, rebui
         for c, (v, m) in enumerate(views):
             recv[c, :nv] = v.reshape(-1)
             recv[c, nv:] = m.reshape(-1)
-    elif world_size > 1:
-        n_views = world_size
+    elif not _single(world_size):
+        n_views = max(world_size, 1)
         if dist.get_backend(group) == "nccl":
             dist.all_reduce(geo, op=dist.ReduceOp.AVG, group=group)
         else:
             dist.all_reduce(geo, op=dist.ReduceOp.SUM, group=group)
-            geo.mul_(1.0 / world_size)
+            geo.mul_(1.0 / n_views)
         recv = bufs[1]
         if dist.get_backend(group) == "nccl":
             dist.all_gather_into_tensor(recv.view(-1), send, group=group)
@@ -137,7 +146,7 @@ def exchange_grads_compact_begin(model, world_size: int, group=None) -> CompactE
     if not getattr(model, "last_compact", False):
         raise RuntimeError("exchange_grads_compact_begin needs gradients from fused_loss(..., compact_sh_grad=True)")
     geo, send, recv, nv, row = _compact_buffers(model, g, max(world_size, 1))
-    if world_size <= 1:
+    if _single(world_size):
         model.sh_views = (1, send[nv:].view(1, 16), row, send.view(1, row), row, 1.0)
         return CompactExchange(None, None, geo, 1.0)
     nccl = dist.get_backend(group) == "nccl"
@@ -147,8 +156,9 @@ def exchange_grads_compact_begin(model, world_size: int, group=None) -> CompactE
     else:                                                         # gloo (rehearsal / CPU tests)
         w_gather = dist.all_gather(list(recv.unbind(0)), send, group=group, async_op=True)
         w_reduce = dist.all_reduce(geo, op=dist.ReduceOp.SUM, group=group, async_op=True)
-    model.sh_views = (world_size, recv[:, nv:], row, recv, row, 1.0 / world_size)
-    return CompactExchange(w_gather, w_reduce, geo, 1.0 if nccl else 1.0 / world_size)
+    n_views = max(world_size, 1)
+    model.sh_views = (n_views, recv[:, nv:], row, recv, row, 1.0 / n_views)
+    return CompactExchange(w_gather, w_reduce, geo, 1.0 if nccl else 1.0 / n_views)
 
 
 def _compact_buffers(model, g, n_rows: int):
@@ -186,7 +196,7 @@ def allreduce_and_step(model, optimizer, world_size: int, n_chunks: int = 4, gro
         raise RuntimeError("no gradients to reduce: call backward() first")
     _refuse_compact(model, "allreduce_and_step")
     total = g.numel()
-    if world_size <= 1:
+    if _single(world_size):
         optimizer.begin_step()
         optimizer.step_range(0, total)
         return
@@ -199,7 +209,7 @@ def allreduce_and_step(model, optimizer, world_size: int, n_chunks: int = 4, gro
     for w, a, b in zip(works, bounds[:-1], bounds[1:]):
         w.wait()                                   # the current stream waits for this piece only
         if not avg:
-            g[a:b].mul_(1.0 / world_size)
+            g[a:b].mul_(1.0 / max(world_size, 1))
         optimizer.step_range(a, b)
 
 

@@ -32,6 +32,35 @@ def test_bench_two_rank_rehearsal_prints_the_contract_line(cuda):
     assert out["value"] == pytest.approx(2 * 3 / (out["ms_per_step"] * 3e-3), rel=1e-6)      # whole-job camera-steps / s
 
 
+@pytest.mark.gpu
+def test_bench_exchange_path_through_rccl_in_a_group_of_one(cuda):
+    """What a one-GPU box can drive of the N > 1 path through the REAL transport: QED_BENCH_RCCL_SELF=1 initialises the `nccl`
+    (= RCCL) backend with one rank and sends every step through the split graphs and the compact exchange -- the AVG
+    all-reduce of the geometry gradients, all_gather_into_tensor of the colour-gradient message, both asynchronous and
+    waited for on the compute stream between graph replays, the barriers and the rank agreement.  With one rank the
+    exchange is the identity, so the step must train exactly as the single-GPU step does."""
+    env = dict(os.environ, QED_BENCH_RCCL_SELF="1", QED_BENCH_COLLECTIVE_TIMEOUT="120")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "QED_BENCH_REHEARSE"):
+        env.pop(k, None)
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+            "--no-cpu-baseline", "--no-api-path", "--gaussians", "100000", "--width", "960", "--height", "540"]
+    outs = []
+    for e in (env, {k: v for k, v in env.items() if k != "QED_BENCH_RCCL_SELF"}):
+        p = subprocess.run(base, env=e, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-4000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, p.stdout[-2000:]
+        outs.append((json.loads(lines[0]), p.stderr))
+    (o_self, err_self), (o_single, _) = outs
+    assert "three hipGraphs" in o_self["config"]["dispatch"], err_self[-2000:]      # the N > 1 dispatch, captured
+    assert "RCCL" in o_self["config"]["parallelism"] and o_single["config"]["parallelism"] == "single"
+    assert o_self["n_gpus"] == 1 and o_self["value"] > 0
+    # the same training: the list length after the timed steps is a fingerprint of the parameters
+    assert o_self["config"]["intersections"] == o_single["config"]["intersections"]
+    a, b = o_self["config"]["intersections_after_timed_steps"], o_single["config"]["intersections_after_timed_steps"]
+    assert abs(a - b) <= 2e-3 * b, (a, b)
+
+
 def test_launcher_enforces_its_wall_limit_and_reaps_its_children(tmp_path):
     """launch_ranks() must not wait for a wedged rank until the driver's own limit: the process group it started is
     terminated at the wall limit and the exit status is non-zero.  (CPU: the 'ranks' here are a stand-in that sleeps.)"""
