@@ -36,6 +36,7 @@ rng = np.random.default_rng(0)
 sample = rng.choice(vis, size=20000, replace=False)
 TW, TH = (w + 15) // 16, (h + 15) // 16
 tot_a = tot_b = tot_c = 0
+per = []                                   # (tiles of (b), of those surviving the exact test) per sampled Gaussian
 for i in sample:
     x, y, r = m2[i, 0], m2[i, 1], float(rad[i])
     a, b, c = con[i]
@@ -50,13 +51,17 @@ for i in sample:
     ex, ey = np.sqrt(2 * tau * c / det), np.sqrt(2 * tau * a / det)      # half extents of sigma <= tau
     bx0, bx1 = max(x0, int(np.floor((x - ex) / 16))), min(x1, int(np.ceil((x + ex) / 16)))
     by0, by1 = max(y0, int(np.floor((y - ey) / 16))), min(y1, int(np.ceil((y + ey) / 16)))
-    tot_b += max(bx1 - bx0, 0) * max(by1 - by0, 0)
+    nb_ = max(bx1 - bx0, 0) * max(by1 - by0, 0)
+    tot_b += nb_
+    nc_ = 0
     # exact per tile: min of sigma over the pixel-centre rectangle [16tx+.5, 16tx+15.5] x [...]
     for ty in range(y0, y1):
         for tx in range(x0, x1):
             lx, hx, ly, hy = 16 * tx + 0.5, 16 * tx + 15.5, 16 * ty + 0.5, 16 * ty + 15.5
+            in_b = bx0 <= tx < bx1 and by0 <= ty < by1
             if lx <= x <= hx and ly <= y <= hy:
                 tot_c += 1
+                nc_ += in_b
                 continue
             best = np.inf
             for (fx, lo, hi, isx) in ((lx, ly, hy, True), (hx, ly, hy, True), (ly, lx, hx, False), (hy, lx, hx, False)):
@@ -73,5 +78,18 @@ for i in sample:
                 best = min(best, 0.5 * (a * dx * dx + c * dy * dy) + b * dx * dy)
             if best <= tau:
                 tot_c += 1
+                nc_ += in_b
+    per.append((nb_, nc_))
 print(f"sample {len(sample)}: 3-sigma square {tot_a} ({tot_a / len(sample):.2f}/Gaussian), + alpha bbox {tot_b} "
       f"({100 * tot_b / tot_a:.1f} %), exact per-tile test {tot_c} ({100 * tot_c / tot_a:.1f} %)")
+per = np.array(per)
+edges = [0, 1, 2, 4, 8, 16, 32, 64, 10 ** 9]
+print("tiles of the alpha bbox per Gaussian -> share of the list, survivors of the exact test")
+for lo, hi in zip(edges[:-1], edges[1:]):
+    m = (per[:, 0] > lo) & (per[:, 0] <= hi)
+    if m.any():
+        print(f"  {lo + 1:>3}..{hi if hi < 10 ** 9 else 'inf':>3}: {m.sum():6d} Gaussians, {per[m, 0].sum():7d} entries "
+              f"({100 * per[m, 0].sum() / per[:, 0].sum():5.1f} %), exact {per[m, 1].sum():7d} ({100 * per[m, 1].sum() / max(per[m, 0].sum(), 1):5.1f} %)")
+w = per[: len(per) // 64 * 64, 0].reshape(-1, 64)
+print(f"per 64 Gaussians: mean candidates {w.sum(1).mean():.0f}, largest single rectangle mean {w.max(1).mean():.1f}, "
+      f"largest capped at 64 mean {np.minimum(w, 64).max(1).mean():.1f}")
