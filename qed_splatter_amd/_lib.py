@@ -27,7 +27,7 @@ SIGNATURES = {
     "qed_last_error": (C.c_char_p, []),
     "qed_camera_setup": (C.c_int, [_I, _P, _P, _P, _P, _P]),
     "qed_project_fwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _F, _F, _F,
-                                  _F, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+                                  _F, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qed_project_bwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _I, _I, _F, _U, _P, _P, _P,
                                   _P, _P, _P, _P, _I, _P, _I, _P, _P, _P]),
     "qed_isect_scan": (C.c_int, [_P, _I, _P, _P, _L, _P, _P]),
@@ -36,7 +36,7 @@ SIGNATURES = {
     "qed_sort_pairs": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P, _L, _P, _P]),
     "qed_tile_offsets": (C.c_int, [_P, _P, _L, _I, _I, _I, _P, _P]),
     "qed_bin_workspace_bytes": (_L, [_L, _L]),
-    "qed_bin_tiles": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P]),
+    "qed_bin_tiles": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P]),
     "qed_composite_fwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "qed_composite_bwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "qed_loss_reduce": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),

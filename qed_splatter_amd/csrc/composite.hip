@@ -87,37 +87,8 @@ __device__ __forceinline__ int sel(u64 m, int a, int b) {
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(a), "s"(m));
     return d;
 }
-// ---- exact-conservative culling of (Gaussian, 8x8 quadrant) pairs -----------------------------------------------
-// alpha >= 1/255  <=>  sigma(d) = (a dx^2 + c dy^2)/2 + b dx dy <= tau = ln(255 o).  sigma is convex, so over the
-// rectangle of a quadrant's pixel centres its minimum is 0 if the mean lies inside and otherwise sits on one of the
-// four edges; along an edge it is a 1-D quadratic whose minimiser is clamped to the edge (v_med3).  A pair whose
-// minimum exceeds tau by more than the rounding margin is one every pixel would have skipped.
-//
-// sigma minimised over t in [lo, hi] on the line where the other coordinate is fixed:
-//   h = (own diagonal term)/2 * fixed^2,  bb = b * fixed,  s = -bb / (other diagonal term),  ho = (other term)/2
-__device__ __forceinline__ float edge_min(float h, float bb, float s, float ho, float lo, float hi) {
-    const float t = __builtin_amdgcn_fmed3f(s, lo, hi);
-    return __builtin_fmaf(t, __builtin_fmaf(ho, t, bb), h);
-}
-
-// Everything a lane needs about its staged Gaussian to test rectangles of the tile at pixel origin (ox, oy).
-// ia, ic = 1/a, 1/c to within an ulp (v_rcp_f32): they only place the point on an edge at which sigma is
-// evaluated, and a point off the minimiser by one part in 1e7 raises the value by one part in 1e14 -- the margin
-// is eleven orders of magnitude wider.  The margin uses the tile's extent for all four quadrants.
-struct CullGauss {
-    float b, ha, hc, ia, ic, X0, Y0, thr;
-};
-__device__ __forceinline__ CullGauss cull_setup(const float4& r0, const float4& r1, float tau, float ox, float oy) {
-    CullGauss g;
-    const float a = r0.z, c = r1.x;
-    g.b = r0.w; g.ha = 0.5f * a; g.hc = 0.5f * c;
-    g.ia = __builtin_amdgcn_rcpf(a); g.ic = __builtin_amdgcn_rcpf(c);
-    g.X0 = ox + 0.5f - r0.x; g.Y0 = oy + 0.5f - r0.y;
-    const float ax = fmaxf(fabsf(g.X0), fabsf(g.X0 + 15.f)), ay = fmaxf(fabsf(g.Y0), fabsf(g.Y0 + 15.f));
-    const float scale = a * ax * ax + c * ay * ay + fabsf(g.b) * ax * ay;
-    g.thr = tau + 1e-3f + 8e-6f * scale;
-    return g;
-}
+// (exact-conservative culling of (Gaussian, rectangle) pairs: edge_min / CullGauss / cull_setup live in qed_common.h --
+// the projection kernel applies the same test to whole tiles when it builds the tight lists)
 // quadrant (i, j) = (right half, lower half).  The per-line terms of the four x- and four y-values of a tile are
 // common subexpressions of the four quadrants' tests (two quadrants share each line).
 __device__ __forceinline__ bool quadrant_may_touch(const CullGauss& g, int i, int j) {

@@ -63,9 +63,10 @@ isect_emit_kernel(int N, int C, const float* __restrict__ means2d, const int* __
                   const int* __restrict__ block_offsets, int tile_w, int tile_h, int tile_bits,
                   int* __restrict__ n_isect, const int* __restrict__ order, KeyT* __restrict__ keys,
                   int* __restrict__ vals, const float* __restrict__ splats, long long capacity,
-                  int* __restrict__ status) {
+                  int* __restrict__ status, const unsigned long long* __restrict__ tile_masks = nullptr) {
     __shared__ int s_pref[4][65];   // per wave: exclusive prefix of counts (+ total)
     __shared__ int s_x0[4][64], s_y0[4][64], s_w[4][64];
+    __shared__ unsigned long long s_mask[4][64];   // qed_project_fwd's tile_masks: which tiles of the rectangle are listed
     __shared__ unsigned s_depth[4][64];
     __shared__ int s_slot[4][64];
     __shared__ int s_wave_tot[4];
@@ -110,7 +111,9 @@ isect_emit_kernel(int N, int C, const float* __restrict__ means2d, const int* __
     if (order != nullptr && pos < total) slot = order[pos];
     int cnt = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0;
     unsigned dbits = 0;
+    unsigned long long tmask = ~0ull;
     if (pos < total) {
+        if (tile_masks != nullptr) tmask = tile_masks[slot];        // (a third gather beside the two below)
         if (splats != nullptr) {
             // the rectangle project_fwd counted (QED_F_TIGHT_TILES or not), packed in record slot 11.  Fetched
             // beside the count, not behind it: both gathers depend on `slot` only (a rectangle read under
@@ -138,6 +141,7 @@ isect_emit_kernel(int N, int C, const float* __restrict__ means2d, const int* __
     if (lane == 63) { s_pref[wid][64] = x; s_wave_tot[wid] = x; }
     s_x0[wid][lane] = x0; s_y0[wid][lane] = y0; s_w[wid][lane] = x1 - x0; s_depth[wid][lane] = dbits;
     s_slot[wid][lane] = (int)slot;
+    s_mask[wid][lane] = tmask;
     __syncthreads();
     int wave_base = block_base;
     for (int w = 0; w < wid; ++w) wave_base += s_wave_tot[w];
@@ -151,7 +155,11 @@ isect_emit_kernel(int N, int C, const float* __restrict__ means2d, const int* __
             if (s_pref[wid][mid] <= j) lo = mid; else hi = mid - 1;
         }
         const int g = lo;
-        const int local = j - s_pref[wid][g];
+        int local = j - s_pref[wid][g];
+        // exact tile lists: the entry is the local-th LISTED tile of the rectangle (mask ~0: every tile is listed, and
+        // the rectangle may hold more than 64)
+        const unsigned long long tm = s_mask[wid][g];
+        if (tm != ~0ull) local = nth_set_bit(tm, local);
         const int w = s_w[wid][g];
         const int ty = s_y0[wid][g] + local / w;
         const int tx = s_x0[wid][g] + local % w;
@@ -683,12 +691,14 @@ extern "C" int64_t qed_bin_workspace_bytes(int64_t n_slots, int64_t capacity) {
 }
 
 extern "C" int qed_bin_tiles(int32_t N, int32_t C, const float* means2d, const int32_t* radii, const float* depths,
-                             const int32_t* tiles_per_gauss, const float* splats, const int32_t* block_sums_in,
-                             int32_t tile_w, int32_t tile_h, int64_t capacity, int32_t mode, int32_t* flatten_ids,
+                             const int32_t* tiles_per_gauss, const float* splats, const uint64_t* tile_masks,
+                             const int32_t* block_sums_in, int32_t tile_w, int32_t tile_h, int64_t capacity,
+                             int32_t mode, int32_t* flatten_ids,
                              int32_t* offsets, int32_t* n_isect, uint64_t* isect_ids, void* workspace,
                              int64_t workspace_bytes, int32_t* status, int32_t* host_words, void* stream) {
     QED_REQUIRE(N >= 0 && C >= 1 && tile_w > 0 && tile_h > 0, "bad extents");
     QED_REQUIRE(splats == nullptr || (tile_w <= 1023 && tile_h <= 2047), "packed tile rectangles need tile_w <= 1023");
+    QED_REQUIRE(tile_masks == nullptr || splats != nullptr, "tile_masks index the rectangles of the splat records");
     QED_REQUIRE(capacity >= 0 && capacity < (1ll << 30), "capacity out of range");
     QED_REQUIRE(offsets && n_isect && status && workspace, "null buffers");
     QED_REQUIRE(((uintptr_t)host_words & 15) == 0, "host_words must be 16-byte aligned");
@@ -733,13 +743,13 @@ extern "C" int qed_bin_tiles(int32_t N, int32_t C, const float* means2d, const i
         if (gridS <= kSelfScanMaxBlocks) {
             hipLaunchKernelGGL((isect_emit_kernel<unsigned, true>), dim3(gridS), dim3(256), 0, st, N, C, means2d, radii,
                                depths, tiles_per_gauss, bsums, tile_w, tile_h, tile_bits, n_isect, order, kB0, vals_out,
-                               splats, (long long)capacity, status);
+                               splats, (long long)capacity, status, (const unsigned long long*)tile_masks);
         } else {
             hipLaunchKernelGGL(isect_scan_kernel, dim3(1), dim3(1024), 0, st, bsums, (int)gridS, block_offsets, n_isect,
                                (long long)capacity, status);
             hipLaunchKernelGGL((isect_emit_kernel<unsigned, false>), dim3(gridS), dim3(256), 0, st, N, C, means2d, radii,
                                depths, tiles_per_gauss, (const int*)block_offsets, tile_w, tile_h, tile_bits, n_isect, order,
-                               kB0, vals_out, splats, (long long)capacity, status);
+                               kB0, vals_out, splats, (long long)capacity, status, (const unsigned long long*)tile_masks);
         }
     };
     // Which pipeline: sorting every tile's run by depth costs time in proportion to the list and runs in LDS only

@@ -283,11 +283,15 @@ project_fwd_kernel(int N, int C, const float* __restrict__ means, const float* _
                    float* __restrict__ depths, float* __restrict__ conics, float* __restrict__ opac_out,
                    float* __restrict__ colors_out, float4* __restrict__ splats, int* __restrict__ tiles_per_gauss,
                    int* __restrict__ block_sums, float* __restrict__ viewmats_out, float* __restrict__ Ks_out,
-                   float* __restrict__ sh_jac) {
+                   float* __restrict__ sh_jac, unsigned long long* __restrict__ tile_masks) {
     // slot = c * N + n ; 256 consecutive slots per block (block_sums granularity)
     const long long slot = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long total = (long long)C * N;
     int ntiles = 0;
+    // what the exact per-tile test below needs of this thread's Gaussian (tile_masks)
+    float4 m_c0 = make_float4(0.f, 0.f, 1.f, 0.f);
+    float m_cc = 1.f, m_tau = 0.f;
+    unsigned m_rect = 0;
     if (slot < total) {
         const int c = ONE_CAM ? 0 : (int)(slot / N);
         const int n = (int)(slot - (long long)c * N);
@@ -345,6 +349,7 @@ project_fwd_kernel(int N, int C, const float* __restrict__ means, const float* _
             if (flags & QED_F_TIGHT_TILES) tight_tile_rect(mx, my, p.radius, ca, cb, cc, tau, tile_w, tile_h, x0, y0, x1, y1);
             else tile_rect(mx, my, p.radius, tile_w, tile_h, x0, y0, x1, y1);
             ntiles = (x1 - x0) * (y1 - y0);
+            m_c0 = make_float4(mx, my, ca, cb); m_cc = cc; m_tau = tau; m_rect = pack_tile_rect(x0, y0, x1);
             r0 = make_float4(mx, my, ca, cb);
             r1 = make_float4(cc, op, rgb[0], rgb[1]);
             r2 = make_float4(rgb[2], (flags & QED_F_DEPTH_CHANNEL) ? z : 0.f, tau,
@@ -357,8 +362,64 @@ project_fwd_kernel(int N, int C, const float* __restrict__ means, const float* _
         opac_out[slot] = op;
         colors_out[3 * slot] = rgb[0]; colors_out[3 * slot + 1] = rgb[1]; colors_out[3 * slot + 2] = rgb[2];
         splats[3 * slot] = r0; splats[3 * slot + 1] = r1; splats[3 * slot + 2] = r2;
-        tiles_per_gauss[slot] = ntiles;
     }
+    // Exact tile lists (tile_masks != NULL, with QED_F_TIGHT_TILES): of the rectangle counted above only the tiles in which
+    // SOME pixel can reach alpha >= 1/255 are listed -- the compositing kernels' own rectangle test (qed_common.h), applied
+    // to whole tiles: a tile it drops is one all four of whose quadrants those kernels would have culled after staging
+    // the entry, so images and gradients do not change and the list loses another ~18 % (config B: 3.35 M -> 2.75 M).
+    // A thread per Gaussian would loop over its own rectangle (the largest of a wave's 64 is ~40 tiles, the mean 7), so
+    // the wave tests all its candidates together, one per lane and trip: candidate j belongs to the Gaussian found by
+    // binary search over the prefix sums of the areas (as the emit pass finds its entries), and a surviving tile sets
+    // its bit in the Gaussian's 64-bit mask, which the emit pass expands -- count and emission cannot disagree.
+    // Rectangles of more than 64 tiles keep every tile (mask ~0: 1 % of the entries at config B).
+    if (tile_masks != nullptr) {
+        __shared__ __attribute__((aligned(16))) float4 s_c0[4][64];
+        __shared__ __attribute__((aligned(16))) float4 s_c1[4][64];
+        __shared__ int s_pref[4][65];
+        __shared__ unsigned long long s_mask[4][64];
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        const int cand = ntiles <= 64 ? ntiles : 0;
+        int x = cand;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        s_pref[wid][lane] = x - cand;
+        if (lane == 63) s_pref[wid][64] = x;
+        s_c0[wid][lane] = m_c0;
+        s_c1[wid][lane] = make_float4(m_cc, m_tau, __uint_as_float(m_rect), 0.f);
+        s_mask[wid][lane] = 0ull;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int wtot = s_pref[wid][64];
+        for (int j = lane; j < wtot; j += 64) {
+            int lo = 0, hi = 63;                                  // largest g with pref[g] <= j
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (s_pref[wid][mid] <= j) lo = mid; else hi = mid - 1;
+            }
+            const int g = lo;
+            const int local = j - s_pref[wid][g];
+            const float4 c0 = s_c0[wid][g], c1 = s_c1[wid][g];
+            const unsigned r = __float_as_uint(c1.z);
+            const int w = (int)(r >> 22);                         // 1 .. 64
+            const int row = (int)(((float)local + 0.5f) * __builtin_amdgcn_rcpf((float)w));    // local < 64: exact
+            const int tx = (int)(r & 2047u) + local - row * w, ty = (int)((r >> 11) & 2047u) + row;
+            const CullGauss cg = cull_setup(c0, make_float4(c1.x, 0.f, 0.f, 0.f), c1.y, (float)(tx * QED_TILE),
+                                            (float)(ty * QED_TILE));
+            if (tile_may_touch(cg)) atomicOr(&s_mask[wid][g], 1ull << local);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (slot < total) {
+            unsigned long long mask = ~0ull;
+            if (cand > 0) { mask = s_mask[wid][lane]; ntiles = __popcll(mask); }
+            tile_masks[slot] = mask;
+        }
+    }
+    if (slot < total) tiles_per_gauss[slot] = ntiles;
     // block sum of tile counts (input of the intersection scan)
     __shared__ int wsum[4];
     int v = ntiles;
@@ -928,8 +989,8 @@ extern "C" int qed_project_fwd(int32_t N, int32_t C, const float* means, const f
                                int32_t width, int32_t height, int32_t tile_w, int32_t tile_h, float eps2d,
                                float near_plane, float far_plane, float radius_clip, uint32_t flags, int32_t* radii,
                                float* means2d, float* depths, float* conics, float* opac_out, float* colors_out,
-                               float* splats, int32_t* tiles_per_gauss, int32_t* block_sums, float* viewmats_out,
-                               float* Ks_out, float* sh_jac, void* stream) {
+                               float* splats, int32_t* tiles_per_gauss, uint64_t* tile_masks, int32_t* block_sums,
+                               float* viewmats_out, float* Ks_out, float* sh_jac, void* stream) {
     QED_REQUIRE(N >= 0 && C >= 1, "N >= 0 and C >= 1 required");
     QED_REQUIRE(sh_degree <= 3, "SH degree > 3 unsupported (reference config uses sh_degree = 3)");
     QED_REQUIRE(width > 0 && height > 0 && tile_w > 0 && tile_h > 0, "bad image / tile extents");
@@ -940,6 +1001,7 @@ extern "C" int qed_project_fwd(int32_t N, int32_t C, const float* means, const f
     QED_REQUIRE(radii && means2d && depths && conics && opac_out && colors_out && splats && tiles_per_gauss &&
                     block_sums, "null output");
     QED_REQUIRE(!(flags & QED_F_CAMERA_C2W) || (viewmats_out && Ks_out), "QED_F_CAMERA_C2W needs viewmats_out and Ks_out");
+    QED_REQUIRE(tile_masks == nullptr || (flags & QED_F_TIGHT_TILES), "tile_masks goes with QED_F_TIGHT_TILES");
     const long long total = (long long)C * N;
     const unsigned grid = (unsigned)((total + 255) / 256);
 #define QED_LAUNCH_PF(ONE)                                                                                           \
@@ -947,7 +1009,7 @@ extern "C" int qed_project_fwd(int32_t N, int32_t C, const float* means, const f
                        scales, opacities, sh0, sh0_stride, shN, shN_stride, sh_degree, viewmats, Ks, width, height,  \
                        tile_w, tile_h, eps2d, near_plane, far_plane, radius_clip, flags, radii, means2d, depths,     \
                        conics, opac_out, colors_out, (float4*)splats, tiles_per_gauss, block_sums, viewmats_out, Ks_out,    \
-                       sh_degree >= 0 ? sh_jac : nullptr)
+                       sh_degree >= 0 ? sh_jac : nullptr, (unsigned long long*)tile_masks)
     if (C == 1) QED_LAUNCH_PF(true);
     else QED_LAUNCH_PF(false);
 #undef QED_LAUNCH_PF

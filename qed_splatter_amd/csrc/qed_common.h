@@ -72,6 +72,65 @@ __device__ __forceinline__ void tight_tile_rect(float mx, float my, float radius
     y1 = min(max(0, (int)ceilf((my + ry) / ts)), tile_h);
 }
 
+// ---- exact-conservative culling of (Gaussian, rectangle of pixel centres) pairs ------------------------------------
+// (the compositing kernels test the four 8x8 quadrants of a tile, composite.hip; the projection kernel whole tiles)
+// alpha >= 1/255  <=>  sigma(d) = (a dx^2 + c dy^2)/2 + b dx dy <= tau = ln(255 o).  sigma is convex, so over the
+// rectangle of a quadrant's (or a tile's) pixel centres its minimum is 0 if the mean lies inside and otherwise sits on one of the
+// four edges; along an edge it is a 1-D quadratic whose minimiser is clamped to the edge (v_med3).  A pair whose
+// minimum exceeds tau by more than the rounding margin is one every pixel would have skipped.
+//
+// sigma minimised over t in [lo, hi] on the line where the other coordinate is fixed:
+//   h = (own diagonal term)/2 * fixed^2,  bb = b * fixed,  s = -bb / (other diagonal term),  ho = (other term)/2
+__device__ __forceinline__ float edge_min(float h, float bb, float s, float ho, float lo, float hi) {
+    const float t = __builtin_amdgcn_fmed3f(s, lo, hi);
+    return __builtin_fmaf(t, __builtin_fmaf(ho, t, bb), h);
+}
+
+// Everything a lane needs about its staged Gaussian to test rectangles of the tile at pixel origin (ox, oy).
+// ia, ic = 1/a, 1/c to within an ulp (v_rcp_f32): they only place the point on an edge at which sigma is
+// evaluated, and a point off the minimiser by one part in 1e7 raises the value by one part in 1e14 -- the margin
+// is eleven orders of magnitude wider.  The margin uses the tile's extent for all four quadrants.
+struct CullGauss {
+    float b, ha, hc, ia, ic, X0, Y0, thr;
+};
+__device__ __forceinline__ CullGauss cull_setup(const float4& r0, const float4& r1, float tau, float ox, float oy) {
+    CullGauss g;
+    const float a = r0.z, c = r1.x;
+    g.b = r0.w; g.ha = 0.5f * a; g.hc = 0.5f * c;
+    g.ia = __builtin_amdgcn_rcpf(a); g.ic = __builtin_amdgcn_rcpf(c);
+    g.X0 = ox + 0.5f - r0.x; g.Y0 = oy + 0.5f - r0.y;
+    const float ax = fmaxf(fabsf(g.X0), fabsf(g.X0 + 15.f)), ay = fmaxf(fabsf(g.Y0), fabsf(g.Y0 + 15.f));
+    const float scale = a * ax * ax + c * ay * ay + fabsf(g.b) * ax * ay;
+    g.thr = tau + 1e-3f + 8e-6f * scale;
+    return g;
+}
+// the whole 16x16 tile at the origin cull_setup was given: can ANY of its pixels reach alpha >= 1/255?  (The same
+// arithmetic as composite.hip's quadrant_may_touch on the rectangle X0 .. X0 + 15, Y0 .. Y0 + 15; a quadrant's
+// rectangle is a subset, so a tile this test drops is one whose four quadrants the compositing kernels would have
+// dropped too, up to roundings eleven orders of magnitude inside the margin.)
+__device__ __forceinline__ bool tile_may_touch(const CullGauss& g) {
+    const float xl = g.X0, xh = xl + 15.f, yl = g.Y0, yh = yl + 15.f;
+    auto vline = [&](float X) { const float bb = g.b * X; return edge_min(g.ha * X * X, bb, -bb * g.ic, g.hc, yl, yh); };
+    auto hline = [&](float Y) { const float bb = g.b * Y; return edge_min(g.hc * Y * Y, bb, -bb * g.ia, g.ha, xl, xh); };
+    const float m = fminf(fminf(vline(xl), vline(xh)), fminf(hline(yl), hline(yh)));
+    const bool inside = (xl <= 0.f) & (xh >= 0.f) & (yl <= 0.f) & (yh >= 0.f);
+    return inside | !(m > g.thr);
+}
+
+// r-th set bit (r = 0 for the lowest) of a 64-bit mask that has more than r bits set
+__device__ __forceinline__ int nth_set_bit(unsigned long long m, int r) {
+    unsigned x = (unsigned)m;
+    int base = 0;
+    int c = __popc(x);
+    if (r >= c) { r -= c; x = (unsigned)(m >> 32); base = 32; }
+#pragma unroll
+    for (int w = 16; w >= 1; w >>= 1) {
+        c = __popc(x & ((1u << w) - 1u));
+        if (r >= c) { r -= c; x >>= w; base += w; }
+    }
+    return base;
+}
+
 // tile rectangle of a splat record (slot 11): x0 | y0 << 11 | width << 22  (tile grids up to 2047 x 2047,
 // rectangles up to 1023 tiles wide); the height follows from tiles_per_gauss
 __device__ __forceinline__ unsigned pack_tile_rect(int x0, int y0, int x1) {

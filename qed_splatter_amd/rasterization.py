@@ -151,6 +151,11 @@ class _Workspace:
 
 _WORKSPACES: Dict[int, _Workspace] = {}
 
+# qed_project_fwd's tile_masks: with the tight rectangles (QED_F_TIGHT_TILES) list only the tiles some pixel of which can reach
+# alpha >= 1/255 (tests switch it off to compare the lists; the images must not change)
+EXACT_TILE_LISTS = True
+_NO_MASKS: "Dict[torch.device, Tensor]" = {}
+
 # qed_project_fwd's sh_jac hand-over to qed_project_bwd (tests switch it off to keep the coefficient-reading backward
 # kernels, which direct C-ABI callers without the planes still get, under the same parity checks)
 SH_HANDOVER = True
@@ -212,6 +217,8 @@ class _ProjectSH(torch.autograd.Function):
         rgb = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
         splats = torch.empty(C * N, L.SPLAT_FLOATS, dtype=torch.float32, device=dev)
         tiles_per_gauss = torch.empty(C, N, dtype=torch.int32, device=dev)
+        # exact tile lists (with the tight rectangles): which tiles of a Gaussian's rectangle any of its pixels can reach
+        tile_masks = torch.empty(C * N, dtype=torch.int64, device=dev) if (flags & L.F_TIGHT_TILES) and EXACT_TILE_LISTS else None
         n_blocks = (C * N + 255) // 256
         block_sums = torch.empty(max(n_blocks, 1), dtype=torch.int32, device=dev)
         # what the backward pass needs of the SH part (direction Jacobian + clamp mask, 40 B per slot) instead of
@@ -223,15 +230,19 @@ class _ProjectSH(torch.autograd.Function):
             N, C, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opacities), L.ptr(sh0_flat), sh0_stride,
             shN_ptr, shN_stride, sh_degree, L.ptr(cam_in[0]), L.ptr(cam_in[1]), width, height, tile_w, tile_h, eps2d,
             near_plane, far_plane, radius_clip, flags, L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics),
-            L.ptr(opac), L.ptr(rgb), L.ptr(splats), L.ptr(tiles_per_gauss), L.ptr(block_sums),
+            L.ptr(opac), L.ptr(rgb), L.ptr(splats), L.ptr(tiles_per_gauss), L.ptr(tile_masks), L.ptr(block_sums),
             L.ptr(viewmats) if c2w is not None else None, L.ptr(Ks) if c2w is not None else None, L.ptr(sh_jac),
             _stream()), "qed_project_fwd")
         flags &= ~L.F_CAMERA_C2W                  # (the backward pass reads the view matrices the kernel wrote)
         ctx.save_for_backward(means, quats, scales, opacities, sh0, shN, viewmats, Ks, radii, sh_jac)
         ctx.meta = (N, C, width, height, sh_degree, flags, eps2d, sh0_stride, shN_stride)
         ctx.opac_shape = opac_shape
-        ctx.mark_non_differentiable(radii, splats, tiles_per_gauss, block_sums)
-        return means2d, depths, conics, opac, rgb, radii, splats, tiles_per_gauss, block_sums
+        if tile_masks is None:
+            tile_masks = _NO_MASKS.get(dev)
+            if tile_masks is None:
+                tile_masks = _NO_MASKS[dev] = torch.empty(0, dtype=torch.int64, device=dev)
+        ctx.mark_non_differentiable(radii, splats, tiles_per_gauss, block_sums, tile_masks)
+        return means2d, depths, conics, opac, rgb, radii, splats, tiles_per_gauss, block_sums, tile_masks
 
     @staticmethod
     def backward(ctx, v_means2d, v_depths, v_conics, v_opac, v_rgb, *_unused):
@@ -323,7 +334,7 @@ def _packed_vsplat(C, N, v_means2d, v_depths, v_conics, v_opac, v_rgb, dev) -> T
 # tile binning + sort + compositing
 # ==================================================================================================
 def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, tile_w, tile_h, sync=True, splats=None,
-                  size=None):
+                  size=None, tile_masks=None):
     """Tile binning (qed_bin_tiles): one C call that leaves the list sorted by (camera, tile, depth) and the tile
     offsets.
 
@@ -366,7 +377,7 @@ def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, til
         isect_ids = torch.empty(cap, dtype=torch.int64, device=dev) if sync else None
         scratch = torch.empty(int(lib.qed_bin_workspace_bytes(C * N, cap)), dtype=torch.uint8, device=dev)
         L.check(lib.qed_bin_tiles(N, C, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(tiles_per_gauss), L.ptr(splats),
-                                  L.ptr(block_sums), tile_w, tile_h, cap, mode, L.ptr(flatten_ids), L.ptr(offsets),
+                                  L.ptr(tile_masks), L.ptr(block_sums), tile_w, tile_h, cap, mode, L.ptr(flatten_ids), L.ptr(offsets),
                                   L.ptr(n_isect), L.ptr(isect_ids), L.ptr(scratch), scratch.numel(), L.ptr(ws.status),
                                   host_ptr, _stream()), "qed_bin_tiles")
         if capturing:
@@ -565,7 +576,7 @@ def rasterization(
             assert colors.shape[1] >= (deg + 1) ** 2, "colors must hold (sh_degree+1)^2 coefficients"
             sh0, shN = colors, None
 
-    means2d, depths, conics, opac, rgb, radii, splats, tiles_per_gauss, block_sums = _ProjectSH.apply(
+    means2d, depths, conics, opac, rgb, radii, splats, tiles_per_gauss, block_sums, tile_masks = _ProjectSH.apply(
         means, quats, scales, opacities, sh0, shN, viewmats, Ks, int(width), int(height), tile_w, tile_h, deg, flags,
         float(eps2d), float(near_plane), float(far_plane), float(radius_clip),
         *(_c2w if _c2w is not None else (None, None)))
@@ -577,7 +588,8 @@ def rasterization(
         raise NotImplementedError("F_TIGHT_TILES needs tile grids of at most 1023 x 2047 tiles")
     isect_ids, flatten_ids, offsets, M = _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums,
                                                        tile_w, tile_h, sync=_sync, splats=splats if use_packed else None,
-                                                       size=(int(width), int(height)))
+                                                       size=(int(width), int(height)),
+                                                       tile_masks=tile_masks if tile_masks.numel() else None)
     # _means2d_leaf: hand out info["means2d"] as a LEAF holding the same values, which receives .grad / .absgrad from
     # the compositing backward without a copy.  For callers that only retain and read the gradient (the reference:
     # model.py:289-290 and the densification strategy); a loss computed FROM info["means2d"] would not reach the

@@ -49,7 +49,7 @@ def test_argument_validation_needs_no_gpu(lib):
     rc = lib.qed_sort_pairs(0, 0, 0, 0, 0, 100, 0, 0, 0, 0, 0)                     # end_bit = 0
     assert rc == -1 and b"end_bit" in lib.qed_last_error()
     rc = lib.qed_project_fwd(10, 1, 0, 0, 0, 0, 0, 3, 0, 0, 4, 0, 0, 64, 64, 4, 4, 0.3, 0.01, 1e10, 0.0, 0,
-                             0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)                  # SH degree 4
+                             0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)               # SH degree 4
     assert rc == -1 and b"SH degree" in lib.qed_last_error()
 
 
