@@ -368,14 +368,17 @@ project_fwd_kernel(int N, int C, const float* __restrict__ means, const float* _
     // to whole tiles: a tile it drops is one all four of whose quadrants those kernels would have culled after staging
     // the entry, so images and gradients do not change and the list loses another ~18 % (config B: 3.35 M -> 2.75 M).
     // A thread per Gaussian would loop over its own rectangle (the largest of a wave's 64 is ~40 tiles, the mean 7), so
-    // the wave tests all its candidates together, one per lane and trip: candidate j belongs to the Gaussian found by
-    // binary search over the prefix sums of the areas (as the emit pass finds its entries), and a surviving tile sets
-    // its bit in the Gaussian's 64-bit mask, which the emit pass expands -- count and emission cannot disagree.
+    // the wave tests all its candidates together, one per lane and trip (candidate j of the wave's concatenated
+    // rectangles), and a surviving tile sets its bit in the Gaussian's 64-bit mask, which the emit pass expands -- count
+    // and emission cannot disagree.
     // Rectangles of more than 64 tiles keep every tile (mask ~0: 1 % of the entries at config B).
     if (tile_masks != nullptr) {
-        __shared__ __attribute__((aligned(16))) float4 s_c0[4][64];
-        __shared__ __attribute__((aligned(16))) float4 s_c1[4][64];
+        __shared__ __attribute__((aligned(16))) float4 s_c0[4][64];      // (x, y, conic b, tau)
+        __shared__ __attribute__((aligned(16))) float4 s_c1[4][64];      // (a / 2, c / 2, 1 / a, 1 / c)
+        __shared__ unsigned s_rect[4][64];
         __shared__ int s_pref[4][65];
+        __shared__ int s_nz[4][64];                                      // the lanes that have candidates, in order
+        __shared__ unsigned long long s_start[4][64];                    // bit j: a Gaussian's candidates start at j
         __shared__ unsigned long long s_mask[4][64];
         const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
         const int cand = ntiles <= 64 ? ntiles : 0;
@@ -385,30 +388,44 @@ project_fwd_kernel(int N, int C, const float* __restrict__ means, const float* _
             const int y = __shfl_up(x, o, 64);
             if (lane >= o) x += y;
         }
-        s_pref[wid][lane] = x - cand;
-        if (lane == 63) s_pref[wid][64] = x;
-        s_c0[wid][lane] = m_c0;
-        s_c1[wid][lane] = make_float4(m_cc, m_tau, __uint_as_float(m_rect), 0.f);
+        const int pref = x - cand;
+        const int wtot = __shfl(x, 63, 64);
+        const unsigned long long nz = __ballot(cand > 0);
+        s_pref[wid][lane] = pref;
+        s_c0[wid][lane] = make_float4(m_c0.x, m_c0.y, m_c0.w, m_tau);
+        s_c1[wid][lane] = make_float4(0.5f * m_c0.z, 0.5f * m_cc, __builtin_amdgcn_rcpf(m_c0.z), __builtin_amdgcn_rcpf(m_cc));
+        s_rect[wid][lane] = m_rect;
         s_mask[wid][lane] = 0ull;
+        s_start[wid][lane] = 0ull;
+        if (cand > 0) s_nz[wid][__popcll(nz & ((1ull << lane) - 1ull))] = lane;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const int wtot = s_pref[wid][64];
-        for (int j = lane; j < wtot; j += 64) {
-            int lo = 0, hi = 63;                                  // largest g with pref[g] <= j
-#pragma unroll
-            for (int it = 0; it < 6; ++it) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (s_pref[wid][mid] <= j) lo = mid; else hi = mid - 1;
-            }
-            const int g = lo;
+        if (cand > 0) atomicOr(&s_start[wid][pref >> 6], 1ull << (pref & 63));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // Candidate j = 64 trip + lane belongs to the Gaussian whose range started last at or before j: the number of
+        // start bits up to j (one LDS word per trip and a popcount) indexes the list of lanes that have candidates -- two
+        // dependent LDS reads per trip where a binary search over the prefix sums takes six.
+        int before = 0;                                           // start bits of the earlier trips (wave-uniform)
+        for (int j0 = 0; j0 < wtot; j0 += 64) {
+            const unsigned long long word = s_start[wid][j0 >> 6];
+            const int j = j0 + lane;
+            const int k = before + __popcll(word & ((2ull << lane) - 1ull)) - 1;
+            before += __popcll(word);
+            if (j >= wtot) continue;
+            const int g = s_nz[wid][k];
             const int local = j - s_pref[wid][g];
             const float4 c0 = s_c0[wid][g], c1 = s_c1[wid][g];
-            const unsigned r = __float_as_uint(c1.z);
+            const unsigned r = s_rect[wid][g];
             const int w = (int)(r >> 22);                         // 1 .. 64
             const int row = (int)(((float)local + 0.5f) * __builtin_amdgcn_rcpf((float)w));    // local < 64: exact
             const int tx = (int)(r & 2047u) + local - row * w, ty = (int)((r >> 11) & 2047u) + row;
-            const CullGauss cg = cull_setup(c0, make_float4(c1.x, 0.f, 0.f, 0.f), c1.y, (float)(tx * QED_TILE),
-                                            (float)(ty * QED_TILE));
+            // (cull_setup's values from the halves and reciprocals formed once per Gaussian)
+            CullGauss cg;
+            cg.b = c0.z; cg.ha = c1.x; cg.hc = c1.y; cg.ia = c1.z; cg.ic = c1.w;
+            cg.X0 = (float)(tx * QED_TILE) + 0.5f - c0.x; cg.Y0 = (float)(ty * QED_TILE) + 0.5f - c0.y;
+            const float ax = fmaxf(fabsf(cg.X0), fabsf(cg.X0 + 15.f)), ay = fmaxf(fabsf(cg.Y0), fabsf(cg.Y0 + 15.f));
+            cg.thr = c0.w + 1e-3f + 8e-6f * (2.f * (cg.ha * ax * ax + cg.hc * ay * ay) + fabsf(cg.b) * ax * ay);
             if (tile_may_touch(cg)) atomicOr(&s_mask[wid][g], 1ull << local);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
