@@ -668,6 +668,22 @@ def test_tight_tile_lists_change_nothing_but_the_lists(cuda, monkeypatch):
             assert float(a_max.max()) < 1.0 / 255.0, (t, float(a_max.max()))
             n_dropped += len(dropped)
     assert n_dropped > 100
+    # both binning pipelines expand the masks to the same list (two cameras: the slot index carries the camera)
+    lists = []
+    for mode in ("two_stage", "tile_sort"):
+        monkeypatch.setenv("QED_BIN_MODE", mode)
+        with torch.no_grad():
+            vm2 = torch.cat([O.get_viewmat(sc["camera_to_worlds"][:1]), O.get_viewmat(sc["camera_to_worlds"][:1])]).to(cuda)
+            vm2[1, 0, 3] += 0.4
+            _, _, inf = R.rasterization(
+                means=sc["means"].to(cuda), quats=sc["quats"].to(cuda), scales=sc["scales"].to(cuda),
+                opacities=sc["opacities"].to(cuda).squeeze(-1), colors=sc["features_dc"].to(cuda), viewmats=vm2,
+                Ks=sc["Ks"][:1].expand(2, 3, 3).contiguous().to(cuda), width=w, height=h, render_mode="RGB+D", sh_degree=3,
+                _flags=L.F_LOG_SCALES | L.F_LOGIT_OPAC | L.F_TIGHT_TILES, _sh_rest=sc["features_rest"].to(cuda))
+        lists.append((inf["flatten_ids"].clone(), inf["isect_offsets"].clone(), inf["tiles_per_gauss"].clone()))
+    monkeypatch.delenv("QED_BIN_MODE")
+    assert all(torch.equal(a, b) for a, b in zip(*lists))
+    assert int(lists[0][2].sum()) == lists[0][0].numel() and int(lists[0][2][1].sum()) > 0
     # (the same terms summed by float atomics in another order; the forty screen-filling Gaussians sum tens of thousands)
     for k in PARAM_NAMES:
         assert_close(g1[k], g0[k], 1e-4, f"grad {k} (tight vs full lists)")
