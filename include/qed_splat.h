@@ -90,11 +90,13 @@ int qed_camera_setup(int32_t C, const float* c2w, const float* intrinsics, float
  *   compositing kernels; block_sums[ceil(C*N/256)] i32 = tile counts summed per 256
  *   consecutive (camera,Gaussian) slots (input of qed_isect_scan).
  * Culled Gaussians get radius 0 and zeros everywhere.
- * tile_masks (may be NULL; with QED_F_TIGHT_TILES only): u64[C*N].  Exact tile lists: bit l of a slot's mask says whether
- *   tile l (row-major) of the rectangle in record slot 11 can be reached -- whether ANY pixel centre of the tile can have
- *   alpha >= 1/255, the rectangle test the compositing kernels apply to a tile's quadrants, applied to the tile;
- *   tiles_per_gauss then counts the set bits.  A rectangle of more than 64 tiles keeps every tile (mask ~0).  Hand the
- *   masks to qed_bin_tiles together with `splats`.  Images and gradients do not change; the list loses ~18 % at config B.
+ * tile_masks (may be NULL; with QED_F_TIGHT_TILES only): u64[C*N][2], 16-byte aligned.  Exact tile lists: word 1 of a slot
+ *   is a mask whose bit l says whether tile l (row-major) of the rectangle in record slot 11 can be reached -- whether ANY
+ *   pixel centre of the tile can have alpha >= 1/255, the rectangle test the compositing kernels apply to a tile's
+ *   quadrants, applied to the tile; tiles_per_gauss then counts the set bits.  A rectangle of more than 64 tiles keeps
+ *   every tile (mask ~0).  Word 0 repeats the count (low half) and the packed rectangle (high half), so that the emit
+ *   pass reads ONE 16-byte descriptor per slot.  Hand the array to qed_bin_tiles together with `splats`.  Images and
+ *   gradients do not change; the list loses ~18 % at config B.
  * sh_jac (may be NULL; used with sh_degree >= 0): QED_SH_JAC_FLOATS planes of C*N floats that the backward pass takes
  *   instead of the coefficients -- planes 0..8 = d colour_ch / d unit direction_axis at [3 axis + ch] (sum over k of
  *   d b_k / d axis * c_k,ch, before the clamp), plane 9 = the clamp mask as an integer (bit ch: colour_ch + 0.5 >= 0).

@@ -113,8 +113,14 @@ isect_emit_kernel(int N, int C, const float* __restrict__ means2d, const int* __
     unsigned dbits = 0;
     unsigned long long tmask = ~0ull;
     if (pos < total) {
-        if (tile_masks != nullptr) tmask = tile_masks[slot];        // (a third gather beside the two below)
-        if (splats != nullptr) {
+        if (tile_masks != nullptr) {
+            // qed_project_fwd's 16-byte descriptor: count, packed rectangle, mask of the listed tiles -- one gather
+            const uint4 d = reinterpret_cast<const uint4*>(tile_masks)[slot];
+            cnt = (int)d.x;
+            x0 = (int)(d.y & 2047u); y0 = (int)((d.y >> 11) & 2047u); x1 = x0 + (int)(d.y >> 22);
+            tmask = ((unsigned long long)d.w << 32) | d.z;
+            if constexpr (sizeof(KeyT) == 8) dbits = __float_as_uint(depths[slot]);
+        } else if (splats != nullptr) {
             // the rectangle project_fwd counted (QED_F_TIGHT_TILES or not), packed in record slot 11.  Fetched
             // beside the count, not behind it: both gathers depend on `slot` only (a rectangle read under
             // `cnt > 0` is a third serialised random access per Gaussian)
@@ -699,6 +705,7 @@ extern "C" int qed_bin_tiles(int32_t N, int32_t C, const float* means2d, const i
     QED_REQUIRE(N >= 0 && C >= 1 && tile_w > 0 && tile_h > 0, "bad extents");
     QED_REQUIRE(splats == nullptr || (tile_w <= 1023 && tile_h <= 2047), "packed tile rectangles need tile_w <= 1023");
     QED_REQUIRE(tile_masks == nullptr || splats != nullptr, "tile_masks index the rectangles of the splat records");
+    QED_REQUIRE(((uintptr_t)tile_masks & 15) == 0, "tile_masks must be 16-byte aligned");
     QED_REQUIRE(capacity >= 0 && capacity < (1ll << 30), "capacity out of range");
     QED_REQUIRE(offsets && n_isect && status && workspace, "null buffers");
     QED_REQUIRE(((uintptr_t)host_words & 15) == 0, "host_words must be 16-byte aligned");

@@ -433,7 +433,10 @@ project_fwd_kernel(int N, int C, const float* __restrict__ means, const float* _
         if (slot < total) {
             unsigned long long mask = ~0ull;
             if (cand > 0) { mask = s_mask[wid][lane]; ntiles = __popcll(mask); }
-            tile_masks[slot] = mask;
+            // one 16-byte descriptor per slot -- count, rectangle, mask -- is all the emit pass reads of a Gaussian: one
+            // gather where count, record slot 11 and mask were three (they are random accesses when the slots are
+            // emitted in depth order: config D's emit pass 332 -> 2xx us)
+            reinterpret_cast<uint4*>(tile_masks)[slot] = make_uint4((unsigned)ntiles, m_rect, (unsigned)mask, (unsigned)(mask >> 32));
         }
     }
     if (slot < total) tiles_per_gauss[slot] = ntiles;
@@ -1019,6 +1022,7 @@ extern "C" int qed_project_fwd(int32_t N, int32_t C, const float* means, const f
                     block_sums, "null output");
     QED_REQUIRE(!(flags & QED_F_CAMERA_C2W) || (viewmats_out && Ks_out), "QED_F_CAMERA_C2W needs viewmats_out and Ks_out");
     QED_REQUIRE(tile_masks == nullptr || (flags & QED_F_TIGHT_TILES), "tile_masks goes with QED_F_TIGHT_TILES");
+    QED_REQUIRE(((uintptr_t)tile_masks & 15) == 0, "tile_masks must be 16-byte aligned");
     const long long total = (long long)C * N;
     const unsigned grid = (unsigned)((total + 255) / 256);
 #define QED_LAUNCH_PF(ONE)                                                                                           \

@@ -218,7 +218,7 @@ class _ProjectSH(torch.autograd.Function):
         splats = torch.empty(C * N, L.SPLAT_FLOATS, dtype=torch.float32, device=dev)
         tiles_per_gauss = torch.empty(C, N, dtype=torch.int32, device=dev)
         # exact tile lists (with the tight rectangles): which tiles of a Gaussian's rectangle any of its pixels can reach
-        tile_masks = torch.empty(C * N, dtype=torch.int64, device=dev) if (flags & L.F_TIGHT_TILES) and EXACT_TILE_LISTS else None
+        tile_masks = torch.empty(C * N, 2, dtype=torch.int64, device=dev) if (flags & L.F_TIGHT_TILES) and EXACT_TILE_LISTS else None
         n_blocks = (C * N + 255) // 256
         block_sums = torch.empty(max(n_blocks, 1), dtype=torch.int32, device=dev)
         # what the backward pass needs of the SH part (direction Jacobian + clamp mask, 40 B per slot) instead of
