@@ -686,8 +686,8 @@ def test_tight_tile_lists_change_nothing_but_the_lists(cuda, monkeypatch):
     assert int(lists[0][2].sum()) == lists[0][0].numel() and int(lists[0][2][1].sum()) > 0
     # (the same terms summed by float atomics in another order; the forty screen-filling Gaussians sum tens of thousands)
     for k in PARAM_NAMES:
-        assert_close(g1[k], g0[k], 1e-4, f"grad {k} (tight vs full lists)")
-        assert_close(g2[k], g0[k], 1e-4, f"grad {k} (exact vs full lists)")
+        assert_close(g1[k], g0[k], 2.5e-4, f"grad {k} (tight vs full lists)")     # (4.8e-5 seen; the order differs run to run)
+        assert_close(g2[k], g0[k], 2.5e-4, f"grad {k} (exact vs full lists)")
 
 
 def test_fused_path_equals_api_path(cuda):
