@@ -435,7 +435,7 @@ project_fwd_kernel(int N, int C, const float* __restrict__ means, const float* _
             if (cand > 0) { mask = s_mask[wid][lane]; ntiles = __popcll(mask); }
             // one 16-byte descriptor per slot -- count, rectangle, mask -- is all the emit pass reads of a Gaussian: one
             // gather where count, record slot 11 and mask were three (they are random accesses when the slots are
-            // emitted in depth order: config D's emit pass 332 -> 2xx us)
+            // emitted in depth order: config D's binning 1 047 -> 864 us)
             reinterpret_cast<uint4*>(tile_masks)[slot] = make_uint4((unsigned)ntiles, m_rect, (unsigned)mask, (unsigned)(mask >> 32));
         }
     }
