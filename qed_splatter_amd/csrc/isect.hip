@@ -65,8 +65,11 @@ isect_emit_kernel(int N, int C, const float* __restrict__ means2d, const int* __
                   int* __restrict__ vals, const float* __restrict__ splats, long long capacity,
                   int* __restrict__ status, const unsigned long long* __restrict__ tile_masks = nullptr) {
     __shared__ int s_pref[4][65];   // per wave: exclusive prefix of counts (+ total)
-    __shared__ int s_x0[4][64], s_y0[4][64], s_w[4][64];
+    __shared__ int s_w[4][64], s_tile0[4][64], s_nz[4][64];
+    __shared__ float s_invw[4][64];
+    __shared__ unsigned long long s_ctb[4][64];    // camera bits of the key
     __shared__ unsigned long long s_mask[4][64];   // qed_project_fwd's tile_masks: which tiles of the rectangle are listed
+    __shared__ unsigned long long s_start[4][64];  // bit j: a Gaussian's entries start at entry j of the wave
     __shared__ unsigned s_depth[4][64];
     __shared__ int s_slot[4][64];
     __shared__ int s_wave_tot[4];
@@ -143,39 +146,67 @@ isect_emit_kernel(int N, int C, const float* __restrict__ means2d, const int* __
         const int y = __shfl_up(x, o, 64);
         if (lane >= o) x += y;
     }
-    s_pref[wid][lane] = x - cnt;
+    const int pref = x - cnt;
+    s_pref[wid][lane] = pref;
     if (lane == 63) { s_pref[wid][64] = x; s_wave_tot[wid] = x; }
-    s_x0[wid][lane] = x0; s_y0[wid][lane] = y0; s_w[wid][lane] = x1 - x0; s_depth[wid][lane] = dbits;
+    // per Gaussian, once: everything of an entry's key but the tile's place inside the rectangle (the per-entry integer
+    // divisions by the rectangle's width and by N used to be two thirds of this kernel's vector instructions)
+    const int rw = x1 - x0;
+    s_w[wid][lane] = rw;
+    s_invw[wid][lane] = __builtin_amdgcn_rcpf((float)max(rw, 1));
+    s_tile0[wid][lane] = y0 * tile_w + x0;
+    s_ctb[wid][lane] = (unsigned long long)(C == 1 ? 0 : slot / N) << tile_bits;
+    s_depth[wid][lane] = dbits;
     s_slot[wid][lane] = (int)slot;
     s_mask[wid][lane] = tmask;
+    s_start[wid][lane] = 0ull;
+    const unsigned long long nz = __ballot(cnt > 0);
+    if (cnt > 0) s_nz[wid][__popcll(nz & ((1ull << lane) - 1ull))] = lane;
     __syncthreads();
     int wave_base = block_base;
     for (int w = 0; w < wid; ++w) wave_base += s_wave_tot[w];
     const int wtot = s_pref[wid][64];
-    for (int j = lane; j < wtot; j += 64) {
-        // largest g with pref[g] <= j
-        int lo = 0, hi = 63;
+    // Entry j of the wave belongs to the Gaussian whose range started last at or before j.  Up to 4096 entries per wave
+    // (nearly always) that is a popcount over one LDS word of range-start bits per trip (as in project_fwd_kernel's
+    // mask pass); beyond, a binary search over the prefix sums.
+    const bool by_bits = wtot <= 64 * 64;
+    if (by_bits && cnt > 0) atomicOr(&s_start[wid][pref >> 6], 1ull << (pref & 63));
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int before = 0;
+    for (int j0 = 0; j0 < wtot; j0 += 64) {
+        const int j = j0 + lane;
+        int g;
+        if (by_bits) {
+            const unsigned long long word = s_start[wid][j0 >> 6];
+            const int k = before + __popcll(word & ((2ull << lane) - 1ull)) - 1;
+            before += __popcll(word);
+            if (j >= wtot) continue;
+            g = s_nz[wid][k];
+        } else {
+            if (j >= wtot) continue;
+            int lo = 0, hi = 63;                              // largest g with pref[g] <= j
 #pragma unroll
-        for (int it = 0; it < 6; ++it) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (s_pref[wid][mid] <= j) lo = mid; else hi = mid - 1;
+            for (int it = 0; it < 6; ++it) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (s_pref[wid][mid] <= j) lo = mid; else hi = mid - 1;
+            }
+            g = lo;
         }
-        const int g = lo;
         int local = j - s_pref[wid][g];
         // exact tile lists: the entry is the local-th LISTED tile of the rectangle (mask ~0: every tile is listed, and
         // the rectangle may hold more than 64)
         const unsigned long long tm = s_mask[wid][g];
         if (tm != ~0ull) local = nth_set_bit(tm, local);
+        // row = local / w through the reciprocal, put right by one step either way (local < 2^21, w <= 1023)
         const int w = s_w[wid][g];
-        const int ty = s_y0[wid][g] + local / w;
-        const int tx = s_x0[wid][g] + local % w;
-        const int sl = s_slot[wid][g];
-        const unsigned long long cam = (unsigned long long)(sl / N);
-        const unsigned long long tile = (unsigned long long)(ty * tile_w + tx);
-        const unsigned long long ct = (cam << tile_bits) | tile;
+        int row = (int)(((float)local + 0.5f) * s_invw[wid][g]);
+        int col = local - row * w;
+        if (col < 0) { --row; col += w; } else if (col >= w) { ++row; col -= w; }
+        const unsigned long long ct = s_ctb[wid][g] | (unsigned long long)(s_tile0[wid][g] + row * tile_w + col);
         if constexpr (sizeof(KeyT) == 8) keys[wave_base + j] = (KeyT)((ct << 32) | (unsigned long long)s_depth[wid][g]);
         else keys[wave_base + j] = (KeyT)ct;
-        vals[wave_base + j] = sl;
+        vals[wave_base + j] = s_slot[wid][g];
     }
 }
 
