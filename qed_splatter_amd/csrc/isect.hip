@@ -313,8 +313,9 @@ __device__ __forceinline__ int wave_digit_rank(bool valid, unsigned d, int* cnt,
 // Short runs (<= kTileWaveItems entries: nearly every tile at config B): ONE WAVE per tile, four tiles per workgroup,
 // no workgroup barrier anywhere, a whole generation of tiles resident at once.  The keys stay in registers (8 rows of
 // 64).  A run is a few hundred depths, so a full 4-pass radix sort is overkill:
-//   (1) ONE stable counting pass on a 9-bit bucket  b = floor((key - kmin) * 511.99 / (kmax - kmin))  -- monotone in the
-//       key, ranks from the same ballot match, the 512 bucket totals scanned by the wave itself (8 per lane);
+//   (1) ONE counting pass on a 9-bit bucket  b = floor((key - kmin) * 511.99 / (kmax - kmin))  -- monotone in the key,
+//       places inside the bucket handed out by returning LDS atomics, the 512 bucket totals scanned by the wave itself
+//       (8 per lane);
 //   (2) the run is now ordered by bucket and two keys can only be out of order inside one bucket, so every entry
 //       counts the members of its own bucket that sort before it (smaller depth, or equal depth and earlier slot:
 //       stable) and that count is its place -- a few LDS reads per entry for a spread of depths.
@@ -328,23 +329,6 @@ constexpr int kTileBucketMax = 12;
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-}
-
-// as wave_digit_rank, for 9-bit digits
-__device__ __forceinline__ int wave_bucket_rank(bool valid, unsigned d, int* cnt, int lane) {
-    unsigned long long peers = __ballot(valid);
-#pragma unroll
-    for (int b = 0; b < 9; ++b) {
-        const bool bit = (d >> b) & 1u;
-        const unsigned long long bal = __ballot(bit);
-        peers &= bit ? bal : ~bal;
-    }
-    int r = 0;
-    if (valid) {
-        r = cnt[d] + __popcll(peers & ((1ull << lane) - 1ull));
-        if ((peers >> lane) == 1ull) cnt[d] = r + 1;
-    }
-    return r;
 }
 
 // one wave sorts the run [start, start + n), 1 <= n <= kTileWaveItems; kv / cnt: this wave's LDS
@@ -395,7 +379,10 @@ __device__ __forceinline__ void tile_sort_wave(int start, int n, int lane, uint2
     for (int k = 0; k < kTileWaveKpt; ++k) {
         if (k >= rows) break;
         bkt[k] = min((unsigned)((float)(key[k] - kmin) * scale), (unsigned)(kTileBuckets - 1));
-        rank[k] = wave_bucket_rank(k * 64 + lane < n, bkt[k], cnt, lane);
+        // the entry's place among its bucket's members as they ARRIVE (one returning LDS atomic; the 9-ballot match that
+        // gave the stable rank was ~60 instructions per row): step (2) orders a bucket's members by (depth, slot) whatever
+        // order they were stored in
+        rank[k] = k * 64 + lane < n ? atomicAdd(&cnt[bkt[k]], 1) : 0;
     }
     wave_lds_fence();
     int largest;
@@ -428,7 +415,8 @@ __device__ __forceinline__ void tile_sort_wave(int start, int n, int lane, uint2
         }
         wave_lds_fence();
         // ---- (2) place every entry inside its bucket: its offset there is the number of bucket members that sort
-        // before it (smaller depth, or the same depth and earlier in slot order = smaller rank).  Buckets hold a handful
+        // before it (smaller depth, or the same depth and a smaller slot: the run arrives in slot order, so that IS the
+        // stable order).  Buckets hold a handful
         // of entries, so this is a few LDS reads per entry and ONE pass (an odd-even transposition took 3-5 rounds of
         // two fenced phases each) ----
 #pragma unroll
@@ -441,7 +429,7 @@ __device__ __forceinline__ void tile_sort_wave(int start, int n, int lane, uint2
                 int before = 0;
                 for (int j = b0; j < b1; ++j) {
                     const unsigned other = kv[j].x;
-                    before += (other < key[k]) | ((other == key[k]) & (j - b0 < rank[k]));
+                    before += (other < key[k]) | ((other == key[k]) & ((int)kv[j].y < val[k]));
                 }
                 vals_out[start + b0 + before] = val[k];
             }
