@@ -169,14 +169,16 @@ sort_scatter_kernel(const KeyT* __restrict__ keys_in, const int* __restrict__ va
     __syncthreads();
 
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // ballots for the bits the digit really has (the tile sort's second pass has five: the other three would all be
+    // "every lane agrees")
+    const int nbits = 32 - __builtin_clz(mask | 1u);
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {
         const int li = wbase + k * 64 + lane;
         const bool valid = li < block_n;
         const unsigned d = digit_of<KeyT>(key[k], shift, mask);
         unsigned long long peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < kRadixBits; ++b) {
+        for (int b = 0; b < nbits; ++b) {
             const bool bit = (d >> b) & 1u;
             const unsigned long long bal = __ballot(bit);
             peers &= bit ? bal : ~bal;
