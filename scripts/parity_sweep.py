@@ -37,7 +37,7 @@ for case in (range(n_cases) if only is None else [only]):
     w = int(torch.randint(40, 260, (1,), generator=g)); h = int(torch.randint(33, 200, (1,), generator=g))
     n = int(torch.randint(200, 6000, (1,), generator=g))
     deg = int(torch.randint(0, 4, (1,), generator=g))
-    mode = "antialiased" if case % 3 == 1 else "classic"
+    mode = os.environ.get("QED_SWEEP_MODE") or ("antialiased" if case % 3 == 1 else "classic")     # (override: diagnosis)
     use_mask = case % 4 == 2
     # QED_SWEEP_CAM=k: view the scene from the k-th camera of a 5-degree fan (k = 11 is 55 degrees off axis: many
     # Gaussians beyond the frustum rim, where the projection Jacobian is clamped)
