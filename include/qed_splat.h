@@ -51,9 +51,11 @@ extern "C" {
 #define QED_F_SH_GRAD_COMPACT 64u /* qed_project_bwd (one camera): v_sh0 receives the clamp-masked colour gradient
                                     (3 floats) instead of b_0 v, v_shN is not written; qed_sh_grad_from_views
                                     rebuilds all coefficient gradients from the views' colour gradients */
-#define QED_F_TIGHT_TILES 32u   /* list only the tiles of the 3-sigma square that can reach alpha >= 1/255:
-                                   tiles_per_gauss / the sorted list become subsets of gsplat's, images and
-                                   gradients are unchanged (pass `splats` to qed_bin_tiles) */
+#define QED_F_TIGHT_TILES 32u   /* list only the tiles of the 3-sigma square that can reach alpha >= 1/255 (the
+                                   rectangle of that ellipse; with qed_project_fwd's tile_masks exactly the tiles in
+                                   which some pixel can): tiles_per_gauss / the sorted list become subsets of gsplat's,
+                                   images and gradients are unchanged (pass `splats` -- and the masks -- to
+                                   qed_bin_tiles) */
 #define QED_F_CAMERA_C2W 128u   /* qed_project_fwd: `viewmats` holds camera-to-world matrices c2w[C,3,4] (OpenGL) and `Ks`
                                    the intrinsics [C,4] = (fx, fy, cx, cy); the kernel derives view matrix and K itself
                                    (get_viewmat, model.py:22-38: what qed_camera_setup does in a launch of its own) and
