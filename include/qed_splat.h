@@ -211,6 +211,9 @@ int qed_tile_offsets(const uint64_t* sorted_keys, const int32_t* n_dev, int64_t 
  * alpha < 1/255, stop (Gaussian not applied) when T(1-alpha) <= 1e-4.
  * channels = 3 (RGB) or 4 (RGB+D).  backgrounds[C,channels] may be NULL (model.py:267-288 passes
  * none).  Outputs render[C,H,W,channels], alpha[C,H,W], last_ids[C,H,W] i32.
+ * t_final (may be NULL; [C,H,W]): receives every pixel's final transmittance T itself.  alpha = 1 - T loses up to
+ * 3e-8 / T of it (a saturated pixel's alpha sits just below 1), and every gradient term of a pixel scales with its T:
+ * qed_composite_bwd, given this image, reconstructs the transmittances from T instead of from 1 - alpha.
  * launch_flags: 0 in production.  One wave composites a whole tile, or one 8x8 quadrant of it for the
  * last tiles of a launch (finer work items fill the end of the launch); QED_CL_TILE_WAVES / _QUADRANT_WAVES
  * / _HALF_AND_HALF force one shape and QED_CL_NO_CULL turns the per-quadrant culling off -- results must
@@ -244,14 +247,16 @@ typedef struct {
 int qed_composite_fwd(int32_t C, int32_t N, const float* splats, const int32_t* flatten_ids,
                       const int32_t* offsets, int32_t width, int32_t height, int32_t tile_w,
                       int32_t tile_h, int32_t channels, const float* backgrounds, float* render,
-                      float* alpha, int32_t* last_ids, int32_t* tile_cost, const qed_post_t* post,
-                      int32_t launch_flags, void* stream);
+                      float* alpha, float* t_final, int32_t* last_ids, int32_t* tile_cost,
+                      const qed_post_t* post, int32_t launch_flags, void* stream);
 
 /* ---- K7: alpha compositing backward ------------------------------------------------------------
  * Back-to-front replay from last_ids; per-pixel gradients are reduced across each 64-wide wave
  * (one permlane level, the rest through LDS) and added once per (tile,Gaussian) to the
  * 64-byte row vsplat[C*N][16] (layout at qed_project_bwd; includes absgrad, model.py:284).
  * vsplat must be zeroed by the caller.
+ * t_final (may be NULL; [C,H,W]): qed_composite_fwd's image of the final transmittances; with it render_alpha is not read
+ * (1 - t_final is that alpha bit for bit).  NULL: T_final = 1 - render_alpha, as gsplat's backward pass forms it.
  * tile_cost (may be NULL; [C*tiles][4] i32, 16-byte aligned): what qed_composite_fwd wrote for the same list -- the
  * tiles are then handed out costliest first (greedy longest-processing-time scheduling of the launch; tiles heavier than
  * the average wave slot's whole share are dealt as four quadrant waves), ordered by one extra one-workgroup launch into
@@ -259,8 +264,8 @@ int qed_composite_fwd(int32_t C, int32_t N, const float* splats, const int32_t* 
 int qed_composite_bwd(int32_t C, int32_t N, const float* splats, const int32_t* flatten_ids,
                       const int32_t* offsets, int32_t width, int32_t height, int32_t tile_w,
                       int32_t tile_h, int32_t channels, const float* backgrounds,
-                      const float* render_alpha, const int32_t* last_ids, const float* v_render,
-                      const float* v_alpha, float* vsplat, const int32_t* tile_cost, int32_t* order_ws,
+                      const float* render_alpha, const float* t_final, const int32_t* last_ids,
+                      const float* v_render, const float* v_alpha, float* vsplat, const int32_t* tile_cost, int32_t* order_ws,
                       const qed_post_grad_t* post, int32_t launch_flags, void* stream);
 
 /* ---- K8: fused image-space loss + gradient ------------------------------------------------------

@@ -277,6 +277,41 @@ def isect_offset_encode(isect_ids: Tensor, C: int, tile_w: int, tile_h: int) -> 
 # ----------------------------------------------------------------------------------
 # K6: alpha compositing   -- vectorised per tile, autograd = K7
 # ----------------------------------------------------------------------------------
+def blend_run(dx: Tensor, dy: Tensor, con: Tensor, op: Tensor, cl: Tensor):
+    """Front-to-back blending of one run of K Gaussians over P pixels: dx, dy [P,K] = mean - pixel
+    centre, con [K,3], op [K], cl [K,D].  Returns (o e^-sigma, alpha, accepted-by-the-alpha-test, T after, T before,
+    contributes, colour [P,D], final T [P]).  (A function of its own so that tests can feed per-pixel copies of the
+    means and read per-pixel gradients: absgrad = sum over pixels of |d L_pixel / d mean|.)"""
+    sigma = 0.5 * (con[None, :, 0] * dx * dx + con[None, :, 2] * dy * dy) + con[None, :, 1] * dx * dy
+    ov = op[None, :] * torch.exp(-sigma)
+    a = torch.clamp(ov, max=ALPHA_MAX)
+    ok = (sigma >= 0) & (a >= ALPHA_MIN)
+    a = torch.where(ok, a, torch.zeros_like(a))
+    T_after = torch.cumprod(1.0 - a, dim=1)
+    T_before = torch.cat([torch.ones_like(T_after[:, :1]), T_after[:, :-1]], dim=1)
+    contrib = ok & (T_after > T_MIN)
+    wgt = torch.where(contrib, a * T_before, torch.zeros_like(a))
+    out = wgt @ cl                                       # [P,D]
+    T_fin = torch.prod(torch.where(contrib, 1.0 - a, torch.ones_like(a)), dim=1)
+    return ov, a, ok, T_after, T_before, contrib, out, T_fin
+
+
+def run_margin(ov: Tensor, ok: Tensor, T_after: Tensor, T_before: Tensor) -> Tensor:
+    """[P] float64: per pixel, the smallest relative distance of any decision blend_run evaluated while the pixel was still
+    alive (alpha >= 1/255, T(1 - alpha) <= 1e-4) to its threshold."""
+    with torch.no_grad():
+        alive = T_before > T_MIN                      # pixel not yet terminated
+        # was the pixel terminated by an earlier Gaussian?  then decisions don't matter
+        term = (ok & (T_after <= T_MIN)).to(torch.int64).cumsum(1)
+        reached = (term - (ok & (T_after <= T_MIN)).to(torch.int64)) == 0
+        m_alpha = torch.abs(torch.clamp(ov, max=ALPHA_MAX) / ALPHA_MIN - 1.0).to(torch.float64)
+        m_T = torch.abs(T_after / T_MIN - 1.0).to(torch.float64)
+        m_T = torch.where(ok, m_T, torch.full_like(m_T, float("inf")))
+        mm = torch.minimum(m_alpha, m_T)
+        mm = torch.where(reached & alive, mm, torch.full_like(mm, float("inf")))
+        return mm.amin(dim=1)
+
+
 def composite_tiles(
     means2d: Tensor, conics: Tensor, colors: Tensor, opacities: Tensor,
     width: int, height: int, tile_size: int, isect_offsets: Tensor, flatten_ids: Tensor,
@@ -327,34 +362,13 @@ def composite_tiles(
                 xy = m2[g]                                           # [K,2]
                 dx = xy[None, :, 0] - (px.to(dt)[:, None] + 0.5)     # [P,K]
                 dy = xy[None, :, 1] - (py.to(dt)[:, None] + 0.5)
-                con = cn[g]
-                sigma = 0.5 * (con[None, :, 0] * dx * dx + con[None, :, 2] * dy * dy) + con[None, :, 1] * dx * dy
-                ov = op[g][None, :] * torch.exp(-sigma)
-                a = torch.clamp(ov, max=ALPHA_MAX)
-                ok = (sigma >= 0) & (a >= ALPHA_MIN)
-                a = torch.where(ok, a, torch.zeros_like(a))
-                T_after = torch.cumprod(1.0 - a, dim=1)
-                T_before = torch.cat([torch.ones_like(T_after[:, :1]), T_after[:, :-1]], dim=1)
-                contrib = ok & (T_after > T_MIN)
-                wgt = torch.where(contrib, a * T_before, torch.zeros_like(a))
-                out = wgt @ cl[g]                                    # [P,D]
-                T_fin = torch.prod(torch.where(contrib, 1.0 - a, torch.ones_like(a)), dim=1)
+                ov, a, ok, T_after, T_before, contrib, out, T_fin = blend_run(dx, dy, cn[g], op[g], cl[g])
                 kk = torch.arange(e - s)[None, :].expand_as(contrib)
                 last = torch.where(contrib, kk + s, torch.zeros_like(kk)).amax(dim=1)
                 render_parts.append((c, py, px, out, 1.0 - T_fin))
                 last_ids[c, py, px] = last.to(torch.int32)
                 if return_margin:
-                    with torch.no_grad():
-                        alive = T_before > T_MIN                      # pixel not yet terminated
-                        # was the pixel terminated by an earlier Gaussian?  then decisions don't matter
-                        term = (ok & (T_after <= T_MIN)).to(torch.int64).cumsum(1)
-                        reached = (term - (ok & (T_after <= T_MIN)).to(torch.int64)) == 0
-                        m_alpha = torch.abs(torch.clamp(ov, max=ALPHA_MAX) / ALPHA_MIN - 1.0).to(torch.float64)
-                        m_T = torch.abs(T_after / T_MIN - 1.0).to(torch.float64)
-                        m_T = torch.where(ok, m_T, torch.full_like(m_T, float("inf")))
-                        mm = torch.minimum(m_alpha, m_T)
-                        mm = torch.where(reached & alive, mm, torch.full_like(mm, float("inf")))
-                        margin[c, py, px] = mm.amin(dim=1)
+                    margin[c, py, px] = run_margin(ov, ok, T_after, T_before)
     # scatter the per-tile results with index_put (keeps autograd simple)
     if render_parts:
         ci = torch.cat([torch.full_like(p[1], p[0]) for p in render_parts])

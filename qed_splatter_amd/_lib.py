@@ -37,8 +37,8 @@ SIGNATURES = {
     "qed_tile_offsets": (C.c_int, [_P, _P, _L, _I, _I, _I, _P, _P]),
     "qed_bin_workspace_bytes": (_L, [_L, _L]),
     "qed_bin_tiles": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P]),
-    "qed_composite_fwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
-    "qed_composite_bwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "qed_composite_fwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "qed_composite_bwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "qed_loss_reduce": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qed_loss_grad": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _I, _F, _F, _P]),
     "qed_sh_grad_from_views": (C.c_int, [_I, _I, _P, _P, _L, _P, _L, _I, _F, _P, _I, _P, _I, _P]),

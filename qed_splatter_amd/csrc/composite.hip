@@ -199,7 +199,8 @@ __device__ __forceinline__ void fwd_tile(int tile, int qf, float (*s_rec)[kRecFl
                                          const int* __restrict__ flatten_ids, const int* __restrict__ offsets, int width,
                                          int height, int tile_w, int tile_h, const float* __restrict__ backgrounds,
                                          float* __restrict__ render, float* __restrict__ alpha_out,
-                                         int* __restrict__ last_ids, int* __restrict__ tile_cost, const FwdPost& post) {
+                                         float* __restrict__ t_final, int* __restrict__ last_ids,
+                                         int* __restrict__ tile_cost, const FwdPost& post) {
     const int q0 = qf & 3;                               // bit 2 of qf: culling off (test hook)
     int n_vis = 0;                                       // quadrant visits of this wave (wave-uniform): K7's work predictor
     const int n_tiles = tile_w * tile_h;
@@ -331,6 +332,9 @@ __device__ __forceinline__ void fwd_tile(int tile, int qf, float (*s_rec)[kRecFl
             }
             const float a_out = 1.f - px[q].T;
             alpha_out[pix] = a_out;
+            // the transmittance itself for the backward pass: 1 - alpha loses up to 3e-8 / T of it (alpha sits just below 1
+            // wherever the pixel saturated), and every gradient term of the pixel scales with T
+            if (t_final != nullptr) t_final[pix] = px[q].T;
             last_ids[pix] = px[q].cur;
             if (post.bg != nullptr) {
                 const float om = 1.f - a_out;            // (as the separate pass forms it from the stored alpha)
@@ -404,7 +408,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QED_K6_
 composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __restrict__ flatten_ids,
                      const int* __restrict__ offsets, int width, int height, int tile_w, int tile_h,
                      const float* __restrict__ backgrounds, float* __restrict__ render, float* __restrict__ alpha_out,
-                     int* __restrict__ last_ids, int* __restrict__ tile_cost, int n_big_flags, FwdPost post) {
+                     float* __restrict__ t_final, int* __restrict__ last_ids, int* __restrict__ tile_cost, int n_big_flags,
+                     FwdPost post) {
     __shared__ __attribute__((aligned(16))) float s_rec[kBatch][kRecFloats];
     const int n_total = C * tile_w * tile_h;
     const int b = blockIdx.x;
@@ -412,12 +417,12 @@ composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
     const int n_big = n_big_flags & 0x3fffffff;
     if (b < n_big) {
         fwd_tile<CH, 4>(xcd_remap(b, n_total), keep_all, s_rec, C, splats, flatten_ids, offsets, width, height, tile_w,
-                        tile_h, backgrounds, render, alpha_out, last_ids, tile_cost, post);
+                        tile_h, backgrounds, render, alpha_out, t_final, last_ids, tile_cost, post);
     } else {
         int t, q;
         small_wave(b - n_big, n_total - n_big, t, q);
         fwd_tile<CH, 1>(xcd_remap(n_big + t, n_total), q | keep_all, s_rec, C, splats, flatten_ids, offsets, width, height,
-                        tile_w, tile_h, backgrounds, render, alpha_out, last_ids, tile_cost, post);
+                        tile_w, tile_h, backgrounds, render, alpha_out, t_final, last_ids, tile_cost, post);
     }
 }
 
@@ -460,6 +465,9 @@ __device__ __forceinline__ void bwd_quadrant(f2 pq, f2 XY, f2 AC, float B, float
     // reciprocal is v_rcp_f32(1.0) = 1.0 exactly (scripts/ubench/rcp_one.hip checks it on the device), so T * 1 is T bit
     // for bit and the weight is 0 * T = 0
     const float a_eff = sel(m_valid, a, 0.f);
+    // (v_rcp_f32 is good to an ulp; a Newton step on it changed no gradient beyond the seventh digit even in scenes that
+    // stack hundreds of layers per pixel -- scripts/dense_scene_diag.py.  What did limit the backward pass there was
+    // T_final = 1 - alpha, see bwd_tile)
     const float ra = __builtin_amdgcn_rcpf(1.f - a_eff);
     const float Tn = s.T * ra;
     s.T = Tn;
@@ -524,7 +532,8 @@ __device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_rec)[kRecFl
                                          const float4* __restrict__ splats,
                                          const int* __restrict__ flatten_ids, const int* __restrict__ offsets, int width,
                                          int height, int tile_w, int tile_h, const float* __restrict__ backgrounds,
-                                         const float* __restrict__ render_alpha, const int* __restrict__ last_ids,
+                                         const float* __restrict__ render_alpha, const float* __restrict__ t_final,
+                                         const int* __restrict__ last_ids,
                                          const float* __restrict__ v_render, const float* __restrict__ v_alpha,
                                          float* __restrict__ vsplat, const BwdPost& post) {
     const int q0 = qf & 3;                               // bit 2 of qf: culling off (test hook)
@@ -560,7 +569,7 @@ __device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_rec)[kRecFl
         inside[q] = ix < width && iy < height;
         const size_t pix = ((size_t)cam * height + min(iy, height - 1)) * width + min(ix, width - 1);
         pix_in[q] = pix;
-        a_in[q] = render_alpha[pix];
+        a_in[q] = (t_final != nullptr ? t_final : render_alpha)[pix];      // T_final itself when the forward pass kept it
         last_in[q] = last_ids[pix];
         vra_in[q] = 0.f; vd_in[q] = 0.f; g3_in[q] = Float3{0.f, 0.f, 0.f};
     }
@@ -596,8 +605,10 @@ __device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_rec)[kRecFl
         float vr[4] = {0.f, 0.f, 0.f, 0.f};
         px[q].bin_final = -1;
         if (inside[q]) {
-            const float a_px = a_in[q];
-            T_final = 1.f - a_px;
+            // (with T_final given, 1 - T_final is the alpha the forward pass stored, bit for bit: the clamp test below takes
+            // the side the forward pass took)
+            const float a_px = t_final != nullptr ? 1.f - a_in[q] : a_in[q];
+            T_final = t_final != nullptr ? a_in[q] : 1.f - a_px;
             px[q].bin_final = last_in[q];
             if (post.bg == nullptr) {
                 vra = vra_in[q];
@@ -754,7 +765,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QED_K7_
 composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __restrict__ flatten_ids,
                      const int* __restrict__ offsets, int width, int height, int tile_w, int tile_h,
                      const float* __restrict__ backgrounds, const float* __restrict__ render_alpha,
-                     const int* __restrict__ last_ids, const float* __restrict__ v_render,
+                     const float* __restrict__ t_final, const int* __restrict__ last_ids, const float* __restrict__ v_render,
                      const float* __restrict__ v_alpha, float* __restrict__ vsplat, int n_big_flags,
                      const int* __restrict__ tile_order, const int* __restrict__ n_split_dev, BwdPost post) {
     __shared__ __attribute__((aligned(16))) float s_part[kParkSlots * kParkSlot];
@@ -771,23 +782,23 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
         const int n_split = n_split_dev[0];
         if (b < 4 * n_split) {
             bwd_tile<CH, 1>(tile_order[b >> 2], (b & 3) | keep_all, s_rec, s_part, C, splats, flatten_ids, offsets,
-                            width, height, tile_w, tile_h, backgrounds, render_alpha, last_ids, v_render, v_alpha, vsplat, post);
+                            width, height, tile_w, tile_h, backgrounds, render_alpha, t_final, last_ids, v_render, v_alpha, vsplat, post);
         } else {
             const int i = b - 3 * n_split;
             if (i >= n_total) return;                    // (the grid is sized for the largest n_split the host allows)
             bwd_tile<CH, 4>(tile_order[i], keep_all, s_rec, s_part, C, splats, flatten_ids, offsets, width, height,
-                            tile_w, tile_h, backgrounds, render_alpha, last_ids, v_render, v_alpha, vsplat, post);
+                            tile_w, tile_h, backgrounds, render_alpha, t_final, last_ids, v_render, v_alpha, vsplat, post);
         }
         return;
     }
     if (b < n_big) {
         bwd_tile<CH, 4>(xcd_remap(b, n_total), keep_all, s_rec, s_part, C, splats, flatten_ids, offsets, width, height, tile_w, tile_h,
-                        backgrounds, render_alpha, last_ids, v_render, v_alpha, vsplat, post);
+                        backgrounds, render_alpha, t_final, last_ids, v_render, v_alpha, vsplat, post);
     } else {
         int t, q;
         small_wave(b - n_big, n_total - n_big, t, q);
         bwd_tile<CH, 1>(xcd_remap(n_big + t, n_total), q | keep_all, s_rec, s_part, C, splats, flatten_ids, offsets, width, height,
-                        tile_w, tile_h, backgrounds, render_alpha, last_ids, v_render, v_alpha, vsplat, post);
+                        tile_w, tile_h, backgrounds, render_alpha, t_final, last_ids, v_render, v_alpha, vsplat, post);
     }
 }
 
@@ -957,8 +968,8 @@ static int no_cull_flag(int launch_flags) { return (launch_flags & QED_CL_NO_CUL
 extern "C" int qed_composite_fwd(int32_t C, int32_t N, const float* splats, const int32_t* flatten_ids,
                                  const int32_t* offsets, int32_t width, int32_t height, int32_t tile_w,
                                  int32_t tile_h, int32_t channels, const float* backgrounds, float* render,
-                                 float* alpha, int32_t* last_ids, int32_t* tile_cost, const qed_post_t* post,
-                                 int32_t launch_flags, void* stream) {
+                                 float* alpha, float* t_final, int32_t* last_ids, int32_t* tile_cost,
+                                 const qed_post_t* post, int32_t launch_flags, void* stream) {
     QED_REQUIRE(C >= 1 && N >= 0 && width > 0 && height > 0, "bad extents");
     QED_REQUIRE(channels == 3 || channels == 4, "channels must be 3 (RGB) or 4 (RGB+D)");
     QED_REQUIRE(tile_w == (width + QED_TILE - 1) / QED_TILE && tile_h == (height + QED_TILE - 1) / QED_TILE,
@@ -979,11 +990,11 @@ extern "C" int qed_composite_fwd(int32_t C, int32_t N, const float* splats, cons
     const unsigned blocks = (unsigned)(n_big + 4 * (grid - n_big));
     if (channels == 4)
         hipLaunchKernelGGL(composite_fwd_kernel<4>, dim3(blocks), dim3(64), 0, st, C, (const float4*)splats,
-                           flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render, alpha, last_ids,
+                           flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render, alpha, t_final, last_ids,
                            tile_cost, (int)n_big | no_cull_flag(launch_flags), fp);
     else
         hipLaunchKernelGGL(composite_fwd_kernel<3>, dim3(blocks), dim3(64), 0, st, C, (const float4*)splats,
-                           flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render, alpha, last_ids,
+                           flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render, alpha, t_final, last_ids,
                            tile_cost, (int)n_big | no_cull_flag(launch_flags), fp);
     if (post != nullptr && channels == 4) {
         const long long n_pix = (long long)C * width * height;
@@ -999,8 +1010,8 @@ extern "C" int qed_composite_fwd(int32_t C, int32_t N, const float* splats, cons
 extern "C" int qed_composite_bwd(int32_t C, int32_t N, const float* splats, const int32_t* flatten_ids,
                                  const int32_t* offsets, int32_t width, int32_t height, int32_t tile_w,
                                  int32_t tile_h, int32_t channels, const float* backgrounds,
-                                 const float* render_alpha, const int32_t* last_ids, const float* v_render,
-                                 const float* v_alpha, float* vsplat, const int32_t* tile_cost,
+                                 const float* render_alpha, const float* t_final, const int32_t* last_ids,
+                                 const float* v_render, const float* v_alpha, float* vsplat, const int32_t* tile_cost,
                                  int32_t* order_ws, const qed_post_grad_t* post, int32_t launch_flags, void* stream) {
     QED_REQUIRE(C >= 1 && N >= 0 && width > 0 && height > 0, "bad extents");
     QED_REQUIRE(channels == 3 || channels == 4, "channels must be 3 (RGB) or 4 (RGB+D)");
@@ -1039,12 +1050,12 @@ extern "C" int qed_composite_bwd(int32_t C, int32_t N, const float* splats, cons
     }
     if (channels == 4)
         hipLaunchKernelGGL(composite_bwd_kernel<4>, dim3(blocks), dim3(64), 0, st, C, (const float4*)splats,
-                           flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render_alpha, last_ids,
+                           flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render_alpha, t_final, last_ids,
                            v_render, v_alpha, vsplat, (int)n_big | no_cull_flag(launch_flags), tile_order,
                            tile_order ? tile_order + grid : nullptr, bp);
     else
         hipLaunchKernelGGL(composite_bwd_kernel<3>, dim3(blocks), dim3(64), 0, st, C, (const float4*)splats,
-                           flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render_alpha, last_ids,
+                           flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render_alpha, t_final, last_ids,
                            v_render, v_alpha, vsplat, (int)n_big | no_cull_flag(launch_flags), tile_order,
                            tile_order ? tile_order + grid : nullptr, bp);
     return check_launch("qed_composite_bwd");

@@ -160,6 +160,10 @@ _NO_MASKS: "Dict[torch.device, Tensor]" = {}
 # kernels, which direct C-ABI callers without the planes still get, under the same parity checks)
 SH_HANDOVER = True
 
+# qed_composite_fwd's t_final image for qed_composite_bwd (tests switch it off to keep gsplat's T_final = 1 - alpha
+# under the same parity checks; see tests/test_gpu_parity.py::test_dense_scene_gradients_against_the_fp32_band)
+KEEP_T_FINAL = True
+
 
 def _workspace(device) -> _Workspace:
     idx = device.index if device.index is not None else torch.cuda.current_device()
@@ -416,9 +420,12 @@ class _Composite(torch.autograd.Function):
         last_ids = torch.empty(C, height, width, dtype=torch.int32, device=dev)
         bg = _f32c(backgrounds, "backgrounds") if backgrounds is not None else None
         # per-tile work counts of this pass: the backward pass hands its tiles out costliest first (qed_composite_bwd)
-        tile_cost = None
+        tile_cost = t_final = None
         if any(ctx.needs_input_grad[:5]):
             tile_cost = torch.empty(C * tile_w * tile_h, 4, dtype=torch.int32, device=dev)
+            # the final transmittances themselves for the backward pass (1 - alpha keeps only ~3e-8 / T of them)
+            if KEEP_T_FINAL:
+                t_final = torch.empty(C, height, width, dtype=torch.float32, device=dev)
         # get_outputs' post-processing (model.py:295-297, 304-306) inside the same launch: rgb, depth as extra outputs
         post, post_rgb, post_depth, pbg = None, None, None, None
         if post_background is not None:
@@ -431,11 +438,12 @@ class _Composite(torch.autograd.Function):
                 dmax = torch.empty(C * tile_w * tile_h * 4, dtype=torch.float32, device=dev)
                 post.depth, post.tile_dmax = post_depth.data_ptr(), dmax.data_ptr()
         L.check(lib.qed_composite_fwd(C, N, L.ptr(splats), L.ptr(flatten_ids), L.ptr(offsets), width, height, tile_w,
-                                      tile_h, channels, L.ptr(bg), L.ptr(render), L.ptr(alpha), L.ptr(last_ids),
-                                      L.ptr(tile_cost), C_byref(post), L.composite_launch_flags(), _stream()),
+                                      tile_h, channels, L.ptr(bg), L.ptr(render), L.ptr(alpha), L.ptr(t_final),
+                                      L.ptr(last_ids), L.ptr(tile_cost), C_byref(post), L.composite_launch_flags(), _stream()),
                 "qed_composite_fwd")
         ctx.tile_cost = tile_cost
-        ctx.save_for_backward(splats, flatten_ids, offsets, alpha, last_ids, bg, render if post is not None else None, pbg)
+        ctx.save_for_backward(splats, flatten_ids, offsets, alpha, last_ids, bg, render if post is not None else None, pbg,
+                              t_final)
         ctx.meta = (C, N, width, height, tile_w, tile_h, channels, absgrad)
         ctx.means2d_ref = means2d
         ctx.mark_non_differentiable(last_ids)
@@ -448,7 +456,7 @@ class _Composite(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_render, v_alpha, _v_last, v_rgb=None, v_depth=None):
         lib = L.load()
-        splats, flatten_ids, offsets, alpha, last_ids, bg, render, pbg = ctx.saved_tensors
+        splats, flatten_ids, offsets, alpha, last_ids, bg, render, pbg, t_final = ctx.saved_tensors
         C, N, width, height, tile_w, tile_h, channels, absgrad = ctx.meta
         dev = splats.device
         post = None
@@ -484,11 +492,12 @@ class _Composite(torch.autograd.Function):
         tile_cost = ctx.tile_cost
         order_ws = torch.empty(C * tile_w * tile_h + 1, dtype=torch.int32, device=dev) if tile_cost is not None else None
         L.check(lib.qed_composite_bwd(C, N, L.ptr(splats), L.ptr(flatten_ids), L.ptr(offsets), width, height, tile_w,
-                                      tile_h, channels, L.ptr(bg), L.ptr(alpha), L.ptr(last_ids),
+                                      tile_h, channels, L.ptr(bg), L.ptr(alpha), L.ptr(t_final), L.ptr(last_ids),
                                       L.ptr(v_render) if post is None else None, L.ptr(v_alpha) if post is None else None,
                                       L.ptr(vsplat), L.ptr(tile_cost), L.ptr(order_ws), C_byref(post),
                                       L.composite_launch_flags(), _stream()),
                 "qed_composite_bwd")
+        ctx.order_ws = order_ws                  # (tests read the launch order: render.grad_fn.order_ws)
         v3 = vsplat.view(C, N, R)
         v_means2d = v3[..., 0:2]
         v_conics = v3[..., 4:7]

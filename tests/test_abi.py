@@ -44,7 +44,7 @@ def test_host_only_entry_points(lib):
 
 def test_argument_validation_needs_no_gpu(lib):
     """Invalid arguments are rejected on the host before any launch, with a readable message."""
-    rc = lib.qed_composite_fwd(1, 0, 0, 0, 0, 64, 64, 4, 4, 5, 0, 0, 0, 0, 0, 0, 0, 0)   # channels = 5
+    rc = lib.qed_composite_fwd(1, 0, 0, 0, 0, 64, 64, 4, 4, 5, 0, 0, 0, 0, 0, 0, 0, 0, 0)   # channels = 5
     assert rc == -1 and b"channels" in lib.qed_last_error()
     rc = lib.qed_sort_pairs(0, 0, 0, 0, 0, 100, 0, 0, 0, 0, 0)                     # end_bit = 0
     assert rc == -1 and b"end_bit" in lib.qed_last_error()

@@ -344,6 +344,108 @@ def test_absgrad_matches_per_pixel_sum(cuda):
     assert_close(absg, acc, 1e-4, "absgrad")
 
 
+def test_dense_scene_gradients_need_the_forward_pass_t_final(cuda, monkeypatch):
+    """Sweep case 112 (4 709 Gaussians on 122 x 40 pixels, antialiased: hundreds of layers per pixel, T_final ~ 1e-4 .. 1e-3)
+    is where round 3 left a violation standing: the `means` gradient of one Gaussian off by 2.5e-4 of the group's largest,
+    diagnosed as "fp32 accumulation".  It was not: the SAME oracle evaluated in fp32 lands within 4e-7 of the fp64 one.
+    The backward pass took T_final from 1 - alpha (as gsplat's does); alpha sits just below 1 in a saturated pixel, so
+    that difference keeps only 3e-8 / T_final of T_final, and every gradient term of the pixel scales with it.  With the
+    forward pass's own T_final (qed_composite_fwd's t_final) the compositing backward is as close to fp64 as the fp32
+    oracle is.  Here: (i) K7 alone on the GPU's own projected splats against the fp64 oracle, inside 10 x the fp32
+    oracle's own distance (and 1e-5); (ii) the same launch with t_final withheld is >= 20 x further off -- the reason the
+    image exists; (iii) the whole fused step against the fp64 oracle at the north_star's 1e-4, every Gaussian compared."""
+    from qed_splatter_amd import rasterization as R
+    from qed_splatter_amd.model import PinholeCameras, QEDSplatterModel, QEDSplatterModelConfig
+    from tests.util import sweep_case, sweep_nonsmooth_pixels
+    cs = sweep_case(112)
+    sc, w, h, n, deg, mode = cs["sc"], cs["w"], cs["h"], cs["n"], cs["deg"], cs["mode"]
+    assert (w, h, n, deg, mode) == (122, 40, 4709, 2, "antialiased")
+
+    def k7_errors(keep_t_final):
+        monkeypatch.setattr(R, "KEEP_T_FINAL", keep_t_final)
+        a = to_dev(activated(sc, torch.float32), cuda)
+        for k in ("means", "quats", "scales", "opacities", "colors"):
+            a[k].requires_grad_(True)
+        render, alpha, info = R.rasterization(
+            means=a["means"], quats=a["quats"], scales=a["scales"], opacities=a["opacities"],
+            colors=a["colors"][:, : (deg + 1) ** 2], viewmats=a["viewmats"], Ks=a["Ks"], width=w, height=h,
+            render_mode="RGB+D", sh_degree=deg, absgrad=True, rasterize_mode=mode)
+
+        def oracle(dt):
+            ins = [info[k].detach().cpu().to(dt).requires_grad_(True) for k in ("means2d", "conics", "opacities")]
+            col = torch.cat([info["colors"].detach().cpu(), info["depths"].detach().cpu()[..., None]], -1).to(dt).requires_grad_(True)
+            r, al, _, margin = O.composite_tiles(ins[0], ins[1], col, ins[2], w, h, 16, info["isect_offsets"].cpu(),
+                                                 info["flatten_ids"].cpu(), return_margin=True)
+            return ins + [col], r, al, margin
+
+        ins64, r64, a64, margin = oracle(torch.float64)
+        assert float((1 - a64.detach()).mean()) < 2e-3                    # the scene saturates nearly everywhere
+        g = torch.Generator().manual_seed(1)
+        safe = (margin > MARGIN)[..., None].double()
+        v_r = torch.randn(r64.shape, generator=g, dtype=torch.float64) * safe
+        v_a = torch.randn(a64.shape, generator=g, dtype=torch.float64) * safe
+        (r64 * v_r).sum().add((a64 * v_a).sum()).backward()
+        ins32, r32, a32, _ = oracle(torch.float32)
+        (r32 * v_r.float()).sum().add((a32 * v_a.float()).sum()).backward()
+        grads = torch.autograd.grad((render * v_r.to(cuda, torch.float32)).sum() + (alpha * v_a.to(cuda, torch.float32)).sum(),
+                                    [info["means2d"], info["conics"], info["opacities"], info["colors"], info["depths"]])
+        out = {}
+        for name, gg, b, f in zip(("v_means2d", "v_conics", "v_opacities", "v_colors", "v_depths"), grads,
+                                  [ins64[0].grad, ins64[1].grad, ins64[2].grad, ins64[3].grad[..., :3], ins64[3].grad[..., 3]],
+                                  [ins32[0].grad, ins32[1].grad, ins32[2].grad, ins32[3].grad[..., :3], ins32[3].grad[..., 3]]):
+            out[name] = (max_rel_(gg, b), max_rel_(f, b))
+        return out
+
+    def max_rel_(x, b):
+        return float((x.detach().cpu().double() - b).abs().max() / b.abs().max())
+
+    with_t, without_t = k7_errors(True), k7_errors(False)
+    for name in with_t:
+        e, band = with_t[name]
+        print(f"[parity] dense scene, K7 alone, {name:12s}: HIP {e:.2e}  fp32 oracle {band:.2e}  HIP with T_final = 1 - alpha {without_t[name][0]:.2e}")
+        assert e <= max(10 * band, 2e-6) and e <= 1e-5, (name, e, band)
+    assert without_t["v_means2d"][0] >= 20 * with_t["v_means2d"][0]
+    monkeypatch.setattr(R, "KEEP_T_FINAL", True)
+
+    # (iii) the whole fused training step, threshold pixels masked on both sides, every Gaussian compared
+    cfg = QEDSplatterModelConfig.synthetic(sh_degree=3, sh_degree_interval=1, rasterize_mode=mode)
+    K = sc["Ks"][0]
+    cam = PinholeCameras(sc["camera_to_worlds"].to(cuda), float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), w, h)
+    batch = {"image": sc["gt_rgb"].to(cuda), "depth_image": sc["gt_depth"].to(cuda)}
+    model = QEDSplatterModel(cfg, **{k: sc[k].to(cuda) for k in PARAM_NAMES})
+    model.step = deg
+    with torch.no_grad():
+        model.fused_loss(cam, batch)
+    radii = model.info["radii"].cpu()
+
+    def oracle_step(dt, mask=None):
+        ps = {k: sc[k].detach().clone().to(dt).requires_grad_(True) for k in PARAM_NAMES}
+        out = O.splatfacto_outputs(ps["means"], ps["scales"], ps["quats"], ps["opacities"], ps["features_dc"], ps["features_rest"],
+                                   sc["camera_to_worlds"].to(dt), sc["Ks"].to(dt), w, h, sc["background"].to(dt),
+                                   sh_degree_to_use=deg, rasterize_mode=mode, radii_override=radii, return_margin=True)
+        if mask is not None:
+            l_rgb = O.main_loss(out["rgb"], sc["gt_rgb"].to(dt), cfg.ssim_lambda, mask.to(dt))
+            l_d = O.depth_l1_loss(out["depth"], sc["gt_depth"].to(dt), mask.to(dt), cfg.depth_lambda)
+            (l_rgb + l_d).backward()
+        return out, ps
+
+    out, _ = oracle_step(torch.float64)
+    bad_px, _ = sweep_nonsmooth_pixels(out, sc)
+    mask = (~bad_px)[..., None].double()
+    assert float(mask.mean()) > 0.99
+    _, ps64 = oracle_step(torch.float64, mask)
+    _, ps32 = oracle_step(torch.float32, mask)
+    batch["mask"] = mask.to(cuda, torch.float32)
+    losses = model.fused_loss(cam, batch)
+    model.backward_fused(losses)
+    assert torch.equal(model.info["radii"].cpu(), radii)
+    for name in PARAM_NAMES:
+        b = ps64[name].grad
+        e, band = max_rel_(model.gauss_params[name].grad, b), max_rel_(ps32[name].grad, b)
+        print(f"[parity] dense scene, fused step, grad {name:14s}: HIP {e:.2e}  fp32 oracle {band:.2e}")
+        assert e <= REL_TOL, (name, e, band)
+
+
 # --------------------------------------------------------------------------------------------------
 # K1/K2 backward
 # --------------------------------------------------------------------------------------------------
@@ -436,7 +538,7 @@ def test_viewmat_gradient(cuda):
     ref = dict(means2d=m2, depths=depths, conics=conics, colors=cols)
     vm = vis.double()
     sum((ref[k] * ups[k].double() * (vm[..., None] if ref[k].dim() == 3 else vm)).sum() for k in ups).backward()
-    assert_close(gv[:, :3, :], ad["viewmats"].grad[:, :3, :], 5e-4, "v_viewmats")
+    assert_close(gv[:, :3, :], ad["viewmats"].grad[:, :3, :], REL_TOL, "v_viewmats")
 
 
 # --------------------------------------------------------------------------------------------------
@@ -686,8 +788,8 @@ def test_tight_tile_lists_change_nothing_but_the_lists(cuda, monkeypatch):
     assert int(lists[0][2].sum()) == lists[0][0].numel() and int(lists[0][2][1].sum()) > 0
     # (the same terms summed by float atomics in another order; the forty screen-filling Gaussians sum tens of thousands)
     for k in PARAM_NAMES:
-        assert_close(g1[k], g0[k], 2.5e-4, f"grad {k} (tight vs full lists)")     # (4.8e-5 seen; the order differs run to run)
-        assert_close(g2[k], g0[k], 2.5e-4, f"grad {k} (exact vs full lists)")
+        assert_close(g1[k], g0[k], REL_TOL, f"grad {k} (tight vs full lists)")
+        assert_close(g2[k], g0[k], REL_TOL, f"grad {k} (exact vs full lists)")
 
 
 def test_fused_path_equals_api_path(cuda):
@@ -1123,11 +1225,13 @@ def test_golden_fixtures(cuda, name):
     assert_close(out["accumulation"].cpu()[safe], torch.from_numpy(c["accumulation"])[safe], REL_TOL, "accumulation")
     assert abs(float(ld["main_loss"].detach()) - float(c["loss_rgb"])) <= 1e-4 * float(c["loss_rgb"])
     assert abs(float(ld["depth_loss"].detach()) - float(c["loss_depth"])) <= 1e-4 * float(c["loss_depth"])
-    tol = REL_TOL if bool(safe.all()) else 1e-3
+    # every pixel of the committed fixtures is clear of the alpha / T cuts (the generator checks it), so the gradients
+    # are held to the north_star's tolerance with nothing left out
+    assert bool(safe.all()), "a golden fixture with a threshold pixel: regenerate it (tests/golden/make_golden.py)"
     for k in PARAM_NAMES:
         if c[f"grad_{k}"].size:
-            assert_close(m.gauss_params[k].grad, torch.from_numpy(c[f"grad_{k}"]), tol, f"grad {k}")
-    assert_close(m.xys.grad, torch.from_numpy(c["means2d_grad"]), tol, "means2d.grad (retain_grad, model.py:289-290)")
+            assert_close(m.gauss_params[k].grad, torch.from_numpy(c[f"grad_{k}"]), REL_TOL, f"grad {k}")
+    assert_close(m.xys.grad, torch.from_numpy(c["means2d_grad"]), REL_TOL, "means2d.grad (retain_grad, model.py:289-290)")
 
 
 def test_graphed_step_matches_eager(cuda):
@@ -1276,7 +1380,7 @@ def test_backward_tile_order_is_costliest_first_and_changes_no_gradient(cuda, li
     cost = torch.full((T, 4), -7, dtype=torch.int32, device=cuda)
     st = _stream()
     L.check(lib.qed_composite_fwd(1, n, L.ptr(splats), L.ptr(fid), L.ptr(offs), w, h, tw, th, 4, None, L.ptr(render),
-                                  L.ptr(alpha), L.ptr(last), L.ptr(cost), None, 0, st), "fwd")
+                                  L.ptr(alpha), None, L.ptr(last), L.ptr(cost), None, 0, st), "fwd")
     c = cost.sum(dim=1).cpu()
     assert int(cost.min()) >= 0 and int(c.sum()) > 0                  # every tile's entry was written
     lens = (offs[1:] - offs[:-1]).cpu()
@@ -1284,7 +1388,7 @@ def test_backward_tile_order_is_costliest_first_and_changes_no_gradient(cuda, li
     # the same image with and without the cost output
     r2 = torch.empty_like(render)
     L.check(lib.qed_composite_fwd(1, n, L.ptr(splats), L.ptr(fid), L.ptr(offs), w, h, tw, th, 4, None, L.ptr(r2),
-                                  L.ptr(alpha), L.ptr(last), None, None, 0, st), "fwd")
+                                  L.ptr(alpha), None, L.ptr(last), None, None, 0, st), "fwd")
     assert torch.equal(r2, render)
     g = torch.Generator().manual_seed(4)
     v_r = torch.randn(1, h, w, 4, generator=g).to(cuda)
@@ -1294,7 +1398,7 @@ def test_backward_tile_order_is_costliest_first_and_changes_no_gradient(cuda, li
     for with_order in (False, True):
         vs = torch.zeros(n, L.VSPLAT_FLOATS, device=cuda)
         L.check(lib.qed_composite_bwd(1, n, L.ptr(splats), L.ptr(fid), L.ptr(offs), w, h, tw, th, 4, None, L.ptr(alpha),
-                                      L.ptr(last), L.ptr(v_r), L.ptr(v_a), L.ptr(vs), L.ptr(cost) if with_order else None,
+                                      None, L.ptr(last), L.ptr(v_r), L.ptr(v_a), L.ptr(vs), L.ptr(cost) if with_order else None,
                                       L.ptr(order_ws) if with_order else None, None, 0, st), "bwd")
         outs.append(vs)
     torch.cuda.synchronize()
@@ -1310,7 +1414,7 @@ def test_backward_tile_order_is_costliest_first_and_changes_no_gradient(cuda, li
     assert scale > 0 and float((outs[0] - outs[1]).abs().max()) <= 2e-5 * scale
     with pytest.raises(L.QedSplatError):                               # the two buffers go together
         L.check(lib.qed_composite_bwd(1, n, L.ptr(splats), L.ptr(fid), L.ptr(offs), w, h, tw, th, 4, None, L.ptr(alpha),
-                                      L.ptr(last), L.ptr(v_r), L.ptr(v_a), L.ptr(outs[0]), L.ptr(cost), None, None, 0, st), "bwd")
+                                      None, L.ptr(last), L.ptr(v_r), L.ptr(v_a), L.ptr(outs[0]), L.ptr(cost), None, None, 0, st), "bwd")
 
 
 @pytest.mark.parametrize("tight", [True, False])

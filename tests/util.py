@@ -98,3 +98,61 @@ def threshold_pixel_mask(ref, gt_rgb, gt_depth, margin_tol, edge_tol=1e-6):
     if ref.get("depth") is not None and gt_depth is not None:
         kink = kink | ((ref["depth"].detach() - gt_depth.to(pre.dtype)).abs() < edge_tol)[..., 0]
     return (safe & ~edge & ~kink)[..., None].to(torch.float64)
+
+
+def sweep_case(case: int, scale_boost: float = 2.5, cam_k: int = 0):
+    """Scene ``case`` of the randomised end-to-end sweep (scripts/parity_sweep.py draws exactly this; the fixed GPU
+    tests re-create single cases of it).  Returns dict(sc, w, h, n, deg, mode, use_mask, gen, n_moved, pre): the two
+    per-GAUSSIAN non-smooth points (the SH colour clamp max(0, c + 0.5), the Jacobian clamp at the frustum rim) are
+    moved off their edge in the scene before either side runs; ``gen`` is the case's generator after the scene draws
+    (the sweep draws its random mask from it)."""
+    g = torch.Generator().manual_seed(2024 + 7919 * case)
+    w = int(torch.randint(40, 260, (1,), generator=g)); h = int(torch.randint(33, 200, (1,), generator=g))
+    n = int(torch.randint(200, 6000, (1,), generator=g))
+    deg = int(torch.randint(0, 4, (1,), generator=g))
+    mode = "antialiased" if case % 3 == 1 else "classic"
+    use_mask = case % 4 == 2
+    sc = O.synthetic_scene(n, w, h, seed=1000 + case, n_cameras=cam_k + 1)
+    sc["camera_to_worlds"] = sc["camera_to_worlds"][cam_k:cam_k + 1]
+    sc["Ks"] = sc["Ks"][:1]
+    sc["scales"] = sc["scales"] + float(torch.rand(1, generator=g)) * scale_boost      # up to e^boost x larger splats
+    sc["opacities"] = sc["opacities"] + (float(torch.rand(1, generator=g)) - 0.7) * 4
+    K = sc["Ks"][0]
+    pre = None
+    with torch.no_grad():
+        vm = O.get_viewmat(sc["camera_to_worlds"].double())
+        campos = torch.linalg.inv(vm)[0, :3, 3]
+        fx, fy, cx, cy = K[0, 0].item(), K[1, 1].item(), K[0, 2].item(), K[1, 2].item()
+        lxp, lxn = (w - cx) / fx + 0.3 * 0.5 * w / fx, cx / fx + 0.3 * 0.5 * w / fx
+        lyp, lyn = (h - cy) / fy + 0.3 * 0.5 * h / fy, cy / fy + 0.3 * 0.5 * h / fy
+        n_moved = 0
+        for _ in range(4):
+            coeffs = torch.cat([sc["features_dc"].double()[:, None, :], sc["features_rest"].double()], dim=1)
+            pre = O.eval_sh(deg, sc["means"].double() - campos, coeffs[:, : (deg + 1) ** 2]) + 0.5
+            near_clamp = pre.abs().min(dim=-1).values < 1e-4
+            pc = (vm[0, :3, :3] @ sc["means"].double().T).T + vm[0, :3, 3]
+            rx, ry = pc[:, 0] / pc[:, 2], pc[:, 1] / pc[:, 2]
+            near_jac = ((rx - lxp).abs() < 1e-5) | ((rx + lxn).abs() < 1e-5) | ((ry - lyp).abs() < 1e-5) | ((ry + lyn).abs() < 1e-5)
+            if not bool((near_clamp | near_jac).any()):
+                break
+            n_moved += int((near_clamp | near_jac).sum())
+            sc["features_dc"][near_clamp] += 1e-2 / O.SH_C0
+            sc["means"][near_jac] *= 1.0 + 1e-3
+    return dict(sc=sc, w=w, h=h, n=n, deg=deg, mode=mode, use_mask=use_mask, gen=g, n_moved=n_moved, pre=pre)
+
+
+def sweep_nonsmooth_pixels(out, sc, margin=1e-4, kink_scale=1.0):
+    """[H,W] bool: pixels of an oracle forward (splatfacto_outputs(..., return_margin=True)) at which the fp32 kernels
+    and the fp64 oracle may legitimately take DIFFERENT sides of a non-smooth point (what the sweeps put into
+    batch["mask"]): an alpha / T decision within ``margin`` of its cut, a pre-clamp colour within 2e-6 of 0 or 1, a
+    prediction within rounding of its target (the kinks of the two L1 terms)."""
+    with torch.no_grad():
+        bad = ~(out["info"]["margin"][0] > margin)
+        pre_rgb = out["render"][0, ..., :3] + (1 - out["accumulation"]) * sc["background"].double()
+        near = torch.minimum(pre_rgb.abs(), (pre_rgb - 1).abs())
+        edge = ((near < 2e-6 * kink_scale) & (near > 0)).any(dim=-1)       # exactly 0 (empty pixel): same on both sides
+        if out.get("depth") is not None:
+            dd = (out["depth"] - sc["gt_depth"].double()).abs()[..., 0]
+            edge |= (dd < 4e-6 * kink_scale * sc["gt_depth"].double()[..., 0].abs()) & (sc["gt_depth"][..., 0] > 0)
+        edge |= ((out["rgb"] - sc["gt_rgb"].double()).abs() < 2e-6 * kink_scale).any(dim=-1)
+    return bad | edge, int(edge.sum())
