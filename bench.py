@@ -408,7 +408,7 @@ def main():
     use_graph = args.graph if args.graph is not None else True
     split = use_graph and (multi or args.graph_split)
     run = lambda: step(args.sync_m)
-    dispatch = "eager"
+    dispatch, graphs = "eager", []
     if use_graph:
         from qed_splatter_amd.graph import GraphedTrainStep
 
@@ -439,12 +439,15 @@ def main():
             adam_only()
             return losses
 
-        opt.dev_state[0] = float(opt.t)               # hand the step counter over to the device-side state
-        try:
+        def capture_all():
+            """(run, dispatch, graphs): every graph of the step captured afresh -- also after an intersection overflow, when
+            the forward+backward graph gets new (larger) buffers and with them new static .grad tensors the optimiser
+            graphs must read."""
+            opt.dev_state[0] = float(opt.t)           # hand the step counter over to the device-side state
             if split:
                 g_fb = GraphedTrainStep(fwd_bwd, dev, warmup=3, check_every=0)
                 g_fb.replay()                          # fills the captured (static) .grad buffers before Adam's
-                graphed = g_fb                         # warm-up run reads them; keep the replicas identical
+                                                       # warm-up run reads them; keep the replicas identical
                 if multi and dp_compact:
                     ex = exchange_grads_compact_begin(model, world)
                     ex.wait_views()
@@ -452,26 +455,26 @@ def main():
                     g_sh = GraphedTrainStep(adam_sh_part, dev, warmup=1, check_every=0)
                     g_lead = GraphedTrainStep(adam_leading_part, dev, warmup=1, check_every=0)
 
-                    def run():
+                    def run_():
                         g_fb.replay()
                         exchange_and_step(g_sh.replay, g_lead.replay, None)
-                    dispatch = ("three hipGraphs (fwd+bwd | Adam SH groups | Adam leading groups): all-gather, SH groups "
-                                "behind it while the geometry all-reduce is on the links, leading groups")
-                else:
+                    return run_, ("three hipGraphs (fwd+bwd | Adam SH groups | Adam leading groups): all-gather, SH groups "
+                                  "behind it while the geometry all-reduce is on the links, leading groups"), [g_fb, g_sh, g_lead]
+                if multi:
+                    allreduce_flat_grad(model, world)
+                g_adam = GraphedTrainStep(adam_only, dev, warmup=1, check_every=0)
+
+                def run_():
+                    g_fb.replay()
                     if multi:
                         allreduce_flat_grad(model, world)
-                    g_adam = GraphedTrainStep(adam_only, dev, warmup=1, check_every=0)
+                    g_adam.replay()
+                return run_, "two hipGraphs (fwd+bwd | Adam) around the gradient all-reduce", [g_fb, g_adam]
+            g = GraphedTrainStep(graph_step, dev, warmup=3, check_every=0)
+            return g.replay, "hipGraph replay of the whole step", [g]
 
-                    def run():
-                        g_fb.replay()
-                        if multi:
-                            allreduce_flat_grad(model, world)
-                        g_adam.replay()
-                    dispatch = "two hipGraphs (fwd+bwd | Adam) around the gradient all-reduce"
-            else:
-                graphed = GraphedTrainStep(graph_step, dev, warmup=3, check_every=0)
-                run = graphed.replay
-                dispatch = "hipGraph replay of the whole step"
+        try:
+            run, dispatch, graphs = capture_all()
             captured = True
         except Exception as e:                         # capture is an optimisation of dispatch only
             log(f"graph capture failed ({type(e).__name__}: {e})")
@@ -488,25 +491,61 @@ def main():
             use_graph, dispatch = False, "eager (graph capture failed)"
             run = lambda: step(args.sync_m)
 
+    from qed_splatter_amd.rasterization import _workspace as _ws_of
+    ws = _ws_of(dev)
+    overflows_seen = ws.overflows
+
+    def replays_had_room() -> bool:
+        """True when no replay since the last call overflowed the captured intersection buffer ON ANY RANK.  A replay that
+        overflows renders an empty frame and its optimiser launches are no-ops on the device -- a FASTER step: a region that
+        contains one is not a measurement.  Otherwise: every graph is captured again with room (on every rank: the
+        decision is collective, the ranks must keep issuing the same collectives) and the caller times the region again."""
+        nonlocal run, dispatch, graphs, overflows_seen
+        if use_graph:
+            graphs[0].check()                          # (reads the overflow word; grows the capacity and re-captures itself)
+        else:
+            torch.cuda.synchronize()
+            ws.poll_pending()
+        had = int(ws.overflows != overflows_seen)
+        overflows_seen = ws.overflows
+        if dist is not None:
+            t = torch.tensor([had], device=dev, dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            had = int(t)
+        if had and use_graph:
+            log("an intersection overflow during the replays: all graphs captured again, region repeated")
+            run, dispatch, graphs = capture_all()
+        return not had
+
     def rewind():
         """Back to the initial scene + W warm-up steps: what precedes every timed region."""
         restore()
         for _ in range(args.warmup):
             run()
-        if use_graph:
-            graphed.check()
+        for _ in range(3):
+            if replays_had_room():
+                return
+            restore()
+            for _ in range(args.warmup):
+                run()
+        raise SystemExit("bench: intersection overflows persisted through three re-captures")
 
-    rewind()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    t_issue = time.perf_counter() - t0               # host time to enqueue the steps (logged, not reported)
-    barrier()
-    dt2 = time.perf_counter() - t0
-    log(f"host enqueue time {t_issue / args.steps * 1e3:.3f} ms/step")
-    if use_graph:
-        graphed.check()                                # no intersection overflow during the timed replays
+    overflows_before = ws.overflows
+    for attempt in range(3):
+        rewind()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        t_issue = time.perf_counter() - t0               # host time to enqueue the steps (logged, not reported)
+        barrier()
+        dt2 = time.perf_counter() - t0
+        log(f"host enqueue time {t_issue / args.steps * 1e3:.3f} ms/step")
+        # a region in which a replay overflowed trained on empty frames with the optimiser skipped: not a measurement
+        if replays_had_room():
+            break
+    else:
+        raise SystemExit("bench: every attempt at the timed region contained an intersection overflow")
     if dist is not None:
         t = torch.tensor([dt2], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -596,7 +635,10 @@ def main():
                        if world > 1 else ("single (QED_BENCH_RCCL_SELF: the N > 1 exchange path through RCCL in a group of one rank)"
                                           if rccl_self else "single"),
                        "async_intersection_count": not args.sync_m,
-                       "dispatch": dispatch},
+                       "dispatch": dispatch,
+                       # frames that overflowed the intersection buffer anywhere in this run (a region that held one was
+                       # timed again: see replays_had_room)
+                       "intersection_overflows": ws.overflows - overflows_before},
             "msplats_per_s": n_vis * world / (dt2 / args.steps) / 1e6,
             # Msplats rasterized / s = N_visible / t_fwd (t_fwd = projection + binning + compositing
             # forward, HIP-event sums of the instrumented region), the list rate M / t_fwd, and the step rate

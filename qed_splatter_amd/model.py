@@ -209,6 +209,56 @@ def _ssim_key(pred: Tensor, gt: Tensor):
     return (pred.data_ptr(), pred._version, tuple(pred.shape), gt.data_ptr(), gt._version, tuple(gt.shape))
 
 
+class StepContext:
+    """What the calls of ONE training step share about it -- created by ``get_outputs`` (or ``fused_loss``), read by
+    ``get_metrics_dict`` / ``get_loss_dict`` / the backward pass, and replaced by the next ``get_outputs``.  Everything in
+    here is an OPTIMISATION of work that the calls can also do on their own (a conversion of the batch, an SSIM forward
+    pass, a zero-filled accumulator), so every consumer falls back to the full computation when the context is not its
+    own -- ``outputs`` of an earlier step, a second ``get_loss_dict`` on the same outputs, metrics taken under ``no_grad``:
+
+      * ``rgb``: the very tensor this step's ``get_outputs`` returned as ``outputs["rgb"]`` -- ``owns(outputs)`` is an
+        identity test, so ``outputs`` kept from an earlier step never pick up this step's state;
+      * ``gt_image(...)``: the last conversion of a batch image (uint8 -> float, downscaling, device), keyed by the source
+        tensor's identity, version and the downscale factor -- get_metrics_dict and get_loss_dict prepare the same image;
+      * ``ssim``: get_metrics_dict's SSIM forward on (rgb, ground truth) with the maps and sums the loss needs -- taken ONCE
+        (``take_ssim``) and checked against the tensors the loss is actually handed before it is used;
+      * ``take_accumulator()``: (holder, rows) through which the loss's backward launch hands the compositing backward a
+        zero-filled gradient accumulator -- once; a second loss on the same outputs makes the backward pass fill its own."""
+
+    __slots__ = ("rgb", "_holder", "_rows", "_gt", "ssim")
+
+    def __init__(self):
+        self.rgb = None
+        self._holder, self._rows = None, 0
+        self._gt = None
+        self.ssim = None
+
+    def owns(self, outputs) -> bool:
+        return self.rgb is not None and outputs.get("rgb") is self.rgb
+
+    def bind(self, rgb: Tensor, holder: list, rows: int) -> None:
+        self.rgb, self._holder, self._rows = rgb, holder, rows
+
+    def gt_image(self, image: Tensor, d: int, convert) -> Tensor:
+        memo = self._gt
+        if memo is not None and memo[0] is image and memo[1] == (image._version, d):
+            return memo[2]
+        out = convert(image)
+        # (the source object is held with its conversion, so that its address cannot be recycled under the key)
+        self._gt = (image, (image._version, d), out) if out is not image else None
+        return out
+
+    def take_ssim(self):
+        shared, self.ssim = self.ssim, None
+        return shared
+
+    def take_accumulator(self):
+        if self._holder is None:
+            return None
+        pair, self._holder = (self._holder, self._rows), None
+        return pair
+
+
 class _PostProcess(torch.autograd.Function):
     """model.py:295-297 + 304-306 as ONE node: rgb = clamp(render[..., :3] + (1 - alpha) background, 0, 1) and
     depth = where(alpha > 0, render[..., 3:4], render[..., 3:4].detach().max())."""
@@ -563,16 +613,14 @@ class QEDSplatterModel(nn.Module):
     def get_gt_img(self, image: Tensor) -> Tensor:
         """uint8 -> float / 255, downscaled by the current factor, on the model's device (the parent's get_gt_img,
         called at model.py:88,91,94)."""
-        # get_metrics_dict and get_loss_dict prepare the SAME batch image within one step: the last conversion is kept
-        # (together with its source object, so that the address cannot be recycled under the key) and handed out again
-        d = self._get_downscale_factor()
-        memo = getattr(self, "_gt_memo", None)
-        if memo is not None and memo[0] is image and memo[1] == (image._version, d):
-            return memo[2]
-        out = image.float() / 255.0 if image.dtype == torch.uint8 else image
-        out = self._downscale_if_required(out).to(self.device)
-        self.__dict__["_gt_memo"] = (image, (image._version, d), out) if out is not image else None
-        return out
+        def convert(img):
+            out = img.float() / 255.0 if img.dtype == torch.uint8 else img
+            return self._downscale_if_required(out).to(self.device)
+
+        # get_metrics_dict and get_loss_dict prepare the SAME batch image within one step: the step's context keeps the
+        # last conversion (StepContext.gt_image)
+        ctx = self.__dict__.get("_step")
+        return convert(image) if ctx is None else ctx.gt_image(image, self._get_downscale_factor(), convert)
 
     def composite_with_background(self, image: Tensor, background: Tensor) -> Tensor:
         """RGBA ground truth composited onto the step's background (the parent does this to the GT image)."""
@@ -647,10 +695,10 @@ class QEDSplatterModel(nn.Module):
         W, H = int(camera.width.item()), int(camera.height.item())
         attrs = self.__dict__            # (plain attributes: nn.Module.__setattr__ costs ~5 us apiece, a dozen per step)
         attrs["last_size"] = (H, W)
-        # what get_metrics_dict / get_loss_dict share about the batch lives for ONE step: a loader that refills its batch
-        # tensors in place without bumping their version counter must not be served last step's conversion
-        attrs["_gt_memo"] = None
-        attrs["_ssim_shared"] = None
+        # what get_metrics_dict / get_loss_dict / backward share about THIS step lives in one object, replaced here: a
+        # loader that refills its batch tensors in place without bumping their version counter must not be served last
+        # step's conversion, and nothing of last step's outputs may reach this step's loss
+        ctx = attrs["_step"] = StepContext()
         if camera_scale_fac != 1:
             camera.rescale_output_resolution(camera_scale_fac)
 
@@ -701,7 +749,6 @@ class QEDSplatterModel(nn.Module):
             _vsplat_holder=holder,
             _means2d_leaf=True,     # xys is only retained and read (below; densify.py): its gradient arrives as a view
         )
-        attrs["_vsplat_pair"] = (holder, info["radii"].numel())
         attrs["info"] = info
         attrs["last_compact"] = False
         if self.training and info["means2d"].requires_grad:                   # model.py:289-290 (a no-op on the leaf)
@@ -723,12 +770,11 @@ class QEDSplatterModel(nn.Module):
 
         # model.py:310-311 `del render; torch.cuda.empty_cache()` is a per-call device sync +
         # allocator flush with no effect on results; deliberately not reproduced.
-        attrs["_last_render"], attrs["_last_alpha"] = render, alpha
 
         if background.shape[0] == 3 and not self.training:                    # model.py:313-314
             background = background.expand(H, W, 3)
         rgb = rgb.squeeze(0)
-        attrs["_last_out_rgb"] = rgb
+        ctx.bind(rgb, holder, info["radii"].numel())
         return {
             "rgb": rgb,
             "depth": depth_im,
@@ -775,14 +821,15 @@ class QEDSplatterModel(nn.Module):
             raise TypeError("get_loss_dict needs outputs['depth'] (the reference fails the same way with "
                             "output_depth_during_training=False, model.py:87,101)")
         H, W = pred_img.shape[:2]
+        ctx = self.__dict__.get("_step")
+        mine = ctx is not None and ctx.owns(outputs)          # these outputs are this step's (not kept from an earlier one)
         gt_img = self.composite_with_background(self.get_gt_img(batch["image"]), outputs["background"])
         mask = self._loss_mask(batch, pred_img.shape)
         gt_img = _f32_image(gt_img[..., :3] if gt_img.shape[-1] > 3 else gt_img, H * W * 3, "batch['image']", self.device)
         depth_batch = _f32_image(self.get_gt_img(batch["depth_image"]), H * W, "batch['depth_image']", self.device)
         # the SSIM forward get_metrics_dict ran on the same two images (same storage, same version; the cache holds the
         # tensors, so neither address can have been recycled), no mask: not computed a second time
-        shared = self.__dict__.get("_ssim_shared")
-        self.__dict__["_ssim_shared"] = None
+        shared = ctx.take_ssim() if mine else None
         if shared is not None and (mask is not None or cfg.ssim_lambda <= 0.0 or
                                    shared["key"] != _ssim_key(pred_img.contiguous(), gt_img)):
             shared = None
@@ -793,10 +840,9 @@ class QEDSplatterModel(nn.Module):
             if shared["depth_key"] == (dc.data_ptr(), dc._version, depth_batch.data_ptr(), depth_batch._version) \
                     and shared["lambdas"] == (float(cfg.ssim_lambda), float(cfg.depth_lambda)):
                 loss_shared = shared["loss"]
-        # the accumulator of the compositing backward behind THESE outputs is zeroed by this loss's backward launch
-        pair = self.__dict__.get("_vsplat_pair")
-        if pair is not None and (self.__dict__.get("_last_out_rgb") is not pred_img or not torch.is_grad_enabled()):
-            pair = None
+        # the accumulator of the compositing backward behind THESE outputs is zeroed by this loss's backward launch (the
+        # first loss taken on them: a second one leaves the fill to the backward pass)
+        pair = ctx.take_accumulator() if (mine and torch.is_grad_enabled()) else None
         main, depth = _ImageLosses.apply(pred_img, depth_out, gt_img, depth_batch, mask, float(cfg.ssim_lambda),
                                          float(cfg.depth_lambda), shared["maps_sum"] if shared else None, loss_shared, pair)
         return {"main_loss": main, "scale_reg": self._scale_reg(), "depth_loss": depth}
@@ -829,20 +875,23 @@ class QEDSplatterModel(nn.Module):
         # In training the loss that follows needs the SSIM of the same two images WITH the coefficient maps of its
         # backward pass: compute that form once here and leave it for get_loss_dict (which checks that it is handed the
         # same tensors before using it)
+        ctx = self.__dict__.get("_step")
         keep = (self.training and torch.is_grad_enabled() and self.config.ssim_lambda > 0.0 and d <= 1
-                and pred_rgb.is_cuda and pred_rgb.dtype == torch.float32)
+                and pred_rgb.is_cuda and pred_rgb.dtype == torch.float32 and ctx is not None and ctx.owns(outputs))
         with torch.no_grad():
             if keep and has_depth:
                 # a training step: the metrics, and what the loss that follows needs from the same images, in one pass
                 from .metrics import step_metrics
                 out, shared = step_metrics(pred_rgb.detach(), gt_rgb, outputs["depth"].detach(), gt_depth,
                                            self.scales[..., -1], float(self.config.ssim_lambda), float(self.config.depth_lambda))
-                self.__dict__["_ssim_shared"] = shared
+                ctx.ssim = shared
                 out["gaussian_count"] = self.num_points
                 return out
             out = dict(_image_metrics(pred_rgb.detach(), gt_rgb, outputs["depth"].detach() if has_depth else None, gt_depth,
                                       keep_ssim_maps=keep))
-            self.__dict__["_ssim_shared"] = out.pop("_ssim_shared", None)
+            kept = out.pop("_ssim_shared", None)
+            if keep:
+                ctx.ssim = kept
             out["gaussian_count"] = self.num_points
             out["avg_min_scale"] = nanmean_exp(self.scales[..., -1])                  # model.py:192-194
         return out
@@ -861,7 +910,7 @@ class QEDSplatterModel(nn.Module):
         same quantities as get_outputs + get_loss_dict."""
         assert camera.shape[0] == 1, "Only one camera at a time"
         cfg = self.config
-        self.__dict__["_gt_memo"] = None      # (conversions of the batch are shared within a step, never across steps)
+        self.__dict__["_step"] = StepContext()   # (conversions of the batch are shared within a step, never across steps)
         # the coarse-to-fine schedule of get_outputs (model.py:244-250): render at 1/d of the camera's resolution
         d = self._get_downscale_factor()
         if d > 1:
@@ -978,6 +1027,19 @@ class FlatAdam:
         self.dev_state = torch.zeros(4, dtype=torch.float32, device=model.device)
         self.dev_lr = torch.zeros(8, dtype=torch.float32, device=model.device)
         self.dev_lr[:len(self.lr)] = torch.tensor(self.lr)
+        from .rasterization import _workspace
+        _workspace(model.device).steppers.add(self)
+
+    def on_skipped_step(self) -> None:
+        """The device skipped the step this optimiser's host counter has already counted (the frame behind it overflowed its
+        intersection buffer: _Workspace.poll_pending): take it back, so that the bias corrections of the host-counter path
+        stay in step with the moments.  (The device-state path counts on the device, where the tick honours the skip.)
+        Not in a data-parallel job: there the skip is collective (parallel.py) but only the rank whose frame overflowed
+        hears of it on the host -- taking the step back here alone would make the replicas' bias corrections differ.  All
+        ranks' host counters then run one ahead of the moments together; step with device_state=True for exact counts."""
+        if getattr(self.model, "_dp_skip", None) is not None:
+            return
+        self.t = max(self.t - 1, 0)
 
     def take_tick(self):
         """The qed_adam_tick_t that lets ANOTHER launch of the step advance this optimiser's device step state
@@ -1006,6 +1068,10 @@ class FlatAdam:
     def _skip(self) -> int:
         """``skip_flag`` of the Adam entry points: the binning overflow word of this device (a frame whose intersection
         list overflowed renders empty; a step enqueued behind it without a host round trip must be a no-op)."""
+        # data parallel: the MAXIMUM of the ranks' words, so that every replica skips the same steps (parallel.py)
+        dp = getattr(self.model, "_dp_skip", None)
+        if dp is not None:
+            return dp.data_ptr()
         from .rasterization import _workspace
         return _workspace(self.model.device).skip_flag_ptr()
 
@@ -1262,6 +1328,10 @@ class QedAdam(torch.optim.Optimizer):
                              "(Nerfstudio builds one optimiser per group name)")
         self._shared: Optional[_SharedFlatState] = None
         _ALL_QED_ADAMS.add(self)
+        p0 = ps[0]
+        if p0.is_cuda:
+            from .rasterization import _workspace
+            _workspace(p0.device).steppers.add(self)
 
     # -- layout -----------------------------------------------------------------------------------------
     def _param(self) -> Tensor:
@@ -1409,6 +1479,21 @@ class QedAdam(torch.optim.Optimizer):
         L.check(L.load().qed_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), 1,
                                        C.cast(h_begin, C.c_void_p), C.cast(h_lr, C.c_void_p), float(beta1), float(beta2),
                                        float(grp["eps"]), t, _skip_flag(p.device), _stream()), "qed_adam_step")
+
+    def on_skipped_step(self) -> None:
+        """See FlatAdam.on_skipped_step: the launch that this instance's last step() counted did nothing on the device."""
+        p = self._param()
+        if self._shared is not None and self._is_flat_view(p):
+            st, off = self._shared, p.storage_offset()
+            if st.t.get(off, 0) > 0:
+                st.t[off] -= 1
+                held = self.__dict__.get("_views")
+                if held is not None:
+                    held[1]["step"].fill_(float(st.t[off]))
+            return
+        state = self.state.get(p)
+        if state and float(state["step"]) > 0:
+            state["step"] -= 1
 
     def flush(self) -> None:
         """Launch the update of the groups that have called step() but are still waiting for the others."""

@@ -30,7 +30,9 @@ def allreduce_flat_grad(model, world_size: int, group=None) -> torch.Tensor:
         raise RuntimeError("no gradients to reduce: call backward() first")
     _refuse_compact(model, "allreduce_flat_grad")
     if _single(world_size):
+        model._dp_skip = None
         return g
+    collective_skip_flag(model, world_size, group)
     if dist.get_backend(group) == "nccl":
         dist.all_reduce(g, op=dist.ReduceOp.AVG, group=group)      # ncclAvg: no extra scaling pass
     else:                                                            # gloo (CPU tests) has no AVG
@@ -80,7 +82,8 @@ def exchange_grads_compact(model, world_size: int, group=None, views=None, rebui
         recv = bufs[1]
         for c, (v, m) in enumerate(views):
             recv[c, :nv] = v.reshape(-1)
-            recv[c, nv:] = m.reshape(-1)
+            recv[c, nv:nv + 16] = m.reshape(-1)
+        model._dp_skip = None
     elif not _single(world_size):
         n_views = max(world_size, 1)
         if dist.get_backend(group) == "nccl":
@@ -93,8 +96,10 @@ def exchange_grads_compact(model, world_size: int, group=None, views=None, rebui
             dist.all_gather_into_tensor(recv.view(-1), send, group=group)
         else:                                                     # gloo (rehearsal / CPU tests)
             dist.all_gather(list(recv.unbind(0)), send, group=group)
+        _fold_skip_words(model, recv, nv)
     else:
         n_views, recv = 1, send.view(1, row)
+        model._dp_skip = None
     if not rebuild:
         model.sh_views = (n_views, recv[:, nv:], row, recv, row, 1.0 / n_views)
         return g
@@ -113,13 +118,15 @@ class CompactExchange:
     wait for the gathered colour gradients (what the SH part of the optimiser reads), ``wait_geometry()`` for the
     averaged geometry gradients (what the leading groups read)."""
 
-    def __init__(self, gather, reduce, geo, scale_after: float):
-        self._gather, self._reduce, self._geo, self._scale_after = gather, reduce, geo, scale_after
+    def __init__(self, gather, reduce, geo, scale_after: float, fold=None):
+        self._gather, self._reduce, self._geo, self._scale_after, self._fold = gather, reduce, geo, scale_after, fold
 
     def wait_views(self) -> None:
         if self._gather is not None:
             self._gather.wait()
             self._gather = None
+            if self._fold is not None:          # the ranks' overflow words -> the step's collective skip flag
+                self._fold()
 
     def wait_geometry(self) -> None:
         if self._reduce is not None:
@@ -147,7 +154,8 @@ def exchange_grads_compact_begin(model, world_size: int, group=None) -> CompactE
         raise RuntimeError("exchange_grads_compact_begin needs gradients from fused_loss(..., compact_sh_grad=True)")
     geo, send, recv, nv, row = _compact_buffers(model, g, max(world_size, 1))
     if _single(world_size):
-        model.sh_views = (1, send[nv:].view(1, 16), row, send.view(1, row), row, 1.0)
+        model.sh_views = (1, send[nv:nv + 16].view(1, 16), row, send.view(1, row), row, 1.0)
+        model._dp_skip = None
         return CompactExchange(None, None, geo, 1.0)
     nccl = dist.get_backend(group) == "nccl"
     if nccl:
@@ -158,7 +166,15 @@ def exchange_grads_compact_begin(model, world_size: int, group=None) -> CompactE
         w_reduce = dist.all_reduce(geo, op=dist.ReduceOp.SUM, group=group, async_op=True)
     n_views = max(world_size, 1)
     model.sh_views = (n_views, recv[:, nv:], row, recv, row, 1.0 / n_views)
-    return CompactExchange(w_gather, w_reduce, geo, 1.0 if nccl else 1.0 / n_views)
+    _dp_skip_word(model, g.device)              # (exists before anything captures an optimiser launch that reads it)
+    return CompactExchange(w_gather, w_reduce, geo, 1.0 if nccl else 1.0 / n_views,
+                           fold=lambda: _fold_skip_words(model, recv, nv))
+
+
+def _fold_skip_words(model, recv: torch.Tensor, nv: int) -> None:
+    """model._dp_skip = max over the gathered rows' overflow words (one small launch; the words are counts >= 0)."""
+    words = recv[:, nv + 16:nv + 17].view(torch.int32)            # [ranks, 1]
+    torch.amax(words, dim=0, out=_dp_skip_word(model, recv.device))
 
 
 def _compact_buffers(model, g, n_rows: int):
@@ -169,15 +185,52 @@ def _compact_buffers(model, g, n_rows: int):
     assert i_dc == 4 and i_rest == 5, "group order: geometry groups first, then features_dc, features_rest"
     geo, v_local = g[:begin[i_dc]], g[begin[i_dc]:begin[i_dc + 1]]
     nv = v_local.numel()                                          # 3 N
-    row = nv + 16                                                 # one message per rank: colour gradients + view matrix
+    # one message per rank: colour gradients + view matrix + (bits of) this rank's intersection-overflow word (4 floats, so
+    # that rows stay 16-byte aligned): the optimiser step is skipped on EVERY rank when ANY rank's frame overflowed
+    row = nv + 16 + 4
     bufs = getattr(model, "_dp_buffers", None)
     if bufs is None or bufs[0].numel() != row or bufs[1].shape != (n_rows, row) or bufs[0].device != g.device:
-        bufs = model._dp_buffers = (torch.empty(row, dtype=torch.float32, device=g.device),
-                                    torch.empty(n_rows, row, dtype=torch.float32, device=g.device))
+        bufs = model._dp_buffers = (torch.zeros(row, dtype=torch.float32, device=g.device),      # (the row's padding stays 0)
+                                    torch.zeros(n_rows, row, dtype=torch.float32, device=g.device))
     send = bufs[0]
     send[:nv] = v_local
-    send[nv:] = model.last_viewmat.reshape(-1).to(torch.float32)
+    send[nv:nv + 16] = model.last_viewmat.reshape(-1).to(torch.float32)
+    send[nv + 16:nv + 17].view(torch.int32).copy_(_local_overflow_word(g.device))
     return geo, send, bufs[1], nv, row
+
+
+def _local_overflow_word(device) -> torch.Tensor:
+    """int32[1] view of this device's binning overflow word (non-zero: the frame just rendered overflowed its intersection
+    buffer and is empty; what single-GPU optimiser launches take as ``skip_flag``)."""
+    if device.type != "cuda":          # gloo rehearsals on CPU tensors (tests): no binning workspace; tests fill the word
+        return _CPU_OVERFLOW_WORD
+    from .rasterization import _workspace
+    return _workspace(device).status[:1]
+
+
+_CPU_OVERFLOW_WORD = torch.zeros(1, dtype=torch.int32)
+
+
+def _dp_skip_word(model, device) -> torch.Tensor:
+    """The persistent int32[1] the optimiser launches of a data-parallel step take as ``skip_flag`` (FlatAdam._skip): the
+    MAXIMUM over all ranks of the overflow words.  A rank whose frame overflowed renders it empty and skips its update on
+    the device; unless its peers skip the same step, the replicas' parameters, moments and step counters part for good
+    (per-rank cameras make the list length rank dependent, so an overflow need not hit every rank in the same step)."""
+    w = getattr(model, "_dp_skip", None)
+    if w is None or w.device != device:
+        w = model._dp_skip = torch.zeros(1, dtype=torch.int32, device=device)
+    return w
+
+
+def collective_skip_flag(model, world_size: int, group=None) -> torch.Tensor:
+    """For the exchanges that gather no message (allreduce_flat_grad, allreduce_and_step): one MAX all-reduce of the
+    overflow word into ``model._dp_skip``."""
+    g = model.flat_grad()
+    w = _dp_skip_word(model, g.device)
+    w.copy_(_local_overflow_word(g.device))
+    if not _single(world_size):
+        dist.all_reduce(w, op=dist.ReduceOp.MAX, group=group)
+    return w
 
 
 def allreduce_and_step(model, optimizer, world_size: int, n_chunks: int = 4, group=None) -> None:
@@ -197,9 +250,11 @@ def allreduce_and_step(model, optimizer, world_size: int, n_chunks: int = 4, gro
     _refuse_compact(model, "allreduce_and_step")
     total = g.numel()
     if _single(world_size):
+        model._dp_skip = None
         optimizer.begin_step()
         optimizer.step_range(0, total)
         return
+    collective_skip_flag(model, world_size, group)
     n_chunks = max(1, min(int(n_chunks), total // 4 or 1))
     bounds = [min(total, (total * k // n_chunks) // 4 * 4) for k in range(n_chunks)] + [total]
     avg = dist.get_backend(group) == "nccl"

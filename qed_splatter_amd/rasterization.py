@@ -79,6 +79,9 @@ class _Workspace:
         self.m_seen: Dict[tuple, int] = {}   # shape key -> longest list read back for that shape
         self.force_sync = False      # the next call reads M back (an asynchronous frame overflowed)
         self.overflows = 0           # asynchronous frames that rendered empty (diagnostics / tests)
+        # optimisers that keep a HOST step counter and take this workspace's overflow word as skip_flag: told when a step
+        # was skipped on the device, so that their bias corrections stay in step with their moments
+        self.steppers: "weakref.WeakSet" = weakref.WeakSet()
 
     def host_slot(self):
         """A pinned 4-word buffer for one asynchronous read-back, as (numpy view, address): qed_bin_tiles' last list kernel
@@ -120,10 +123,18 @@ class _Workspace:
         words, key = self.pending
         self.pending = None
         if words[0] < 0:
-            # the host is a frame ahead of the device: wait for that frame's binning (yielding the GIL between looks)
+            # the host is a frame ahead of the device: wait for that frame's binning.  A few looks back to back (the word
+            # usually lands within microseconds), then sleeps that double up to 100 us: a host that runs ahead of a ~1 ms
+            # step does not burn a core on it, and wakes at most a tenth of a step late
             deadline = time.monotonic() + self.POLL_TIMEOUT_S
+            looks, nap = 0, 5e-6
             while words[0] < 0:
-                time.sleep(0)
+                looks += 1
+                if looks <= 8:
+                    time.sleep(0)
+                    continue
+                time.sleep(nap)
+                nap = min(2.0 * nap, 1e-4)
                 if time.monotonic() > deadline:
                     torch.cuda.synchronize(self.device)             # surfaces a device fault as its own error
                     if words[0] < 0:
@@ -142,6 +153,8 @@ class _Workspace:
             self.force_sync = True
             old = self.capacity
             self.saw(key, overflow)
+            for opt in list(self.steppers):                        # (the host is at most one frame ahead: ONE step was skipped)
+                opt.on_skipped_step()
             warnings.warn(f"qed_splatter_amd: an asynchronous rasterization needed {overflow} tile intersections, more "
                           f"than the buffer held ({old}); that frame rendered empty and its optimiser step was skipped "
                           f"on the device.  Capacity raised to {self.capacity}.", RuntimeWarning, stacklevel=3)

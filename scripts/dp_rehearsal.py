@@ -80,5 +80,50 @@ print(f"rank {rank}: overlapped exchange (gather | SH part | all-reduce | leadin
       f"replicas identical: {replicas4}", flush=True)
 same = same and same2 and same3 and same4
 replicas = replicas and replicas4
+
+# ---- one rank's frame overflows its intersection buffer: EVERY rank must skip that step ----------------
+# Per-rank cameras make the list length rank dependent, so an overflow need not hit all ranks in the same step; the rank
+# it hits renders an empty frame and skips its update on the device.  The overflow word travels in the gathered message
+# (or a MAX all-reduce on the plain path) and every rank's optimiser launches take the maximum as their skip flag.
+import warnings  # noqa: E402
+from qed_splatter_amd.rasterization import _workspace  # noqa: E402
+ws = _workspace(dev)
+skip_ok = True
+for i, (m, o) in ((0, (models[0], opts[0])), (4, (models[4], opts[4]))):
+    def one_step(sync):
+        for p in m.parameters():
+            p.grad = None
+        m.backward_fused(m.fused_loss(cam, batch, sync=sync, compact_sh_grad=(i == 4)))
+        if i == 0:
+            allreduce_flat_grad(m, world)
+            o.step()
+        else:
+            ex = exchange_grads_compact_begin(m, world)
+            ex.wait_views()
+            o.step(fused_sh=True, part=1)
+            ex.wait_geometry()
+            o.step(fused_sh=True, part=2)
+    one_step(True)                               # calibrates this shape: the next call may leave the count on the device
+    torch.cuda.synchronize()
+    before = m.flat_params.detach().clone()
+    mom = (o.exp_avg.clone(), o.exp_avg_sq.clone())
+    M = int(m.info["n_isects"])
+    if rank == world - 1:
+        ws.capacity = max(M // 3, 1024)          # (what a sudden change of this rank's view would amount to)
+    one_step(False)                              # rank world-1 overflows: empty frame there, skipped step EVERYWHERE
+    torch.cuda.synchronize()
+    unchanged = torch.equal(m.flat_params, before) and torch.equal(o.exp_avg, mom[0]) and torch.equal(o.exp_avg_sq, mom[1])
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        one_step(False)                          # the rank that overflowed regrows and reads M back; all ranks train
+    torch.cuda.synchronize()
+    warned = any("rendered empty" in str(c.message) for c in caught)
+    trained = not torch.equal(m.flat_params, before)
+    gathered5 = [torch.empty_like(m.flat_params) for _ in range(world)]
+    dist.all_gather(gathered5, m.flat_params.detach())
+    identical = all(torch.equal(gathered5[0], t) for t in gathered5)
+    print(f"rank {rank}: forced overflow on rank {world - 1}, {'plain all-reduce' if i == 0 else 'compact exchange'}: step skipped on this "
+          f"rank: {unchanged}; warned here: {warned}; next step trained: {trained}; replicas identical: {identical}", flush=True)
+    skip_ok = skip_ok and unchanged and trained and identical and (warned == (rank == world - 1))
 dist.destroy_process_group()
-sys.exit(0 if same and replicas else 1)
+sys.exit(0 if same and replicas and skip_ok else 1)

@@ -486,7 +486,7 @@ def test_ssim_forward_shared_between_metrics_and_loss(cuda, uint8_image):
         n_fwd = len(L.TIMER.events.get("qed_ssim_fwd", []))
         calls = {k: len(v) for k, v in L.TIMER.events.items()}
         sum(ld.values()).backward()
-        assert getattr(m, "_ssim_shared", None) is None              # consumed (or never made)
+        assert m._step.ssim is None                                  # consumed (or never made)
         run.last = (m, out, batch, calls)
         return md, ld, out["rgb"].grad.clone(), n_fwd
 
@@ -529,7 +529,7 @@ def test_ssim_forward_shared_between_metrics_and_loss(cuda, uint8_image):
     with torch.no_grad():
         out = m.get_outputs(cam)
         m.get_metrics_dict(out, batch)
-    assert getattr(m, "_ssim_shared", None) is None                   # nothing kept outside training
+    assert m._step.ssim is None                                       # nothing kept outside training
 
 
 @pytest.mark.parametrize("ch,masked,size", [(4, False, (75, 101)), (4, True, (64, 96)), (3, False, (45, 70)), (3, True, (33, 33))])
@@ -823,3 +823,145 @@ def test_qedadam_group_without_a_gradient_does_not_delay_the_others(cuda):
     assert len(oq["means"]._shared.pending) == 3
     sd = oq["means"].state_dict()
     assert len(oq["means"]._shared.pending) == 0 and float(sd["state"][0]["step"]) == 4.0
+
+
+# ---- the eval-time crop box (model.py:217-239) ----------------------------------------------------------------------
+class _Box:
+    """Stands in for Nerfstudio's OrientedBox: ``within(points) -> [N,1] bool`` (the reference squeezes it, model.py:218)."""
+
+    def __init__(self, lo, hi):
+        self.lo, self.hi = lo, hi
+
+    def within(self, pts):
+        return ((pts[:, 2] >= self.lo) & (pts[:, 2] < self.hi))[:, None]
+
+
+def test_eval_crop_box_renders_the_kept_subset_and_none_kept_gives_the_empty_outputs(cuda):
+    """get_outputs in eval mode with a crop box (model.py:217-239): the six groups are indexed by the box's mask and only
+    the kept Gaussians are rendered -- outputs equal the oracle's on that subset, `radii` / `xys` have the subset's length;
+    in training mode the box is ignored (model.py:217 `and not self.training`); a box that keeps nothing returns
+    get_empty_outputs (background colour image, depth 10, zero accumulation, model.py:219-222)."""
+    from tests.test_gpu_parity import MARGIN_E2E
+    w, h, n = 160, 112, 3000
+    sc = scene(n, w, h, seed=41)
+    m, cam, batch = _model(sc, cuda, background_color="white")
+    z = sc["means"][:, 2]
+    cut = float(z.sort().values[int(0.6 * n)])                       # keeps the ~40 % nearest the camera (z in (-12, -2))
+    m.crop_box = _Box(cut, 0.0)
+    keep = ((z >= cut) & (z < 0.0))
+    n_kept = int(keep.sum())
+    assert 0.35 * n < n_kept < 0.45 * n
+    m.eval()
+    with torch.no_grad():
+        out = m.get_outputs(cam)
+    assert m.radii.shape == (n_kept,) and m.xys.shape == (1, n_kept, 2)            # "radii: [N]" of the cropped set
+    assert out["rgb"].shape == (h, w, 3) and out["depth"].shape == (h, w, 1) and out["accumulation"].shape == (h, w, 1)
+    assert out["background"].shape == (h, w, 3)                                    # expanded in eval (model.py:313-314)
+    sub = {k: sc[k][keep].double() for k in PARAM_NAMES}
+    bg = torch.ones(3, dtype=torch.float64)
+    ref = O.splatfacto_outputs(sub["means"], sub["scales"], sub["quats"], sub["opacities"], sub["features_dc"],
+                               sub["features_rest"], sc["camera_to_worlds"][:1].double(), sc["Ks"][:1].double(), w, h, bg,
+                               radii_override=m.info["radii"].cpu(), return_margin=True)
+    safe = ref["info"]["margin"][0] > MARGIN_E2E
+    assert float(safe.float().mean()) > 0.999
+    assert_close(out["rgb"].cpu()[safe], ref["rgb"][safe], REL_TOL, "rgb (cropped)")
+    assert_close(out["depth"].cpu()[safe], ref["depth"][safe], REL_TOL, "depth (cropped)")
+    assert_close(out["accumulation"].cpu()[safe], ref["accumulation"][safe], REL_TOL, "accumulation (cropped)")
+    # the crop really removed something: the full set renders a different image
+    m.crop_box = None
+    with torch.no_grad():
+        full = m.get_outputs(cam)
+    assert m.radii.shape == (n,)
+    assert float((full["accumulation"] - out["accumulation"]).abs().max()) > 0.05
+    # training ignores the box
+    m.crop_box = _Box(cut, 0.0)
+    m.train()
+    out_t = m.get_outputs(cam)
+    assert m.radii.shape == (n,)
+    assert torch.equal(out_t["accumulation"].detach(), full["accumulation"])
+    # a box that keeps nothing: the parent's get_empty_outputs
+    m.eval()
+    m.crop_box = _Box(5.0, 6.0)
+    with torch.no_grad():
+        empty = m.get_outputs(cam)
+    assert set(empty) == {"rgb", "depth", "accumulation", "background"}
+    assert empty["rgb"].shape == (h, w, 3) and empty["depth"].shape == (h, w, 1) and empty["accumulation"].shape == (h, w, 1)
+    assert bool((empty["rgb"] == 1.0).all()) and bool((empty["depth"] == 10.0).all()) and bool((empty["accumulation"] == 0.0).all())
+    assert torch.equal(empty["background"], torch.ones(3, device=cuda))
+
+
+# ---- the per-step context (StepContext): calls out of order must still give the right values ------------------------
+def test_step_context_misuse_gives_correct_values_each_time(cuda):
+    """get_outputs leaves a StepContext that get_metrics_dict / get_loss_dict / backward share (an SSIM forward, the batch
+    conversions, a zero-filled accumulator for the compositing backward).  Every consumer must fall back to the full
+    computation when the context is not its own: (B) two losses on one `outputs`; (C) a loss on the PREVIOUS step's
+    outputs after a new get_outputs, then the loss of the new ones; (D) metrics taken under no_grad, then a training
+    loss; (E) metrics of stale outputs must not reach the fresh outputs' loss.  Values and gradients are compared with a
+    fresh model that makes the plain sequence of calls."""
+    from qed_splatter_amd.model import PinholeCameras
+    w, h, n = 160, 112, 3000
+    sc = scene(n, w, h, seed=12, n_cameras=2)
+    K = sc["Ks"][0]
+
+    def fresh():
+        m, cam, batch = _model(sc, cuda)
+        m.train()
+        cam2 = PinholeCameras(sc["camera_to_worlds"][1:2].to(cuda), K[0, 0], K[1, 1], K[0, 2], K[1, 2], w, h)
+        return m, cam, cam2, batch
+
+    def grads(m):
+        return {k: m.gauss_params[k].grad.clone() for k in PARAM_NAMES}
+
+    def same(ld, ref):
+        return all(float(ld[k]) == pytest.approx(float(ref[k]), rel=3e-6, abs=1e-9) for k in ref)
+
+    def close(g, ref, scale=1.0):
+        for k in PARAM_NAMES:
+            assert_close(g[k], scale * ref[k].double().cpu(), 2e-5, f"grad {k}")
+
+    # (A) the plain sequence, per camera
+    ref = {}
+    for which in (0, 1):
+        m, cam, cam2, batch = fresh()
+        out = m.get_outputs((cam, cam2)[which])
+        ld = m.get_loss_dict(out, batch)
+        sum(ld.values()).backward()
+        ref[which] = ({k: v.detach().clone() for k, v in ld.items()}, grads(m))
+    # (B) metrics, then the loss twice on the same outputs
+    m, cam, cam2, batch = fresh()
+    out = m.get_outputs(cam)
+    md = m.get_metrics_dict(out, batch)
+    ld1 = m.get_loss_dict(out, batch, md)
+    ld2 = m.get_loss_dict(out, batch, md)
+    assert same(ld1, ref[0][0]) and same(ld2, ref[0][0])
+    (sum(ld1.values()) + sum(ld2.values())).backward()
+    close(grads(m), ref[0][1], 2.0)
+    # (C) + (E): stale outputs
+    m, cam, cam2, batch = fresh()
+    out_old = m.get_outputs(cam)
+    out_new = m.get_outputs(cam2)
+    m.get_metrics_dict(out_old, batch)                     # (E) stale metrics: nothing of them may be kept
+    assert m._step.ssim is None
+    md_new = m.get_metrics_dict(out_new, batch)
+    assert m._step.ssim is not None
+    ld_old = m.get_loss_dict(out_old, batch)               # (C) the previous step's outputs: the context is not theirs
+    assert m._step.ssim is not None                        #     ... and they did not consume the new outputs' SSIM
+    ld_new = m.get_loss_dict(out_new, batch, md_new)
+    assert m._step.ssim is None
+    assert same(ld_old, ref[0][0]) and same(ld_new, ref[1][0])
+    sum(ld_old.values()).backward()
+    close(grads(m), ref[0][1])
+    for p in m.parameters():
+        p.grad = None
+    sum(ld_new.values()).backward()
+    close(grads(m), ref[1][1])
+    # (D) metrics under no_grad, then a training loss
+    m, cam, cam2, batch = fresh()
+    out = m.get_outputs(cam)
+    with torch.no_grad():
+        m.get_metrics_dict(out, batch)
+    assert m._step.ssim is None                            # an SSIM forward without the maps is of no use to the loss
+    ld = m.get_loss_dict(out, batch)
+    assert same(ld, ref[0][0])
+    sum(ld.values()).backward()
+    close(grads(m), ref[0][1])

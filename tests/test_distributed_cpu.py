@@ -38,8 +38,9 @@ def _worker(rank, world, port, q):
             p.grad = flat[off:off + p.numel()].view(p.shape)
             off += p.numel()
         g = allreduce_flat_grad(m, world)
+        ok0 = int(m._dp_skip) == 0                                    # no rank overflowed: nobody skips
         want = torch.arange(total, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
-        ok = torch.allclose(g, want) and g.data_ptr() == m.means.grad.data_ptr()
+        ok = ok0 and torch.allclose(g, want) and g.data_ptr() == m.means.grad.data_ptr()
         # identical update on every rank keeps the replicas bit-identical
         with torch.no_grad():
             m.flat_params.add_(g, alpha=-1e-3)
@@ -64,7 +65,13 @@ def _worker(rank, world, port, q):
         ok = ok and abs(float(dz.xys_grad_norm[0]) - 0.5 * sum(range(1, world + 1))) < 1e-6
         # compact exchange, both collectives left in flight (what bench.py runs for N > 1) == the blocking form:
         # averaged geometry gradients, one (colour gradients + view matrix) message per rank, scale 1 / world
+        from qed_splatter_amd import parallel as P
         from qed_splatter_amd.parallel import exchange_grads_compact, exchange_grads_compact_begin
+        # ... and the optimiser's skip decision is collective: ONE rank's frame overflowed its intersection buffer (its
+        # overflow word holds the count it needed) -> every rank's step takes the same non-zero skip word
+        P._CPU_OVERFLOW_WORD[0] = 77 if rank == world - 1 else 0
+        allreduce_flat_grad(m, world)
+        ok = ok and int(m._dp_skip) == 77
         results = []
         for overlapped in (False, True):
             m2 = QEDSplatterModel(None, **{k: sc[k] for k in PARAM_NAMES})
@@ -83,17 +90,19 @@ def _worker(rank, world, port, q):
                 ex.wait_geometry()                                   # idempotent
             else:
                 exchange_grads_compact(m2, world, rebuild=False)
+            ok = ok and int(m2._dp_skip) == 77
             n_views, vms, vm_stride, v_views, view_stride, scale = m2.sh_views
             results.append((m2.flat_grad().clone(), v_views.clone(), n_views, vm_stride, view_stride, scale))
         b = m.group_begin
         nv = b[5] - b[4]
         mean_w = sum(range(1, world + 1)) / world
         for g2, recv, n_views, vm_stride, view_stride, scale in results:
-            ok = ok and n_views == world and vm_stride == view_stride == nv + 16 and scale == 1.0 / world
+            ok = ok and n_views == world and vm_stride == view_stride == nv + 20 and scale == 1.0 / world
             ok = ok and torch.allclose(g2[:b[4]], (torch.arange(b[4], dtype=torch.float32) + 1.0) * mean_w)
             for r in range(world):
                 ok = ok and torch.equal(recv[r, :nv], (torch.arange(b[4], b[5], dtype=torch.float32) + 1.0) * (r + 1))
-                ok = ok and torch.equal(recv[r, nv:], (torch.eye(4) * (r + 2)).reshape(-1))
+                ok = ok and torch.equal(recv[r, nv:nv + 16], (torch.eye(4) * (r + 2)).reshape(-1))
+                ok = ok and int(recv[r, nv + 16:nv + 17].view(torch.int32)) == (77 if r == world - 1 else 0)
         ok = ok and torch.equal(results[0][0][:b[4]], results[1][0][:b[4]]) and torch.equal(results[0][1], results[1][1])
         q.put((rank, bool(ok)))
     finally:

@@ -138,6 +138,11 @@ def test_async_overflow_skips_the_update_warns_and_recovers(cuda):
     assert ws.overflows == 1 and ws.capacity >= 2 * M and int(ws.status[0]) == 0
     assert float(out["accumulation"].sum()) > 0.0
     assert not torch.equal(m.flat_params, before)
+    # five step() calls, four updates: the host step counters (bias corrections, torch-layout checkpoints) were told
+    for name in m.group_names:
+        o = opts[name]
+        assert o._shared.t[m.gauss_params[name].storage_offset()] == 4, name
+        assert float(o.state[m.gauss_params[name]]["step"]) == 4.0, name
     with warnings.catch_warnings():
         warnings.simplefilter("error", RuntimeWarning)
         for step in range(5, 8):                                # and asynchronous again

@@ -61,6 +61,27 @@ def test_bench_exchange_path_through_rccl_in_a_group_of_one(cuda):
     assert abs(a - b) <= 2e-3 * b, (a, b)
 
 
+@pytest.mark.gpu
+def test_two_rank_exchanges_agree_and_an_overflow_on_one_rank_skips_the_step_on_all(cuda):
+    """scripts/dp_rehearsal.py on two gloo ranks that share cuda:0: the four exchange forms leave the parameters the plain
+    all-reduce + step leaves, replicas stay bit-identical -- also through a step in which ONE rank's frame overflows its
+    intersection buffer: that rank renders an empty frame and every rank skips the update (the overflow word travels with
+    the exchange; parallel.py), then all train on."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, QED_BENCH_REHEARSE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "scripts", "dp_rehearsal.py")]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-3000:])
+    assert p.stdout.count("step skipped on this rank: True") == 4, p.stdout[-3000:]       # two ranks x two exchange forms
+
+
 def test_launcher_enforces_its_wall_limit_and_reaps_its_children(tmp_path):
     """launch_ranks() must not wait for a wedged rank until the driver's own limit: the process group it started is
     terminated at the wall limit and the exit status is non-zero.  (CPU: the 'ranks' here are a stand-in that sleeps.)"""
