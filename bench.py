@@ -128,7 +128,8 @@ def cpu_baseline(args):
     }
 
 
-def api_path_ms(args, sc, dev, optimizer: str, separate_params: bool = False, host: dict = None) -> float:
+def api_path_ms(args, sc, dev, optimizer: str, separate_params: bool = False, host: dict = None,
+                graph_segments: bool = True) -> float:
     """ms per training step through the REFERENCE's own call sequence, eager dispatch, same scene and same steps
     (W warm-up + K timed from the initial parameters) as the headline number:
 
@@ -144,7 +145,7 @@ def api_path_ms(args, sc, dev, optimizer: str, separate_params: bool = False, ho
     from qed_splatter_amd.model import (FlatAdam, PinholeCameras, QEDSplatterModel, QEDSplatterModelConfig, QedAdam,
                                         exponential_decay_lr)
     n, w, h = args.gaussians, args.width, args.height
-    cfg = QEDSplatterModelConfig.synthetic(sh_degree=3, sh_degree_interval=1)
+    cfg = QEDSplatterModelConfig.synthetic(sh_degree=3, sh_degree_interval=1, graph_segments=graph_segments)
     model = QEDSplatterModel(cfg, separate_params=separate_params,
                              **{k: sc[k].clone() for k in ("means", "scales", "quats", "opacities", "features_dc",
                                                            "features_rest")})
@@ -181,17 +182,27 @@ def api_path_ms(args, sc, dev, optimizer: str, separate_params: bool = False, ho
     # runs of one process) says nothing about the route: collect now, keep the collector off for the timed steps.
     gc.collect()
     gc.disable()
+    from qed_splatter_amd.rasterization import _workspace
+    ws = _workspace(dev)
     try:
+        waited0 = ws.waited_s
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         t_issue = time.perf_counter() - t0             # host time to enqueue the steps (the GPU may still be running)
+        waited = ws.waited_s - waited0
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     finally:
         gc.enable()
     if host is not None:
+        # enqueue = wall time until the last step was enqueued.  The host may run at most ONE frame ahead of the device (each
+        # get_outputs first looks at the previous frame's intersection count), so when the device is the slower side this
+        # is about the step time whatever the host costs; busy = enqueue minus the time spent waiting for that count: what
+        # the host really spends per step, and what bounds the step on a slower host
         host["enqueue_ms_per_step"] = t_issue / args.steps * 1e3
+        host["busy_ms_per_step"] = (t_issue - waited) / args.steps * 1e3
+        host["graph_segments"] = bool(model.__dict__.get("_segments") and model._segments.segments)
     del model, opts
     torch.cuda.empty_cache()
     return dt / args.steps * 1e3
@@ -670,6 +681,13 @@ def main():
             out["api_path_torch_adam_ms_per_step"] = api_torch
             out["api_path_separate_params_ms_per_step"] = api_sep
             out["api_path_host_enqueue_ms_per_step"] = api_host.get("enqueue_ms_per_step")
+            out["api_path_host_busy_ms_per_step"] = api_host.get("busy_ms_per_step")
+            out["api_path_graph_segments"] = api_host.get("graph_segments")
+            if os.environ.get("QED_BENCH_API_EAGER", "1") == "1":
+                # the same route with config.graph_segments = False (every call eager), for comparison
+                eager_host = {}
+                out["api_path_eager_ms_per_step"] = api_path_ms(args, sc, dev, "qed", host=eager_host, graph_segments=False)
+                out["api_path_eager_host_busy_ms_per_step"] = eager_host.get("busy_ms_per_step")
             out["api_path"] = {
                 "sequence": "zero_grad, get_outputs, get_metrics_dict, get_loss_dict, sum, backward, six per-group "
                             "optimisers stepped in turn, means scheduler; eager dispatch; same scene, warm-up and steps",

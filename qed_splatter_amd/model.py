@@ -83,6 +83,10 @@ class QEDSplatterModelConfig:
     # get_outputs(): after the first (calibrating) call do not read the intersection count back every step; a
     # buffer overflow then makes the NEXT call raise (the frame in between rendered empty)
     async_intersection_count: bool = True
+    # get_outputs() of a training step as captured hipGraphs behind one autograd node once a shape has been seen a few
+    # times (segments.py): ~0.3 ms less host work per step.  The step's outputs then live in static buffers that the next
+    # get_outputs overwrites (backward through older outputs raises); False keeps every call eager
+    graph_segments: bool = True
 
     @classmethod
     def synthetic(cls, **kw) -> "QEDSplatterModelConfig":
@@ -150,6 +154,16 @@ def _unit_grad(device) -> Tensor:
     if one is None:
         one = _UNIT_GRADS[device] = torch.ones((), dtype=torch.float32, device=device)
     return one
+
+
+def _refuse_overwritten(rgb: Tensor, who: str) -> None:
+    """Outputs of a captured get_outputs segment live in static buffers: once a later get_outputs has replayed the segment
+    they hold THAT step's image.  Using them is an error, not a silently wrong loss (segments.py)."""
+    tag = getattr(rgb, "_qed_segment", None)
+    if tag is not None and tag[0].generation != tag[1]:
+        raise RuntimeError(f"{who}: these outputs belong to an earlier get_outputs call and have been overwritten (with "
+                           "config.graph_segments a training step's outputs live in static buffers).  Use them before "
+                           "the next get_outputs, or set config.graph_segments = False.")
 
 
 def _is_camera(obj) -> bool:
@@ -225,13 +239,16 @@ class StepContext:
       * ``take_accumulator()``: (holder, rows) through which the loss's backward launch hands the compositing backward a
         zero-filled gradient accumulator -- once; a second loss on the same outputs makes the backward pass fill its own."""
 
-    __slots__ = ("rgb", "_holder", "_rows", "_gt", "ssim")
+    __slots__ = ("rgb", "_holder", "_rows", "_gt", "ssim", "static")
 
     def __init__(self):
         self.rgb = None
         self._holder, self._rows = None, 0
         self._gt = None
         self.ssim = None
+        # a captured segment's static buffers (segments.OutputsSegment): (v_rgb [H,W,3], v_depth [H,W,1] | None, the
+        # compositing backward's accumulator) -- the loss's backward launch writes / zeroes THESE instead of fresh ones
+        self.static = None
 
     def owns(self, outputs) -> bool:
         return self.rgb is not None and outputs.get("rgb") is self.rgb
@@ -255,8 +272,15 @@ class StepContext:
     def take_accumulator(self):
         if self._holder is None:
             return None
-        pair, self._holder = (self._holder, self._rows), None
+        pair, self._holder = (self._holder, self._rows, self.static[2] if self.static is not None else None), None
         return pair
+
+    def take_grad_buffers(self):
+        """(v_rgb, v_depth) static buffers of a captured segment for the loss's backward launch, once; else None."""
+        if self.static is None or self.static[0] is None:
+            return None
+        bufs, self.static = self.static[:2], (None, None, self.static[2])
+        return bufs
 
 
 class _PostProcess(torch.autograd.Function):
@@ -307,10 +331,12 @@ class _ImageLosses(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rgb, depth, gt_rgb, gt_depth, mask, ssim_lambda, depth_lambda, ssim_shared=None, loss_shared=None,
-                vsplat=None):
+                vsplat=None, grad_out=None):
         lib = L.load()
         ctx.set_materialize_grads(False)
-        ctx.vsplat = vsplat       # (holder, rows): the compositing backward's accumulator, zeroed by this node's backward launch
+        # (holder, rows, static buffer | None): the compositing backward's accumulator, zeroed by this node's backward launch
+        ctx.vsplat = vsplat
+        ctx.grad_out = grad_out   # (v_rgb, v_depth) static buffers of a captured get_outputs segment, or None
         if not rgb.is_cuda:
             raise L.QedSplatError("get_loss_dict needs GPU tensors: there is no CPU path in the product")
         H, W, _ = rgb.shape
@@ -363,16 +389,21 @@ class _ImageLosses(torch.autograd.Function):
         def scalar(g):
             return None if g is None else g.to(torch.float32).reshape(1).contiguous()
         g_main, g_depth = scalar(g_main), scalar(g_depth)
-        v_rgb = torch.empty_like(rgb) if (g_main is not None and ctx.needs_input_grad[0]) else None
-        v_depth = torch.empty_like(depth) if (g_depth is not None and depth is not None and ctx.needs_input_grad[1]) \
+        sv_rgb, sv_depth = ctx.grad_out if ctx.grad_out is not None else (None, None)
+
+        def out_like(t, static):
+            return static if (static is not None and static.shape == t.shape) else torch.empty_like(t)
+        v_rgb = out_like(rgb, sv_rgb) if (g_main is not None and ctx.needs_input_grad[0]) else None
+        v_depth = out_like(depth, sv_depth) if (g_depth is not None and depth is not None and ctx.needs_input_grad[1]) \
             else None
         if v_rgb is not None and ssim_lambda > 0.0:
             # ONE launch: the L1 term joins the SSIM term inside the SSIM backward pass, the depth term rides along
             n_out = 3.0 * (H - 10) * (W - 10)
             zero = None
             if ctx.vsplat is not None:
-                holder, rows = ctx.vsplat
-                zero = torch.empty(rows, L.VSPLAT_FLOATS, dtype=torch.float32, device=rgb.device)
+                holder, rows, static = ctx.vsplat
+                zero = static if static is not None else \
+                    torch.empty(rows, L.VSPLAT_FLOATS, dtype=torch.float32, device=rgb.device)
             L.check(lib.qed_image_losses_ssim_bwd(H, W, L.ptr(rgb), L.ptr(depth), L.ptr(gt_rgb), L.ptr(gt_depth),
                                                   L.ptr(mask), L.ptr(maps), L.ptr(sums), 1.0 - ssim_lambda, depth_lambda,
                                                   -ssim_lambda / n_out, L.ptr(g_main), L.ptr(g_depth), L.ptr(v_rgb),
@@ -385,7 +416,7 @@ class _ImageLosses(torch.autograd.Function):
             L.check(lib.qed_image_losses_bwd(H * W, L.ptr(rgb), L.ptr(depth), L.ptr(gt_rgb), L.ptr(gt_depth), L.ptr(mask),
                                              L.ptr(sums), 1.0 - ssim_lambda, depth_lambda, L.ptr(g_main), L.ptr(g_depth), 0,
                                              L.ptr(v_rgb), L.ptr(v_depth), st), "qed_image_losses_bwd")
-        return v_rgb, v_depth, None, None, None, None, None, None, None, None
+        return v_rgb, v_depth, None, None, None, None, None, None, None, None, None
 
 
 class _FusedImageLoss(torch.autograd.Function):
@@ -641,6 +672,34 @@ class QEDSplatterModel(nn.Module):
         accumulation = background.new_zeros(*rgb.shape[:2], 1)
         return {"rgb": rgb, "depth": depth, "accumulation": accumulation, "background": background}
 
+    def _outputs_segment(self, W, H, render_mode, deg, flags, render_fn, cam_c2w, background):
+        """The captured form of this call's device work (segments.OutputsSegment), or None while the shape is still being
+        seen eagerly / after anything the capture was specialised on has changed."""
+        from .rasterization import _workspace
+        from .segments import OutputsSegment, SegmentCache
+        cache = self.__dict__.get("_segments")
+        if cache is None:
+            cache = self.__dict__["_segments"] = SegmentCache()
+        ws = _workspace(self.device)
+        ps = [self.gauss_params[n] for n in GROUP_ORDER]
+        C = cam_c2w[0].shape[0]
+        shape_key = ((W, H), self.num_points, C)
+        key = (shape_key, render_mode, deg, flags, self.config.rasterize_mode, tuple(p.data_ptr() for p in ps),
+               tuple(bool(p.requires_grad) for p in ps))
+        # the count of the previous frame (eager or replayed) comes back here; an overflow drops every capture: their
+        # buffers are too small, and the next call has to read M back
+        ws.poll_pending()
+        if ws.force_sync or not ws.calibrated(shape_key):
+            cache.drop_all()
+            return None
+        seg = cache.get(key)
+        if seg is not None:
+            return seg
+        if not cache.should_capture(key):
+            return None
+        return cache.capture(key, lambda: OutputsSegment(self.device, ps, render_fn, shape_key), cam_c2w[0], cam_c2w[1],
+                             background)
+
     # ---- a2-a10: get_outputs (model.py:199-321) ----
     def get_outputs(self, camera) -> Dict[str, Union[Tensor, List]]:
         if not _is_camera(camera):
@@ -722,45 +781,68 @@ class QEDSplatterModel(nn.Module):
 
         background = self._get_background_color()
         holder: list = []         # (get_loss_dict's backward launch leaves the compositing backward's zeroed accumulator here)
-        render, alpha, info = rasterization(
-            means=means_crop,
-            quats=quats_crop,                       # normalised inside the projection kernel (model.py:269)
-            scales=scales_crop,
-            opacities=opacities_crop,
-            colors=colors,
-            viewmats=viewmat.to(torch.float32),
-            Ks=K.to(torch.float32),
-            width=W,
-            height=H,
-            tile_size=BLOCK_WIDTH,
-            packed=False,
-            near_plane=0.01,
-            far_plane=1e10,
-            render_mode=render_mode,
-            sh_degree=sh_degree_to_use,
-            sparse_grad=False,
-            absgrad=True,
-            rasterize_mode=self.config.rasterize_mode,
-            _flags=flags,
-            _sh_rest=sh_rest,
-            _sync=not (self.config.async_intersection_count and self.training),
-            _c2w=cam_c2w,
-            _post_background=background,
-            _vsplat_holder=holder,
-            _means2d_leaf=True,     # xys is only retained and read (below; densify.py): its gradient arrives as a view
-        )
+
+        def render_fn(c2w, intr, bg, hold, capture_slot=None, viewmats=None, Ks=None, manual=None):
+            """The rasterization(...) call of model.py:267-288 (+ the statements that follow it, inside the compositing
+            kernels): here on this call's tensors, and -- once the shape has been seen a few times -- captured on static
+            ones (segments.OutputsSegment)."""
+            C = 1 if c2w is None else c2w.shape[0]
+            if viewmats is None:
+                viewmats = torch.empty(C, 4, 4, dtype=torch.float32, device=self.device)
+                Ks = torch.empty(C, 3, 3, dtype=torch.float32, device=self.device)
+            return rasterization(
+                means=means_crop,
+                quats=quats_crop,                       # normalised inside the projection kernel (model.py:269)
+                scales=scales_crop,
+                opacities=opacities_crop,
+                colors=colors,
+                viewmats=viewmats,
+                Ks=Ks,
+                width=W,
+                height=H,
+                tile_size=BLOCK_WIDTH,
+                packed=False,
+                near_plane=0.01,
+                far_plane=1e10,
+                render_mode=render_mode,
+                sh_degree=sh_degree_to_use,
+                sparse_grad=False,
+                absgrad=True,
+                rasterize_mode=self.config.rasterize_mode,
+                _flags=flags,
+                _sh_rest=sh_rest,
+                _sync=not (self.config.async_intersection_count and self.training),
+                _c2w=(c2w, intr) if c2w is not None else None,
+                _post_background=bg,
+                _vsplat_holder=hold,
+                _means2d_leaf=True,     # xys is only retained and read (below; densify.py): its gradient arrives as a view
+                _capture_slot=capture_slot,
+                _manual=manual,
+            )
+
+        seg = None
+        if (self.training and self.config.graph_segments and cam_c2w is not None and crop_ids is None
+                and torch.is_grad_enabled() and self.config.async_intersection_count):
+            seg = self._outputs_segment(W, H, render_mode, sh_degree_to_use, flags, render_fn, cam_c2w, background)
+        if seg is not None:
+            rgb, alpha, depth_im = seg.run(cam_c2w[0], cam_c2w[1], background)
+            info, holder, render = seg.info, seg.holder, None
+            ctx.static = (seg.v_rgb[0], seg.v_depth[0] if seg.v_depth is not None else None, seg.vsplat)
+            background = seg.bg
+        else:
+            render, alpha, info = render_fn(cam_c2w[0] if cam_c2w else None, cam_c2w[1] if cam_c2w else None, background,
+                                            holder, viewmats=viewmat.to(torch.float32), Ks=K.to(torch.float32))
+            # model.py:296-297 (composite + clamp) and :304-308 (depth fix-up) ran inside the compositing kernel, and
+            # their backward runs inside the compositing backward (rasterization(_post_background=...)): no pass of its
+            # own over the image in either direction (_PostProcess above is the stand-alone form of the same statements)
+            rgb = info.pop("post_rgb")
+            depth_im = info.pop("post_depth")
         attrs["info"] = info
         attrs["last_compact"] = False
         if self.training and info["means2d"].requires_grad:                   # model.py:289-290 (a no-op on the leaf)
             info["means2d"].retain_grad()
         attrs["xys"] = info["means2d"]                                        # [1,N,2]
         attrs["radii"] = info["radii"][0]                                     # [N]
-
-        # model.py:296-297 (composite + clamp) and :304-308 (depth fix-up) ran inside the compositing kernel, and their
-        # backward runs inside the compositing backward (rasterization(_post_background=...)): no pass of its own over the
-        # image in either direction (_PostProcess below is the stand-alone form of the same statements)
-        rgb = info.pop("post_rgb")
-        depth_im = info.pop("post_depth")
         if depth_im is not None:
             depth_im = depth_im.squeeze(0)
 
@@ -774,6 +856,8 @@ class QEDSplatterModel(nn.Module):
         if background.shape[0] == 3 and not self.training:                    # model.py:313-314
             background = background.expand(H, W, 3)
         rgb = rgb.squeeze(0)
+        if seg is not None:
+            rgb._qed_segment = (seg, seg.generation)       # (get_loss_dict / get_metrics_dict refuse them once overwritten)
         ctx.bind(rgb, holder, info["radii"].numel())
         return {
             "rgb": rgb,
@@ -821,6 +905,7 @@ class QEDSplatterModel(nn.Module):
             raise TypeError("get_loss_dict needs outputs['depth'] (the reference fails the same way with "
                             "output_depth_during_training=False, model.py:87,101)")
         H, W = pred_img.shape[:2]
+        _refuse_overwritten(pred_img, "get_loss_dict")
         ctx = self.__dict__.get("_step")
         mine = ctx is not None and ctx.owns(outputs)          # these outputs are this step's (not kept from an earlier one)
         gt_img = self.composite_with_background(self.get_gt_img(batch["image"]), outputs["background"])
@@ -843,8 +928,10 @@ class QEDSplatterModel(nn.Module):
         # the accumulator of the compositing backward behind THESE outputs is zeroed by this loss's backward launch (the
         # first loss taken on them: a second one leaves the fill to the backward pass)
         pair = ctx.take_accumulator() if (mine and torch.is_grad_enabled()) else None
+        grad_out = ctx.take_grad_buffers() if (mine and torch.is_grad_enabled()) else None
         main, depth = _ImageLosses.apply(pred_img, depth_out, gt_img, depth_batch, mask, float(cfg.ssim_lambda),
-                                         float(cfg.depth_lambda), shared["maps_sum"] if shared else None, loss_shared, pair)
+                                         float(cfg.depth_lambda), shared["maps_sum"] if shared else None, loss_shared, pair,
+                                         grad_out)
         return {"main_loss": main, "scale_reg": self._scale_reg(), "depth_loss": depth}
 
     # ---- get_metrics_dict (model.py:120-197) ----
@@ -870,6 +957,7 @@ class QEDSplatterModel(nn.Module):
             img = batch["image"]
             gt_rgb = resize(img.float() / 255.0 if img.dtype == torch.uint8 else img).to(self.device)[..., :3]
         pred_rgb = outputs["rgb"][0] if outputs["rgb"].dim() == 4 else outputs["rgb"]
+        _refuse_overwritten(outputs["rgb"], "get_metrics_dict")
         has_depth = "depth_image" in batch and outputs.get("depth") is not None
         gt_depth = resize(batch["depth_image"]).to(self.device) if has_depth else None
         # In training the loss that follows needs the SSIM of the same two images WITH the coefficient maps of its

@@ -82,6 +82,7 @@ class _Workspace:
         # optimisers that keep a HOST step counter and take this workspace's overflow word as skip_flag: told when a step
         # was skipped on the device, so that their bias corrections stay in step with their moments
         self.steppers: "weakref.WeakSet" = weakref.WeakSet()
+        self.waited_s = 0.0          # host time spent in poll_pending waiting for the device to reach the previous frame's binning
 
     def host_slot(self):
         """A pinned 4-word buffer for one asynchronous read-back, as (numpy view, address): qed_bin_tiles' last list kernel
@@ -126,7 +127,8 @@ class _Workspace:
             # the host is a frame ahead of the device: wait for that frame's binning.  A few looks back to back (the word
             # usually lands within microseconds), then sleeps that double up to 100 us: a host that runs ahead of a ~1 ms
             # step does not burn a core on it, and wakes at most a tenth of a step late
-            deadline = time.monotonic() + self.POLL_TIMEOUT_S
+            t_wait = time.monotonic()
+            deadline = t_wait + self.POLL_TIMEOUT_S
             looks, nap = 0, 5e-6
             while words[0] < 0:
                 looks += 1
@@ -140,6 +142,7 @@ class _Workspace:
                     if words[0] < 0:
                         raise L.QedSplatError("the intersection count of the previous asynchronous rasterization never "
                                               "arrived (qed_bin_tiles' host_words)")
+            self.waited_s += time.monotonic() - t_wait
         M, overflow, watchdog = int(words[0]), int(words[1]), int(words[2])
         if watchdog:
             self.status.zero_()
@@ -184,6 +187,52 @@ def _workspace(device) -> _Workspace:
     if ws is None:
         ws = _WORKSPACES[idx] = _Workspace(torch.device("cuda", idx))
     return ws
+
+
+# ==================================================================================================
+# the two nodes driven by hand (captured segments: segments.py)
+# ==================================================================================================
+class ManualContext:
+    """Stands in for the autograd context when _ProjectSH / _Composite are run WITHOUT the autograd engine: a captured
+    get_outputs segment calls their forward and, in a second hipGraph, their backward directly.  (The engine pins gradient
+    accumulation to the stream a leaf first ran on and synchronises with it at the end of every backward pass: on the
+    legacy default stream -- where Nerfstudio trains -- that is an illegal call inside a stream capture.)"""
+
+    def __init__(self, needs_input_grad):
+        self.needs_input_grad = tuple(needs_input_grad)
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def set_materialize_grads(self, _value):
+        pass
+
+    def mark_non_differentiable(self, *_tensors):
+        pass
+
+
+def _run_node(fn, manual, needs, *args):
+    """fn.apply(*args), or -- driven by hand -- fn.forward on a ManualContext that is kept in ``manual`` for
+    manual_backward().  ``needs``: needs_input_grad of the hand-driven form (None: from the arguments)."""
+    if manual is None:
+        return fn.apply(*args)
+    if needs is None:
+        needs = [torch.is_tensor(a) and a.requires_grad for a in args]
+    ctx = ManualContext(needs)
+    manual.append(ctx)
+    with torch.no_grad():
+        return fn.forward(ctx, *args)
+
+
+def manual_backward(manual, v_render=None, v_alpha=None, v_rgb=None, v_depth=None):
+    """The backward pass of a rasterization(_manual=[...]) call: (v_means, v_quats, v_scales, v_opacities, v_colors | v_sh0,
+    v_sh_rest, v_viewmats) for upstream gradients of render / alpha / post_rgb / post_depth (any may be None)."""
+    c_proj, c_comp = manual
+    with torch.no_grad():
+        g = _Composite.backward(c_comp, v_render, v_alpha, None, v_rgb, v_depth)
+        v_means2d, v_conics, v_rgb_g, v_opac, v_depths = g[:5]
+        return _ProjectSH.backward(c_proj, v_means2d, v_depths, v_conics, v_opac, v_rgb_g)[:7]
 
 
 # ==================================================================================================
@@ -351,13 +400,16 @@ def _packed_vsplat(C, N, v_means2d, v_depths, v_conics, v_opac, v_rgb, dev) -> T
 # tile binning + sort + compositing
 # ==================================================================================================
 def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, tile_w, tile_h, sync=True, splats=None,
-                  size=None, tile_masks=None):
+                  size=None, tile_masks=None, capture_slot=None):
     """Tile binning (qed_bin_tiles): one C call that leaves the list sorted by (camera, tile, depth) and the tile
     offsets.
 
     Returns (isect_ids, flatten_ids, offsets, M).  With ``sync=False`` -- honoured only for a shape
     ``(width, height, N, C)`` whose capacity has been calibrated by a synchronous call (_Workspace) -- nothing is read
     back: M and isect_ids are None and flatten_ids keeps its capacity length.
+    ``capture_slot`` (while a hipGraph is being captured): the pinned (words, address) pair every REPLAY of the captured
+    launch stores {M, overflow, watchdog} into -- the replaying code sets words[0] = -1 before a replay and hands the pair
+    to ``_Workspace.pending`` after it (segments.OutputsSegment), exactly as an eager asynchronous call does.
     """
     lib = L.load()
     dev = means2d.device
@@ -388,6 +440,8 @@ def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, til
     host = host_ptr = None
     if not sync and not capturing:
         host, host_ptr = ws.host_slot()
+    elif capturing and capture_slot is not None:
+        host, host_ptr = capture_slot
     for _attempt in range(2):
         cap = ws.capacity
         flatten_ids = torch.empty(cap, dtype=torch.int32, device=dev)
@@ -545,7 +599,8 @@ def rasterization(
     absgrad: bool = False, rasterize_mode: str = "classic", radius_clip: float = 0.0, eps2d: float = 0.3,
     backgrounds: Optional[Tensor] = None, _flags: int = 0, _sh_rest: Optional[Tensor] = None,
     _sync: bool = True, _vsplat_holder: Optional[list] = None, _c2w: Optional[Tuple[Tensor, Tensor]] = None,
-    _post_background: Optional[Tensor] = None, _means2d_leaf: bool = False,
+    _post_background: Optional[Tensor] = None, _means2d_leaf: bool = False, _capture_slot=None,
+    _manual: Optional[list] = None,
 ) -> Tuple[Tensor, Tensor, Dict]:
     """Same call surface as the reference's call (model.py:267-288).
 
@@ -598,7 +653,10 @@ def rasterization(
             assert colors.shape[1] >= (deg + 1) ** 2, "colors must hold (sh_degree+1)^2 coefficients"
             sh0, shN = colors, None
 
-    means2d, depths, conics, opac, rgb, radii, splats, tiles_per_gauss, block_sums, tile_masks = _ProjectSH.apply(
+    # (_manual: a list that receives the two nodes' contexts -- the call then runs without autograd, manual_backward()
+    # is its backward pass: what a captured segment replays)
+    means2d, depths, conics, opac, rgb, radii, splats, tiles_per_gauss, block_sums, tile_masks = _run_node(
+        _ProjectSH, _manual, None,
         means, quats, scales, opacities, sh0, shN, viewmats, Ks, int(width), int(height), tile_w, tile_h, deg, flags,
         float(eps2d), float(near_plane), float(far_plane), float(radius_clip),
         *(_c2w if _c2w is not None else (None, None)))
@@ -611,18 +669,21 @@ def rasterization(
     isect_ids, flatten_ids, offsets, M = _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums,
                                                        tile_w, tile_h, sync=_sync, splats=splats if use_packed else None,
                                                        size=(int(width), int(height)),
-                                                       tile_masks=tile_masks if tile_masks.numel() else None)
+                                                       tile_masks=tile_masks if tile_masks.numel() else None,
+                                                       capture_slot=_capture_slot)
     # _means2d_leaf: hand out info["means2d"] as a LEAF holding the same values, which receives .grad / .absgrad from
     # the compositing backward without a copy.  For callers that only retain and read the gradient (the reference:
     # model.py:289-290 and the densification strategy); a loss computed FROM info["means2d"] would not reach the
     # Gaussians through the leaf, which is why it is not the default.
     means2d_out, grad_leaf = means2d, None
-    if _means2d_leaf and means2d.requires_grad:
+    wants_grad = means2d.requires_grad or (_manual is not None and any(_manual[0].needs_input_grad[:6]))
+    if _means2d_leaf and wants_grad:
         means2d_out = means2d.detach().requires_grad_(True)
         grad_leaf = [means2d_out]
-    outs = _Composite.apply(means2d, conics, rgb, opac, depths if channels == 4 else None, splats, flatten_ids, offsets,
-                            backgrounds, int(width), int(height), tile_w, tile_h, channels, bool(absgrad), _vsplat_holder,
-                            _post_background, grad_leaf)
+    outs = _run_node(_Composite, _manual, (wants_grad,) * 5 + (False,) * 13,
+                     means2d, conics, rgb, opac, depths if channels == 4 else None, splats, flatten_ids, offsets,
+                     backgrounds, int(width), int(height), tile_w, tile_h, channels, bool(absgrad), _vsplat_holder,
+                     _post_background, grad_leaf)
     render, alpha, last_ids = outs[:3]
     info = {
         "camera_ids": None, "gaussian_ids": None,

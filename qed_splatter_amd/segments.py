@@ -1,0 +1,204 @@
+"""``get_outputs`` of a training step as two captured hipGraphs behind ONE autograd node.
+
+The reference-shaped route (Nerfstudio's trainer calling ``get_outputs`` -> ``get_metrics_dict`` -> ``get_loss_dict`` ->
+``backward`` -> one optimiser per group; /root/reference/qed_splatter/model.py:199-321, 73-118) enqueues ~25 launches per
+step from Python: three autograd nodes, ~40 allocations, one ctypes call per entry point.  On a slow host that bounds the
+step.  Nothing those launches are given depends on the step once the shape is fixed: the kernels read the intersection
+count from device memory and size their grids by a calibrated capacity (rasterization._Workspace), the parameters are
+updated in place.  So after a few eager calls of a shape the device work behind ``get_outputs`` -- projection, binning, K6,
+the depth fix-up -- is captured into one graph, and its backward -- the tile ordering, K7, the projection backward -- into
+a second one; ``get_outputs`` then costs the host three small copies (camera, intrinsics, background), a graph launch and
+one autograd node, and ``backward`` one more graph launch.
+
+What the captured form gives up, and how it is guarded:
+  * outputs live in STATIC buffers: the tensors ``get_outputs`` returned for step k are overwritten by step k+1's replay.
+    Nerfstudio's trainer never reads them past the step; code that does gets an error from ``backward`` (generation
+    check) instead of the wrong gradients, and ``config.graph_segments = False`` keeps every call's outputs;
+  * the intersection buffer cannot grow inside a graph: the captured binning launch stores {M, overflow} into a pinned
+    word the next call looks at (exactly the eager asynchronous path, ``_Workspace.poll_pending``); an overflow renders
+    that frame empty, skips the optimiser launches on the device, and drops the segment -- the next calls run eagerly
+    (regrown, re-calibrated) and capture again;
+  * anything the capture was specialised on -- image size, number of Gaussians, SH degree in use, render / rasterize
+    mode, the parameters' storage -- is part of the key: a change (resolution schedule, densification) falls back to
+    eager calls and a new capture;
+  * a camera optimiser (camera-to-world matrices that require grad), the eval-time crop box and ``no_grad`` calls stay
+    eager.
+"""
+from __future__ import annotations
+
+import warnings
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib as L
+from .rasterization import _workspace, manual_backward
+
+
+class _SegmentFn(torch.autograd.Function):
+    """One node for the whole of ``get_outputs``' device work: forward = replay of the forward graph, backward = replay
+    of the backward graph on the static upstream-gradient buffers."""
+
+    @staticmethod
+    def forward(ctx, seg: "OutputsSegment", *params):
+        seg.g_fwd.replay()
+        seg.generation += 1
+        ctx.seg, ctx.generation = seg, seg.generation
+        ctx.set_materialize_grads(False)
+        outs = [seg.rgb.detach(), seg.alpha.detach()]
+        if seg.depth is not None:
+            outs.append(seg.depth.detach())
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, v_rgb, v_alpha, v_depth=None):
+        seg = ctx.seg
+        if ctx.generation != seg.generation:
+            raise RuntimeError(
+                "backward through the outputs of an EARLIER get_outputs call: with config.graph_segments the outputs of a "
+                "training step live in static buffers that the next get_outputs overwrites.  Take the loss and call "
+                "backward before the next get_outputs, or set config.graph_segments = False.")
+        if v_rgb is None and v_depth is None and v_alpha is None:
+            return (None,) * (1 + len(seg.params))
+        with_alpha = v_alpha is not None
+        graph, grads = seg.backward_graph(with_alpha)
+        pairs = [(v_rgb, seg.v_rgb), (v_depth, seg.v_depth)] + ([(v_alpha, seg.v_alpha)] if with_alpha else [])
+        for src, dst in pairs:
+            if dst is None:
+                continue
+            if src is None:
+                dst.zero_()
+            elif src.data_ptr() != dst.data_ptr() or src.stride() != dst.stride():
+                dst.copy_(src)                          # (a loss other than _ImageLosses: its gradient is copied in)
+        # the accumulator K7 adds into: zeroed by the loss's own backward launch when that was _ImageLosses (StepContext)
+        if not (seg.holder and seg.holder[0] is seg.vsplat):
+            seg.vsplat.zero_()
+        del seg.holder[:]
+        graph.replay()
+        leaf = seg.info["means2d"]
+        if leaf.requires_grad:                           # model.py:289-292: xys.grad / xys.absgrad for the densifier
+            leaf.grad, leaf.absgrad = seg.leaf_grad, seg.leaf_absgrad
+        # fresh aliases of the static gradient views: autograd adopts an incoming gradient it holds the only reference
+        # to as .grad without copying it (the views stay pieces of ONE allocation in group order: model.flat_grad())
+        return (None,) + tuple(g.detach() if g is not None else None for g in grads)
+
+
+class OutputsSegment:
+    """The captured form of one shape of ``get_outputs`` (see the module docstring).  ``render_fn(c2w, intr, background,
+    holder, capture_slot) -> (render, alpha, info)`` makes the eager ``rasterization(...)`` call of get_outputs on the
+    tensors it is given."""
+
+    def __init__(self, device, params: List[Tensor], render_fn: Callable, shape_key: Tuple,
+                 param_names=("means", "scales", "quats", "opacities", "features_dc", "features_rest")):
+        self.device = device
+        self.params = list(params)
+        self.param_names = tuple(param_names)
+        self.render_fn = render_fn
+        self.shape_key = shape_key                # the workspace's calibration key of this shape: ((W, H), N, C)
+        self.generation = 0
+        self.holder: list = []
+        self._bwd: Dict[bool, Tuple] = {}
+        host = torch.zeros(4, dtype=torch.int32).pin_memory()
+        self.slot = (host.numpy(), host.data_ptr())
+        self._keep = host
+
+    # ---- capture ---------------------------------------------------------------------------------------------
+    def capture(self, c2w: Tensor, intr: Tensor, background: Tensor) -> None:
+        self.c2w, self.intr = c2w.detach().clone(), intr.detach().clone()
+        self.bg = background.detach().to(torch.float32).clone()
+        torch.cuda.synchronize(self.device)
+        self.g_fwd = torch.cuda.CUDAGraph()
+        # thread_local: HIP calls of other threads (a viewer's eval render, RCCL's watchdog) must not break the capture
+        self.manual: list = []                    # the two nodes' contexts: the call runs without the autograd engine
+        with torch.cuda.graph(self.g_fwd, capture_error_mode="thread_local"):
+            render, alpha, info = self.render_fn(self.c2w, self.intr, self.bg, self.holder, self.slot, manual=self.manual)
+        self.render, self.alpha, self.info = render, alpha, info
+        self.rgb = info.pop("post_rgb")
+        self.depth = info.pop("post_depth")
+        dev = self.device
+        self.v_rgb = torch.zeros_like(self.rgb)
+        self.v_depth = torch.zeros_like(self.depth) if self.depth is not None else None
+        self.v_alpha = None
+        self.vsplat = torch.zeros(info["radii"].numel(), L.VSPLAT_FLOATS, dtype=torch.float32, device=dev)
+        self.backward_graph(False)                # the usual backward (nothing downstream used `accumulation`)
+
+    def backward_graph(self, with_alpha: bool):
+        """(graph, static parameter gradients) of the backward pass, captured on first use: without / with a gradient
+        for ``accumulation`` (a loss on the alpha image sends the compositing backward through its general path)."""
+        got = self._bwd.get(with_alpha)
+        if got is not None:
+            return got
+        if with_alpha and self.v_alpha is None:
+            self.v_alpha = torch.zeros_like(self.alpha)
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self.g_fwd.pool(), capture_error_mode="thread_local"):
+            self.holder[:] = [self.vsplat]        # _Composite.backward takes its accumulator from the holder
+            v_means, v_quats, v_scales, v_opac, v_dc, v_rest, _ = manual_backward(
+                self.manual, None, self.v_alpha if with_alpha else None, self.v_rgb, self.v_depth)
+        del self.holder[:]
+        by_name = dict(means=v_means, scales=v_scales, quats=v_quats, opacities=v_opac, features_dc=v_dc, features_rest=v_rest)
+        grads = tuple((by_name[n].view(p.shape) if (by_name[n] is not None and p.requires_grad) else None)
+                      for n, p in zip(self.param_names, self.params))
+        leaf = self.info["means2d"]
+        self.leaf_grad, self.leaf_absgrad = leaf.grad, getattr(leaf, "absgrad", None)
+        self._bwd[with_alpha] = (g, grads)
+        return self._bwd[with_alpha]
+
+    # ---- replay ----------------------------------------------------------------------------------------------
+    def run(self, c2w: Tensor, intr: Tensor, background: Tensor):
+        """One training-step forward: (rgb [1,H,W,3], alpha [1,H,W,1], depth [1,H,W,1] | None, info, holder, grad buffers)."""
+        ws = _workspace(self.device)
+        self.c2w.copy_(c2w)
+        self.intr.copy_(intr)
+        self.bg.copy_(background)
+        self.slot[0][0] = -1                      # (the previous replay's word was read by poll_pending before this call)
+        del self.holder[:]
+        outs = _SegmentFn.apply(self, *self.params)
+        ws.pending = (self.slot[0], self.shape_key)
+        rgb, alpha = outs[0], outs[1]
+        depth = outs[2] if self.depth is not None else None
+        return rgb, alpha, depth
+
+
+class SegmentCache:
+    """The segments of one model: at most ``KEEP`` live captures, one per key; a key is captured on its
+    ``WARM_CALLS``-th eager call (the eager calls calibrate the intersection capacity and warm the allocator)."""
+
+    WARM_CALLS = 3
+    KEEP = 3
+
+    def __init__(self):
+        self.calls: Dict[Tuple, int] = {}
+        self.segments: Dict[Tuple, OutputsSegment] = {}
+        self.disabled: Optional[str] = None       # why capturing was given up for this model (the first failure)
+
+    def drop_all(self) -> None:
+        self.segments.clear()
+        self.calls.clear()
+
+    def get(self, key: Tuple) -> Optional[OutputsSegment]:
+        return self.segments.get(key)
+
+    def should_capture(self, key: Tuple) -> bool:
+        n = self.calls.get(key, 0) + 1
+        if len(self.calls) > 16:
+            self.calls.clear()
+        self.calls[key] = n
+        return self.disabled is None and n > self.WARM_CALLS
+
+    def capture(self, key: Tuple, make: Callable[[], OutputsSegment], c2w, intr, background) -> Optional[OutputsSegment]:
+        try:
+            seg = make()
+            seg.capture(c2w, intr, background)
+        except Exception as e:                    # capturing is an optimisation of dispatch only: stay eager
+            self.disabled = f"{type(e).__name__}: {e}"
+            torch.cuda.synchronize()
+            warnings.warn(f"qed_splatter_amd: get_outputs could not be captured into a hipGraph ({self.disabled}); "
+                          "staying with eager dispatch for this model", RuntimeWarning, stacklevel=3)
+            return None
+        while len(self.segments) >= self.KEEP:    # (oldest first: the shapes of an earlier resolution / size)
+            self.segments.pop(next(iter(self.segments)))
+        self.segments[key] = seg
+        return seg

@@ -965,3 +965,94 @@ def test_step_context_misuse_gives_correct_values_each_time(cuda):
     assert same(ld, ref[0][0])
     sum(ld.values()).backward()
     close(grads(m), ref[0][1])
+
+
+# ---- get_outputs as captured hipGraphs behind one autograd node (segments.py) ---------------------------------------
+def _reference_sequence(m, cam, batch, opts, sched=None):
+    """One iteration of the trainer's call sequence (bench.api_path_ms)."""
+    import functools
+    for o in opts.values():
+        o.zero_grad(set_to_none=True)
+    out = m.get_outputs(cam)
+    md = m.get_metrics_dict(out, batch)
+    ld = m.get_loss_dict(out, batch, md)
+    functools.reduce(torch.add, ld.values()).backward()
+    for o in opts.values():
+        o.step()
+    return out, ld
+
+
+@pytest.mark.parametrize("background", ["black", "random"])
+def test_graphed_get_outputs_trains_like_the_eager_route(cuda, background):
+    """config.graph_segments: after a few eager calls of a shape, get_outputs replays a captured forward graph and its
+    backward replays a captured backward graph (projection / binning / K6 | ordering / K7 / projection backward).  Same
+    kernels on the same data: losses, xys.grad / absgrad and the parameters after ten steps equal the eager route's up to
+    the order of the float atomics.  Outputs of an earlier step are refused once overwritten."""
+    from qed_splatter_amd import rasterization as R
+    from qed_splatter_amd.model import FlatAdam, QedAdam
+    w, h, n = 200, 136, 6000
+    sc = scene(n, w, h, seed=23)
+    runs = {}
+    for graphed in (False, True):
+        R._WORKSPACES.clear()
+        torch.manual_seed(5)                                  # the "random" training background draws from the global generator
+        m, cam, batch = _model(sc, cuda, background_color=background, graph_segments=graphed)
+        m.train()
+        lrs = FlatAdam.DEFAULT_LRS
+        opts = {k: QedAdam([m.gauss_params[k]], lr=lrs[k], eps=1e-15) for k in PARAM_NAMES}
+        losses, outs = [], None
+        for step in range(10):
+            out, ld = _reference_sequence(m, cam, batch, opts)
+            losses.append(torch.stack([v.detach() for v in ld.values()]))
+            if step == 5:
+                kept = out                                    # an earlier step's outputs, used too late below
+        torch.cuda.synchronize()
+        cache = m.__dict__.get("_segments")
+        assert (cache is not None and len(cache.segments) == 1 and cache.disabled is None) == graphed
+        runs[graphed] = (torch.stack(losses).cpu(), m.flat_params.detach().clone(), m.xys.grad.clone(), m.xys.absgrad.clone(),
+                         m.radii.clone(), out["rgb"].detach().clone())
+        if graphed:
+            with pytest.raises(RuntimeError, match="overwritten"):
+                m.get_loss_dict(kept, batch)
+            assert m.info["means2d"] is m.xys and m.xys.grad is not None
+    (l0, p0, g0, a0, r0, i0), (l1, p1, g1, a1, r1, i1) = runs[False], runs[True]
+    assert torch.equal(r0, r1)
+    assert_close(l1, l0.double(), 2e-5, "losses over ten steps")
+    assert_close(i1, i0.double().cpu(), 2e-5, "rgb of the tenth step")
+    assert_close(g1, g0.double().cpu(), 2e-4, "xys.grad")
+    assert_close(a1, a0.double().cpu(), 2e-4, "xys.absgrad")
+    assert float((p1 - p0).abs().max()) <= 2e-3 * float(p0.abs().max())       # ten Adam steps amplify the last bits
+    assert float((p1 - p0).abs().mean()) <= 1e-5 * float(p0.abs().max())
+
+
+def test_graphed_get_outputs_follows_shape_changes_and_other_losses(cuda):
+    """What a capture was specialised on is part of its key: another resolution / SH degree runs eagerly until it has been
+    seen often enough; a loss that is not _ImageLosses (its gradients arrive in tensors of its own, and `accumulation` gets
+    one too) goes through the copy-in path and the general backward graph -- against the eager route's gradients."""
+    w, h, n = 160, 112, 3000
+    sc = scene(n, w, h, seed=29)
+    g = torch.Generator().manual_seed(3)
+    w_rgb = torch.rand(h, w, 3, generator=g).to(cuda)
+    w_acc = torch.rand(h, w, 1, generator=g).to(cuda)
+    w_d = torch.rand(h, w, 1, generator=g).to(cuda)
+    grads = {}
+    for graphed in (False, True):
+        m, cam, batch = _model(sc, cuda, graph_segments=graphed)
+        m.train()
+        for it in range(6):
+            for p in m.parameters():
+                p.grad = None
+            out = m.get_outputs(cam)
+            loss = (out["rgb"] * w_rgb).sum() + (out["accumulation"] * w_acc).sum() + (out["depth"] * w_d).sum()
+            loss.backward()
+        grads[graphed] = {k: m.gauss_params[k].grad.clone() for k in PARAM_NAMES}
+        if graphed:
+            seg = next(iter(m._segments.segments.values()))
+            assert set(seg._bwd) == {False, True}            # the usual graph (captured with the segment) + the general one
+            m.step = 0                                        # SH degree 0 in use: another key -> eager, then its own capture
+            for it in range(5):
+                out = m.get_outputs(cam)
+                (out["rgb"] * w_rgb).sum().backward()
+            assert len(m._segments.segments) == 2
+    for k in PARAM_NAMES:
+        assert_close(grads[True][k], grads[False][k].double().cpu(), 2e-5, f"grad {k} (custom loss through the segment)")
