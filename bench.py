@@ -49,6 +49,10 @@ def parse():
     ap.add_argument("--plain-adam", action="store_true",
                     help="write the 48 N SH-coefficient gradients in the projection backward and read them in the plain "
                          "fused Adam step, instead of expanding them inside the optimiser pass (qed_adam_step_sh)")
+    ap.add_argument("--dp-one-graph", action="store_true",
+                    help="N > 1: try to capture the WHOLE data-parallel step, collectives included, as one hipGraph, with the "
+                         "colour-gradient all-gather issued ahead of the projection backward (also QED_BENCH_DP_ONE_GRAPH=1); "
+                         "falls back to the three graphs around eager collectives when the capture fails")
     ap.add_argument("--launch-timeout", type=float, default=900.0,
                     help="--gpus N > 1 without a launcher: wall limit in seconds for the ranks this process starts")
     ap.add_argument("--graph-split", action="store_true",
@@ -208,6 +212,9 @@ def api_path_ms(args, sc, dev, optimizer: str, separate_params: bool = False, ho
     return dt / args.steps * 1e3
 
 
+_JSON_FD = 1
+
+
 def launch_ranks(args) -> int:
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as FRESH child processes
     (one per GPU, torch.distributed.run over 127.0.0.1) before this process has made any GPU call, relay their
@@ -257,6 +264,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries ONE line, rank 0's JSON.  Libraries print there too (RCCL writes a version banner to stdout when its
+    # first communicator comes up): everything else of this process goes to stderr, the line through the saved descriptor
+    global _JSON_FD
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     # rehearsal aid for a one-GPU box: QED_BENCH_REHEARSE=1 puts every rank on cuda:0 and uses gloo, which
     # exercises the multi-rank control flow (split graphs, rank agreement, barriers) without RCCL
@@ -450,11 +463,39 @@ def main():
             adam_only()
             return losses
 
+        one_graph = [args.dp_one_graph or os.environ.get("QED_BENCH_DP_ONE_GRAPH", "0") in ("1", "2")]
+
         def capture_all():
             """(run, dispatch, graphs): every graph of the step captured afresh -- also after an intersection overflow, when
             the forward+backward graph gets new (larger) buffers and with them new static .grad tensors the optimiser
             graphs must read."""
             opt.dev_state[0] = float(opt.t)           # hand the step counter over to the device-side state
+            if split and multi and dp_compact and one_graph[0]:
+                # the whole data-parallel step in ONE graph: PyTorch captures RCCL collectives issued on (or joined to) the
+                # capture stream; the all-gather leaves from inside the backward pass, ahead of the projection backward
+                def dp_step():
+                    for p in model.parameters():
+                        p.grad = None
+                    losses = model.fused_loss(cam, batch, background=bg, sync=False, compact_sh_grad=True, optimizer=opt)
+                    if os.environ.get("QED_BENCH_DP_ONE_GRAPH") == "2":      # (comparison: the gather behind the whole backward)
+                        model.backward_fused(losses)
+                    else:
+                        P.backward_with_early_gather(model, losses, world)
+                    ex = exchange_grads_compact_begin(model, world)
+                    ex.wait_views()
+                    adam_sh_part()
+                    ex.wait_geometry()
+                    adam_leading_part()
+                    return losses
+                try:
+                    g1 = GraphedTrainStep(dp_step, dev, warmup=3, check_every=0)
+                    return g1.replay, ("ONE hipGraph with the collectives inside: all-gather ahead of the projection backward, "
+                                       "SH groups behind it while the geometry all-reduce is on the links, leading groups"), [g1]
+                except Exception as e:
+                    log(f"one-graph capture of the data-parallel step failed ({type(e).__name__}: {e}); three graphs instead")
+                    torch.cuda.synchronize()
+                    opt.drop_tick()
+                    one_graph[0] = False
             if split:
                 g_fb = GraphedTrainStep(fwd_bwd, dev, warmup=3, check_every=0)
                 g_fb.replay()                          # fills the captured (static) .grad buffers before Adam's
@@ -725,7 +766,7 @@ def main():
                 step_a()
             torch.cuda.synchronize()
             out["cpu_baseline"]["config_a"]["gpu_iters_per_s_same_workload"] = 100 / (time.perf_counter() - ta)
-        print(json.dumps(out), flush=True)
+        os.write(_JSON_FD, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

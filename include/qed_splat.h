@@ -138,6 +138,11 @@ int qed_project_bwd(int32_t N, int32_t C, const float* means, const float* quats
  * does not see a Gaussian holds zeros) and its 4x4 view matrix viewmats + c * viewmat_stride (strides in
  * floats, so that one all-gathered buffer can carry both); v_sh0 / v_shN receive scale * the sums
  * (scale = 1/n_views averages). */
+/* The same clamp-masked colour gradient BEFORE qed_project_bwd has run: out[total,3] = vsplat row slots 8..10 (what
+ * qed_composite_bwd accumulated) under the clamp mask qed_project_fwd kept in plane 9 of sh_jac (total = C * N slots, one
+ * camera per rank in the exchange).  Lets the all-gather of the colour gradients start ahead of the projection backward. */
+int qed_pack_color_grad(int32_t total, const float* vsplat, const float* sh_jac, float* out, void* stream);
+
 int qed_sh_grad_from_views(int32_t N, int32_t n_views, const float* means, const float* viewmats,
                            int64_t viewmat_stride, const float* v_views, int64_t view_stride,
                            int32_t sh_degree, float scale, float* v_sh0, int32_t v_sh0_stride,

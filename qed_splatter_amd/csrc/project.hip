@@ -1078,6 +1078,34 @@ extern "C" int qed_project_bwd(int32_t N, int32_t C, const float* means, const f
     return check_launch("qed_project_bwd");
 }
 
+// The message of the data-parallel exchange BEFORE the projection backward has run: the compositing backward's colour
+// gradient (vsplat row slots 8..10) under the clamp mask the forward pass kept (sh_jac plane 9) is exactly what
+// qed_project_bwd(QED_F_SH_GRAD_COMPACT) writes as v_sh0 -- packed here into [N,3] so that the all-gather of the colour
+// gradients can be on the links while the projection backward runs.
+__global__ void __launch_bounds__(256)
+pack_color_grad_kernel(int total, const float* __restrict__ vsplat, const float* __restrict__ mask_plane,
+                       float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const float4 r = *reinterpret_cast<const float4*>(vsplat + (size_t)i * QED_VSPLAT_FLOATS + 8);     // v_r, v_g, v_b, v_depth
+    const unsigned m = __float_as_uint(mask_plane[i]);
+    // (a slot the camera does not see has an all-zero row -- the compositing backward never touched it -- and an
+    // unwritten mask word: 0 either way)
+    out[3 * (size_t)i] = (m & 1u) ? r.x : 0.f;
+    out[3 * (size_t)i + 1] = (m & 2u) ? r.y : 0.f;
+    out[3 * (size_t)i + 2] = (m & 4u) ? r.z : 0.f;
+}
+
+extern "C" int qed_pack_color_grad(int32_t total, const float* vsplat, const float* sh_jac, float* out, void* stream) {
+    QED_REQUIRE(total >= 0, "bad extent");
+    if (total == 0) return QED_OK;
+    QED_REQUIRE(vsplat && sh_jac && out, "null buffers");
+    QED_REQUIRE(((uintptr_t)vsplat & 15) == 0, "vsplat must be 16-byte aligned");
+    hipLaunchKernelGGL(pack_color_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, total,
+                       vsplat, sh_jac + (size_t)9 * total, out);
+    return check_launch("qed_pack_color_grad");
+}
+
 extern "C" int qed_sh_grad_from_views(int32_t N, int32_t n_views, const float* means, const float* viewmats,
                                       int64_t viewmat_stride, const float* v_views, int64_t view_stride,
                                       int32_t sh_degree, float scale, float* v_sh0, int32_t v_sh0_stride,

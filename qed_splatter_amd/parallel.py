@@ -136,6 +136,93 @@ class CompactExchange:
                 self._geo.mul_(self._scale_after)
 
 
+class early_gather:
+    """Context manager: while it is active, the backward pass of ``model.fused_loss(..., compact_sh_grad=True)`` issues the
+    all-gather of the colour-gradient message ITSELF, between the compositing backward and the projection backward
+    (rasterization.PRE_PROJECT_BWD): the message is K7's colour gradient under the forward pass's clamp mask
+    (qed_pack_color_grad) -- exactly what the projection backward would write -- so the 6 MB per rank are on the links
+    while the projection backward (~30 us at 500 k Gaussians) runs.  ``exchange_grads_compact_begin`` then finds the
+    gather in flight and only adds the geometry all-reduce.
+
+        with early_gather(model, world):
+            model.backward_fused(losses)
+        ex = exchange_grads_compact_begin(model, world)
+        ...
+    """
+
+    def __init__(self, model, world_size: int, group=None):
+        self.model, self.world_size, self.group = model, world_size, group
+
+    def _hook(self, vsplat, sh_jac, total):
+        from . import _lib as L
+        m = self.model
+        N = m.num_points
+        assert total == N, "one camera per rank in the data-parallel exchange"
+        dev = vsplat.device
+        nv, row = 3 * N, 3 * N + 16 + 4
+        n_rows = max(self.world_size, 1)
+        send, recv = _message_buffers(m, row, n_rows, dev)
+        L.check(L.load().qed_pack_color_grad(total, L.ptr(vsplat), L.ptr(sh_jac), L.ptr(send),
+                                             torch.cuda.current_stream().cuda_stream), "qed_pack_color_grad")
+        send[nv:nv + 16] = m.last_viewmat.reshape(-1).to(torch.float32)
+        send[nv + 16:nv + 17].view(torch.int32).copy_(_local_overflow_word(dev))
+        work = None
+        if not _single(self.world_size):
+            if dist.get_backend(self.group) == "nccl":
+                work = dist.all_gather_into_tensor(recv.view(-1), send, group=self.group, async_op=True)
+            else:
+                work = dist.all_gather(list(recv.unbind(0)), send, group=self.group, async_op=True)
+        m._early_gather = (work, send, recv)
+
+    def __enter__(self):
+        from . import rasterization as R
+        self._prev, R.PRE_PROJECT_BWD = R.PRE_PROJECT_BWD, self._hook
+        self.model._early_gather = None
+        return self
+
+    def __exit__(self, *exc):
+        from . import rasterization as R
+        R.PRE_PROJECT_BWD = self._prev
+        return False
+
+
+def backward_with_early_gather(model, losses, world_size: int, group=None) -> None:
+    """``model.backward_fused(losses)`` in two phases run from THIS thread, with the colour-gradient all-gather issued
+    between them: (1) the loss's and the compositing backward (autograd.grad up to the projected splats), (2) pack the
+    message from K7's rows + launch the all-gather, (3) the projection backward.  Same gradients as backward_fused; the
+    6 MB per rank are on the links while the projection backward runs.
+
+    Why not simply from a hook inside ONE backward pass (``early_gather``): the autograd engine runs the nodes on its own
+    worker thread, and ProcessGroupNCCL decides by the CALLING thread's stream state whether a collective is being
+    captured into a graph -- issued from the worker thread during a capture, its work object reaches the watchdog, which
+    queries an event recorded on a capturing stream (hipErrorCapturedEvent) and aborts the process.  From the capturing
+    thread itself the collectives are captured (bench.py --dp-one-graph)."""
+    from .model import _unit_grad
+    from .rasterization import _VSPLAT_REGISTRY
+    info = model.info
+    names = ("means2d", "conics", "colors", "opacities", "depths")
+    inter = [info[k] for k in names]
+    node = inter[0].grad_fn                                        # _ProjectSH's backward node: its saved tensors hold sh_jac
+    loss = losses["loss"]
+    g = torch.autograd.grad(loss, inter, grad_outputs=_unit_grad(loss.device), allow_unused=True)
+    vsplat = _VSPLAT_REGISTRY.get(g[0].untyped_storage().data_ptr())
+    sh_jac = node.saved_tensors[9]
+    eg = early_gather(model, world_size, group)
+    if vsplat is not None and sh_jac is not None and getattr(model, "last_compact", False):
+        model._early_gather = None
+        eg._hook(vsplat, sh_jac, vsplat.shape[0])
+    keep = [(t, gi) for t, gi in zip(inter, g) if gi is not None]
+    torch.autograd.backward([t for t, _ in keep], [gi for _, gi in keep])
+
+
+def _message_buffers(model, row: int, n_rows: int, device):
+    bufs = getattr(model, "_dp_buffers", None)
+    if bufs is None or bufs[0].numel() != row or bufs[1].shape != (n_rows, row) or bufs[0].device != device:
+        bufs = model._dp_buffers = (torch.zeros(row, dtype=torch.float32, device=device),      # (the row's padding stays 0)
+                                    torch.zeros(n_rows, row, dtype=torch.float32, device=device))
+    return bufs
+
+
 def exchange_grads_compact_begin(model, world_size: int, group=None) -> CompactExchange:
     """``exchange_grads_compact(..., rebuild=False)`` with both collectives left in flight, the all-gather of the
     colour gradients FIRST: the SH part of the optimiser (88 us at 500 k Gaussians, two thirds of the Adam pass) needs
@@ -152,17 +239,23 @@ def exchange_grads_compact_begin(model, world_size: int, group=None) -> CompactE
         raise RuntimeError("no gradients to exchange: call backward() first")
     if not getattr(model, "last_compact", False):
         raise RuntimeError("exchange_grads_compact_begin needs gradients from fused_loss(..., compact_sh_grad=True)")
-    geo, send, recv, nv, row = _compact_buffers(model, g, max(world_size, 1))
+    early = getattr(model, "_early_gather", None)
+    model._early_gather = None
+    geo, send, recv, nv, row = _compact_buffers(model, g, max(world_size, 1), fill=early is None)
     if _single(world_size):
         model.sh_views = (1, send[nv:nv + 16].view(1, 16), row, send.view(1, row), row, 1.0)
         model._dp_skip = None
         return CompactExchange(None, None, geo, 1.0)
     nccl = dist.get_backend(group) == "nccl"
-    if nccl:
+    if early is not None:                                         # the backward pass issued the gather itself (early_gather)
+        w_gather = early[0]
+    elif nccl:
         w_gather = dist.all_gather_into_tensor(recv.view(-1), send, group=group, async_op=True)
-        w_reduce = dist.all_reduce(geo, op=dist.ReduceOp.AVG, group=group, async_op=True)
     else:                                                         # gloo (rehearsal / CPU tests)
         w_gather = dist.all_gather(list(recv.unbind(0)), send, group=group, async_op=True)
+    if nccl:
+        w_reduce = dist.all_reduce(geo, op=dist.ReduceOp.AVG, group=group, async_op=True)
+    else:
         w_reduce = dist.all_reduce(geo, op=dist.ReduceOp.SUM, group=group, async_op=True)
     n_views = max(world_size, 1)
     model.sh_views = (n_views, recv[:, nv:], row, recv, row, 1.0 / n_views)
@@ -177,9 +270,10 @@ def _fold_skip_words(model, recv: torch.Tensor, nv: int) -> None:
     torch.amax(words, dim=0, out=_dp_skip_word(model, recv.device))
 
 
-def _compact_buffers(model, g, n_rows: int):
+def _compact_buffers(model, g, n_rows: int, fill: bool = True):
     """(geometry slice of the flat gradient, this rank's message, the receive buffer, 3 N, message length): the
-    message buffers are persistent, so captured graphs keep reading the right memory."""
+    message buffers are persistent, so captured graphs keep reading the right memory.  ``fill=False``: the message has been
+    written already (early_gather)."""
     names, begin = model.group_names, model.group_begin
     i_dc, i_rest = names.index("features_dc"), names.index("features_rest")
     assert i_dc == 4 and i_rest == 5, "group order: geometry groups first, then features_dc, features_rest"
@@ -188,11 +282,10 @@ def _compact_buffers(model, g, n_rows: int):
     # one message per rank: colour gradients + view matrix + (bits of) this rank's intersection-overflow word (4 floats, so
     # that rows stay 16-byte aligned): the optimiser step is skipped on EVERY rank when ANY rank's frame overflowed
     row = nv + 16 + 4
-    bufs = getattr(model, "_dp_buffers", None)
-    if bufs is None or bufs[0].numel() != row or bufs[1].shape != (n_rows, row) or bufs[0].device != g.device:
-        bufs = model._dp_buffers = (torch.zeros(row, dtype=torch.float32, device=g.device),      # (the row's padding stays 0)
-                                    torch.zeros(n_rows, row, dtype=torch.float32, device=g.device))
+    bufs = _message_buffers(model, row, n_rows, g.device)
     send = bufs[0]
+    if not fill:
+        return geo, send, bufs[1], nv, row
     send[:nv] = v_local
     send[nv:nv + 16] = model.last_viewmat.reshape(-1).to(torch.float32)
     send[nv + 16:nv + 17].view(torch.int32).copy_(_local_overflow_word(g.device))

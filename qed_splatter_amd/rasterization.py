@@ -180,6 +180,11 @@ SH_HANDOVER = True
 # under the same parity checks; see tests/test_gpu_parity.py::test_dense_scene_gradients_against_the_fp32_band)
 KEEP_T_FINAL = True
 
+# Called by _ProjectSH.backward right before qed_project_bwd is launched, with (packed gradient rows [C*N,16], sh_jac planes,
+# C * N), when the backward pass writes compact SH gradients: the data-parallel exchange packs the colour-gradient message
+# from them and puts its all-gather on the links while the projection backward runs (parallel.early_gather)
+PRE_PROJECT_BWD = None
+
 
 def _workspace(device) -> _Workspace:
     idx = device.index if device.index is not None else torch.cuda.current_device()
@@ -349,6 +354,8 @@ class _ProjectSH(torch.autograd.Function):
         v_viewmats = None
         if ctx.needs_input_grad[6]:
             v_viewmats = torch.zeros_like(viewmats)
+        if PRE_PROJECT_BWD is not None and sh_jac is not None and (flags & L.F_SH_GRAD_COMPACT):
+            PRE_PROJECT_BWD(vsplat, sh_jac, C * N)
         L.check(lib.qed_project_bwd(
             N, C, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opacities), L.ptr(sh0), sh0_stride, shN_ptr,
             shN_stride, sh_degree, L.ptr(viewmats), L.ptr(Ks), width, height, eps2d, flags, L.ptr(radii),

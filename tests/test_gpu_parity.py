@@ -948,6 +948,45 @@ def test_compact_sh_gradient_exchange_equals_averaged_full_gradients(cuda):
     assert_close(got[:b[4]], full[-1][:b[4]], 1e-5, "geometry gradients unaffected by the compact flag")
 
 
+@pytest.mark.parametrize("deg_step", [30000, 1])
+def test_colour_gradient_message_packed_ahead_of_the_projection_backward(cuda, deg_step):
+    """parallel.backward_with_early_gather: the backward pass in two phases with the data-parallel message -- K7's colour
+    gradient under the forward pass's clamp mask (qed_pack_color_grad) + the view matrix -- packed between them, where a
+    multi-GPU job puts the all-gather on the links.  The message must be exactly what the projection backward writes as
+    compact colour gradient in the same pass, and all gradients must equal backward_fused's; the hook form (early_gather)
+    gives the same message."""
+    from qed_splatter_amd.parallel import backward_with_early_gather, early_gather, exchange_grads_compact_begin
+    w, h, n = 200, 136, 6000
+    sc = scene(n, w, h, seed=14)
+    sc["features_dc"] = sc["features_dc"] - 1.2              # a good share of colours below the clamp: the mask matters
+    ref = None
+    for how in ("plain", "two-phase", "hook"):
+        m, cam, batch = _model(sc, cuda)
+        m.step = deg_step
+        losses = m.fused_loss(cam, batch, compact_sh_grad=True)
+        if how == "plain":
+            m.backward_fused(losses)
+        elif how == "two-phase":
+            backward_with_early_gather(m, losses, 1)
+        else:
+            with early_gather(m, 1):
+                m.backward_fused(losses)
+        g = m.flat_grad().clone()
+        b = m.group_begin
+        if how == "plain":
+            ref = g
+            assert float((g[b[4]:b[5]] == 0).float().mean()) > 0.05          # clamped colours are really there
+            continue
+        send = m._dp_buffers[0]
+        assert torch.equal(send[:3 * n], g[b[4]:b[5]])                        # the message == the compact colour gradient
+        assert torch.equal(send[3 * n:3 * n + 16], m.last_viewmat.reshape(-1))
+        assert_close(g[:b[5]], ref[:b[5]].double().cpu(), 2e-5, f"gradients ({how})")
+        ex = exchange_grads_compact_begin(m, 1)                               # finds the message in place: no second packing
+        ex.wait_views()
+        ex.wait_geometry()
+        assert m.sh_views[0] == 1 and m.sh_views[3].data_ptr() == send.data_ptr()
+
+
 @pytest.mark.parametrize("n,model_step,device_state", [(1237, 30000, False), (1000, 30000, True), (1001, 1, True),
                                                          (258, 0, False), (3, 30000, False)])
 def test_adam_with_sh_gradients_rebuilt_in_the_optimiser_equals_plain_step(cuda, n, model_step, device_state):
