@@ -71,7 +71,7 @@ def make_scene(n, w, h, rank, dev):
     return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sc.items()}
 
 
-def cpu_baseline(args):
+def cpu_baseline(args, m_full=None):
     """The CPU oracle (a port: the reference has no CPU rasterizer) timed on this box's
     host cores on a bounded sample: config B shrunk by div^2 in area AND Gaussian count (same
     Gaussians-per-pixel density), fp32, forward + loss + backward."""
@@ -96,15 +96,94 @@ def cpu_baseline(args):
         loss.backward()
         return out["info"]["flatten_ids"].numel()
 
+    import gc
+    import resource
+
+    def rss_gb():                                    # current resident set (not the process's historical peak)
+        try:
+            with open("/proc/self/statm") as f:
+                return int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE") / 2 ** 30
+        except (OSError, ValueError, IndexError):
+            return 0.0
+
+    def mem_available_gb():
+        try:
+            with open("/proc/meminfo") as f:
+                for ln in f:
+                    if ln.startswith("MemAvailable:"):
+                        return int(ln.split()[1]) / 2 ** 20
+        except OSError:
+            pass
+        return 0.0
+
+    import threading
+    gc.collect()
+    rss0 = rss_gb()
+    seen = [rss0]
+    stop = threading.Event()
+
+    def watch():                                     # resident set sampled every 10 ms while the first iteration runs
+        while not stop.wait(0.01):
+            seen[0] = max(seen[0], rss_gb())
+    th = threading.Thread(target=watch, daemon=True)
+    th.start()
     t0 = time.perf_counter()
     m = one()
     dt = time.perf_counter() - t0
+    stop.set()
+    th.join()
+    # what ONE sample iteration holds at its peak (the autograd graph of every tile's blend, alive until backward)
+    peak_sample = max(seen[0] - rss0, 0.0)
     iters = 1
     while dt < 12.0 and iters < 16:                 # about 10-15 s of CPU work on the GPU box's host share
         one()
         iters += 1
         dt = time.perf_counter() - t0
     sample_it_s = iters / dt
+    # ONE iteration of the configuration itself ("config B timed for 1 fwd+bwd iteration (minutes) or, if > 10
+    # min, extrapolated").  The oracle keeps every tile's [pixels x run] intermediates alive until backward: the
+    # full size needs div^2 times the sample's peak.  It runs only where that fits the host with room to spare and the
+    # sample says it takes under five minutes; otherwise the reason is recorded with the measured numbers.
+    full = {"workload": f"{args.gaussians} Gaussians @ {args.width}x{args.height} (the configuration itself), fp32"}
+    # memory and time of the oracle go with pixels-per-tile x list length, i.e. with the intersection count M (measured:
+    # ~60 B x 256 x M resident at the peak): the full configuration has div^2 times the tiles AND longer runs per tile
+    # (splat radii scale with the image), so the factor is M_full / M_sample -- from the GPU run's own count of the
+    # reference's list when given, else the pessimistic div^4
+    scale = (m_full / max(m, 1)) if m_full else float(div) ** 4
+    est_gb = peak_sample * scale
+    est_s = (dt / iters) * scale
+    avail_gb = mem_available_gb()
+    try:                                             # a container's own limit, where there is one
+        with open("/sys/fs/cgroup/memory.max") as f:
+            v = f.read().strip()
+            if v.isdigit():
+                avail_gb = min(avail_gb, int(v) / 2 ** 30 - rss_gb())
+    except OSError:
+        pass
+    limit_gb = float(os.environ.get("QED_BENCH_CPU_FULL_MAX_GB", "150"))
+    if div == 1:
+        full.update(skipped="the sample is the full configuration")
+    elif peak_sample <= 0.0:
+        full.update(skipped="peak memory of the sample could not be measured")
+    elif 1.3 * est_gb > limit_gb or 1.3 * est_gb > 0.6 * avail_gb or est_s > 300.0:
+        full.update(skipped=f"estimated from the sample: {est_gb:.0f} GiB peak resident memory (the oracle's per-tile autograd "
+                            f"graphs; {avail_gb:.0f} GiB available, limit {limit_gb:.0f}) and {est_s:.0f} s")
+    else:
+        del sc
+        gc.collect()
+        nf, wf, hf = args.gaussians, args.width, args.height
+        sf = O.synthetic_scene(nf, wf, hf, seed=1235)
+        tf = time.perf_counter()
+        psf = {k: sf[k].clone().requires_grad_(True) for k in names}
+        outf = O.splatfacto_outputs(psf["means"], psf["scales"], psf["quats"], psf["opacities"], psf["features_dc"],
+                                    psf["features_rest"], sf["camera_to_worlds"], sf["Ks"], wf, hf, sf["background"])
+        (O.main_loss(outf["rgb"], sf["gt_rgb"], 0.2) + O.depth_l1_loss(outf["depth"], sf["gt_depth"])).backward()
+        dtf = time.perf_counter() - tf
+        full.update(iters=1, seconds=round(dtf, 2), iters_per_s=1.0 / dtf, intersections=outf["info"]["flatten_ids"].numel(),
+                    peak_rss_gib=round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2 ** 20, 1),
+                    estimated_from_sample_gib=round(est_gb, 1))
+        del sf, psf, outf
+        gc.collect()
     # BASELINE.json configs[0] -- 10 k Gaussians, one camera @ 256 x 256, the plumbing case -- timed IN FULL ("config
     # A timed in full (fwd+bwd, 10 iterations)"): the only configuration the CPU runs at its real size
     na, wa, ha = 10_000, 256, 256
@@ -124,11 +203,17 @@ def cpu_baseline(args):
     dta = time.perf_counter() - ta
     config_a = {"workload": f"{na} Gaussians, 1 cam @ {wa}x{ha} (BASELINE configs[0]), fp32, fwd+loss+bwd, full size",
                 "iters": 10, "seconds": round(dta, 3), "iters_per_s": 10 / dta, "intersections": ma}
+    ran_full = "iters_per_s" in full
     return {
-        "value": sample_it_s / (div * div), "unit": "train iters/s (full-workload equivalent)",
-        "cores": cores, "kind": "port", "config_a": config_a,
-        "sample": f"{n} Gaussians @ {w}x{h} (config / {div * div}, same density), fp32, fwd+loss+bwd, "
-                  f"{iters} iters in {dt:.1f}s = {sample_it_s:.3f} sample-iters/s, M={m}; value = that / {div * div}",
+        # the configuration's own iteration when it ran; otherwise the sample's rate / div^2
+        "value": full["iters_per_s"] if ran_full else sample_it_s / (div * div),
+        "unit": "train iters/s" + ("" if ran_full else " (full-workload equivalent)"),
+        "cores": cores, "kind": "port", "config_a": config_a, "full_iteration": full,
+        "sample": (f"ONE iteration of the full configuration in {full['seconds']} s (peak {full['peak_rss_gib']} GiB); beside it " if ran_full
+                   else f"full configuration not run ({full.get('skipped')}); ") +
+                  f"{n} Gaussians @ {w}x{h} (config / {div * div}, same density), fp32, fwd+loss+bwd, "
+                  f"{iters} iters in {dt:.1f}s = {sample_it_s:.3f} sample-iters/s, M={m}"
+                  + ("" if ran_full else f"; value = that / {div * div}"),
     }
 
 
@@ -742,7 +827,7 @@ def main():
             log(f"reference-shaped route: {api_qed:.3f} ms/step (QedAdam), {api_torch:.3f} ms/step (torch.optim.Adam), "
                 f"{api_sep:.3f} ms/step (QedAdam, separate Parameters)")
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"] = cpu_baseline(args, m_full=M_ref)
             # the same full-size configs[0] step on the GPU (fused route, eager dispatch), beside the CPU figure
             from qed_splatter_amd.scene import synthetic_scene
             sa = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synthetic_scene(10_000, 256, 256, seed=1234).items()}
