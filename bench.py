@@ -22,8 +22,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # committed rocprofv3 --pmc summaries the roofline objects quote (re-taken whenever the compositing kernels change)
-PMC_TRAFFIC = "r03_hbm_traffic_pmc.json"
-PMC_VALU = "r03_valu_issue_pmc.json"
+PMC_TRAFFIC = "r04_hbm_traffic_pmc.json"
+PMC_VALU = "r04_valu_issue_pmc.json"
 
 import torch  # noqa: E402
 

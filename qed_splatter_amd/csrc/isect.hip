@@ -6,6 +6,11 @@
 namespace qed {
 
 // ---- exclusive scan of block_sums (one workgroup; n_blocks is N/256, i.e. thousands) -----------
+// Every thread owns kScanPer CONSECUTIVE sums, requested together (one memory round trip per 32 768 sums: the first
+// version walked the array in 1 024-wide slices, one dependent round trip and three barriers each -- 31 us for the
+// 19 532 sums of 5 M slots, 7 us now), scans them in registers, and the 1 024 thread totals are scanned across the
+// workgroup.
+constexpr int kScanPer = 32;
 __global__ void __launch_bounds__(1024)
 isect_scan_kernel(const int* __restrict__ block_sums, int n_blocks, int* __restrict__ block_offsets,
                   int* __restrict__ n_isect, long long capacity, int* __restrict__ status) {
@@ -14,11 +19,16 @@ isect_scan_kernel(const int* __restrict__ block_sums, int n_blocks, int* __restr
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (tid == 0) carry_s = 0;
     __syncthreads();
-    for (int base = 0; base < n_blocks; base += 1024) {
-        const int i = base + tid;
-        const long long v = i < n_blocks ? (long long)block_sums[i] : 0;
-        // inclusive scan within the wave
-        long long x = v;
+    for (int base = 0; base < n_blocks; base += 1024 * kScanPer) {
+        const int i0 = base + tid * kScanPer;
+        int v[kScanPer];
+#pragma unroll
+        for (int j = 0; j < kScanPer; ++j) v[j] = block_sums[i0 + j < n_blocks ? i0 + j : n_blocks - 1];
+        long long mine = 0;
+#pragma unroll
+        for (int j = 0; j < kScanPer; ++j) mine += i0 + j < n_blocks ? v[j] : 0;
+        // inclusive scan of the thread totals within the wave, then across the 16 waves
+        long long x = mine;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const long long y = __shfl_up(x, o, 64);
@@ -29,8 +39,14 @@ isect_scan_kernel(const int* __restrict__ block_sums, int n_blocks, int* __restr
         long long wbase = 0;
         for (int w = 0; w < wid; ++w) wbase += wave_tot[w];
         const long long carry = carry_s;
-        const long long excl = carry + wbase + x - v;
-        if (i < n_blocks) block_offsets[i] = (int)min(excl, (long long)0x7fffffff);
+        long long run = carry + wbase + x - mine;             // exclusive prefix of this thread's first sum
+#pragma unroll
+        for (int j = 0; j < kScanPer; ++j) {
+            if (i0 + j < n_blocks) {
+                block_offsets[i0 + j] = (int)min(run, (long long)0x7fffffff);
+                run += v[j];
+            }
+        }
         __syncthreads();
         if (tid == 1023) carry_s = carry + wbase + x;
         __syncthreads();
