@@ -724,28 +724,12 @@ __device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_rec)[kRecFl
             g.vxy = g.c01 = g.rg = g.bd = (f2){0.f, 0.f};
             g.ax = g.ay = g.c2 = g.s0 = 0.f;
             u64 any_valid = 0;
-#ifdef QED_K7_PAIR_ILP
-            // (experiment) two quadrants that both see the Gaussian in ONE basic block: their chains are independent (other
-            // pixels), so the scheduler can interleave them -- same instructions, same order per accumulator, more ILP per wave
-            auto body = [&](int q) {
-                QED_STAT(11, 1);
-                bwd_quadrant<CH>(pq[q], XY, AC, B, op, cab, cbc, col01, col23, idx, px[q], any_valid, g);
-            };
-            if constexpr (NQ == 4) {
-                const bool a0 = (mq[0] & bit) != 0, a1 = (mq[1] & bit) != 0, a2 = (mq[2] & bit) != 0, a3 = (mq[3] & bit) != 0;
-                if (a0 && a1) { body(0); body(1); } else if (a0) body(0); else if (a1) body(1);
-                if (a2 && a3) { body(2); body(3); } else if (a2) body(2); else if (a3) body(3);
-            } else {
-                if (mq[0] & bit) body(0);
-            }
-#else
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 if (!(mq[q] & bit)) continue;           // wave-uniform: this quadrant cannot see Gaussian t
                 QED_STAT(11, 1);
                 bwd_quadrant<CH>(pq[q], XY, AC, B, op, cab, cbc, col01, col23, idx, px[q], any_valid, g);
             }
-#endif
             if (km) fetch(__builtin_ctzll(km));
             if (any_valid == 0) continue;
             QED_STAT(12, 1);
