@@ -83,10 +83,12 @@ class QEDSplatterModelConfig:
     # get_outputs(): after the first (calibrating) call do not read the intersection count back every step; a
     # buffer overflow then makes the NEXT call raise (the frame in between rendered empty)
     async_intersection_count: bool = True
-    # get_outputs() of a training step as captured hipGraphs behind one autograd node once a shape has been seen a few
-    # times (segments.py): ~0.3 ms less host work per step.  The step's outputs then live in static buffers that the next
-    # get_outputs overwrites (backward through older outputs raises); False keeps every call eager
-    graph_segments: bool = True
+    # get_outputs() of a training step as captured hipGraphs behind one autograd node (segments.py): ~0.15-0.2 ms less host
+    # work per step.  True = "when it pays": a shape is captured once it has been stable for as many calls as the capture
+    # costs (~240) AND the host, not the device, is the slower side; "always" = on the fourth call of a shape (tests,
+    # benchmarks); False = never.  A captured step's outputs live in static buffers that the next get_outputs overwrites
+    # (using older outputs raises)
+    graph_segments: Union[bool, str] = True
 
     @classmethod
     def synthetic(cls, **kw) -> "QEDSplatterModelConfig":
@@ -695,7 +697,7 @@ class QEDSplatterModel(nn.Module):
         seg = cache.get(key)
         if seg is not None:
             return seg
-        if not cache.should_capture(key):
+        if not cache.should_capture(key, self.config.graph_segments, ws):
             return None
         return cache.capture(key, lambda: OutputsSegment(self.device, ps, render_fn, shape_key), cam_c2w[0], cam_c2w[1],
                              background)

@@ -5,10 +5,11 @@ The reference-shaped route (Nerfstudio's trainer calling ``get_outputs`` -> ``ge
 step from Python: three autograd nodes, ~40 allocations, one ctypes call per entry point.  On a slow host that bounds the
 step.  Nothing those launches are given depends on the step once the shape is fixed: the kernels read the intersection
 count from device memory and size their grids by a calibrated capacity (rasterization._Workspace), the parameters are
-updated in place.  So after a few eager calls of a shape the device work behind ``get_outputs`` -- projection, binning, K6,
-the depth fix-up -- is captured into one graph, and its backward -- the tile ordering, K7, the projection backward -- into
-a second one; ``get_outputs`` then costs the host three small copies (camera, intrinsics, background), a graph launch and
-one autograd node, and ``backward`` one more graph launch.
+updated in place.  So once a shape has proved stable AND the host is the slower side (SegmentCache: a capture costs ~35 ms
+at 500 k Gaussians, a replay saves ~0.15 ms of host time and nothing while the device is the bottleneck) the device work
+behind ``get_outputs`` -- projection, binning, K6, the depth fix-up -- is captured into one graph, and its backward -- the
+tile ordering, K7, the projection backward -- into a second one; ``get_outputs`` then costs the host one multi-tensor copy
+(camera, intrinsics, background), a graph launch and one autograd node, and ``backward`` one more graph launch.
 
 What the captured form gives up, and how it is guarded:
   * outputs live in STATIC buffers: the tensors ``get_outputs`` returned for step k are overwritten by step k+1's replay.
@@ -173,35 +174,73 @@ class OutputsSegment:
 
 
 class SegmentCache:
-    """The segments of one model: at most ``KEEP`` live captures, one per key; a key is captured on its
-    ``WARM_CALLS``-th eager call (the eager calls calibrate the intersection capacity and warm the allocator)."""
+    """The segments of one model: at most ``KEEP`` live captures, one per key.
+
+    WHEN a key is captured (``config.graph_segments``):
+      * ``"always"``: on its ``WARM_CALLS``-th eager call (the eager calls calibrate the intersection capacity and warm the
+        allocator) -- tests, benchmarks;
+      * ``True`` (the default, "when it pays"): a capture costs ~35 ms at 500 k Gaussians @ 1080p (measured:
+        scripts/segment_capture_time.py) and saves ~0.15 ms of HOST time per step, and nothing at all while the device is
+        the slower side.  So (i) ski rental: a key is captured only once it has been called as often as the capture costs
+        in savings (~240 calls) -- a shape that densification replaces every 100 steps is never captured, a stable one is
+        captured with at most twice the optimal overhead; and (ii) only if the host is the bottleneck: over those calls
+        it spent less than ``WAIT_FRAC`` of the wall time waiting for the device (``_Workspace.waited_s``: the host can
+        run at most one frame ahead).  A GPU-bound loop therefore stays eager, where a replay would buy nothing."""
 
     WARM_CALLS = 3
     KEEP = 3
+    SAVING_S = 1.5e-4                             # host time one replayed step saves (measured 0.62-0.69 -> 0.45-0.48 ms)
+    WAIT_FRAC = 0.10
 
     def __init__(self):
-        self.calls: Dict[Tuple, int] = {}
+        self.stats: Dict[Tuple, list] = {}        # key -> [calls, wall clock at the window's start, waited_s at its start]
         self.segments: Dict[Tuple, OutputsSegment] = {}
         self.disabled: Optional[str] = None       # why capturing was given up for this model (the first failure)
+        self.capture_s = 0.04                     # cost of a capture: an estimate until one has been timed
+        self.decision = "eager: no shape seen often enough yet"
 
     def drop_all(self) -> None:
         self.segments.clear()
-        self.calls.clear()
+        self.stats.clear()
 
     def get(self, key: Tuple) -> Optional[OutputsSegment]:
         return self.segments.get(key)
 
-    def should_capture(self, key: Tuple) -> bool:
-        n = self.calls.get(key, 0) + 1
-        if len(self.calls) > 16:
-            self.calls.clear()
-        self.calls[key] = n
-        return self.disabled is None and n > self.WARM_CALLS
+    def should_capture(self, key: Tuple, mode, ws=None) -> bool:
+        import time
+        now = time.perf_counter()
+        waited = ws.waited_s if ws is not None else 0.0
+        if len(self.stats) > 16:
+            self.stats.clear()
+        st = self.stats.get(key)
+        if st is None:
+            st = self.stats[key] = [0, now, waited]
+        st[0] += 1
+        if self.disabled is not None:
+            return False
+        if mode == "always":
+            return st[0] > self.WARM_CALLS
+        need = max(self.WARM_CALLS, int(self.capture_s / self.SAVING_S))
+        if st[0] <= need:
+            return False
+        wall = now - st[1]
+        wait_frac = (waited - st[2]) / wall if wall > 0 else 1.0
+        if wait_frac > self.WAIT_FRAC:
+            # the device is the slower side: look again after another `need` calls
+            self.decision = f"eager: the host waited for the device {100 * wait_frac:.0f} % of the last {st[0]} calls"
+            self.stats[key] = [0, now, waited]
+            return False
+        self.decision = f"captured: host-bound (waited {100 * wait_frac:.0f} % of {st[0]} calls)"
+        return True
 
     def capture(self, key: Tuple, make: Callable[[], OutputsSegment], c2w, intr, background) -> Optional[OutputsSegment]:
+        import time
         try:
+            t0 = time.perf_counter()
             seg = make()
             seg.capture(c2w, intr, background)
+            torch.cuda.synchronize(seg.device)
+            self.capture_s = time.perf_counter() - t0
         except Exception as e:                    # capturing is an optimisation of dispatch only: stay eager
             self.disabled = f"{type(e).__name__}: {e}"
             torch.cuda.synchronize()

@@ -996,7 +996,7 @@ def test_graphed_get_outputs_trains_like_the_eager_route(cuda, background):
     for graphed in (False, True):
         R._WORKSPACES.clear()
         torch.manual_seed(5)                                  # the "random" training background draws from the global generator
-        m, cam, batch = _model(sc, cuda, background_color=background, graph_segments=graphed)
+        m, cam, batch = _model(sc, cuda, background_color=background, graph_segments="always" if graphed else False)
         m.train()
         lrs = FlatAdam.DEFAULT_LRS
         opts = {k: QedAdam([m.gauss_params[k]], lr=lrs[k], eps=1e-15) for k in PARAM_NAMES}
@@ -1037,7 +1037,7 @@ def test_graphed_get_outputs_follows_shape_changes_and_other_losses(cuda):
     w_d = torch.rand(h, w, 1, generator=g).to(cuda)
     grads = {}
     for graphed in (False, True):
-        m, cam, batch = _model(sc, cuda, graph_segments=graphed)
+        m, cam, batch = _model(sc, cuda, graph_segments="always" if graphed else False)
         m.train()
         for it in range(6):
             for p in m.parameters():
