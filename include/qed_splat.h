@@ -63,6 +63,10 @@ extern "C" {
 
 int qed_version(void);
 const char* qed_last_error(void);
+
+/* Device-side address of a pinned, mapped host allocation (hipHostGetDevicePointer): what qed_bin_tiles' host_words must
+ * be given.  Host code, no launch. */
+int qed_host_device_pointer(void* host, void** device);
 /* size in bytes of the error/overflow status word block a caller passes as `status` (int32[4]):
  * [0] != 0 -> intersection buffer capacity exceeded (value = required M),
  * [1] != 0 -> radix-sort look-back watchdog fired. */

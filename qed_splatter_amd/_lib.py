@@ -43,6 +43,7 @@ SIGNATURES = {
     "qed_loss_grad": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _I, _F, _F, _P]),
     "qed_sh_grad_from_views": (C.c_int, [_I, _I, _P, _P, _L, _P, _L, _I, _F, _P, _I, _P, _I, _P]),
     "qed_pack_color_grad": (C.c_int, [_I, _P, _P, _P, _P]),
+    "qed_host_device_pointer": (C.c_int, [_P, _P]),
     "qed_lr_exp_decay_dev": (C.c_int, [_P, _P, _F, _F, _I, _P]),
     "qed_densify_accumulate": (C.c_int, [_I, _P, _I, _P, _F, _P, _P, _P, _P]),
     "qed_densify_pos_ints": (C.c_int64, [_I]),

@@ -240,8 +240,10 @@ tile_offsets_kernel(const KeyT* __restrict__ keys, const int* __restrict__ n_dev
     // 16-byte store (a reader that sees word 0 change sees all four) -- every kernel that sets one of them has retired
     // by now, and the caller is spared a copy and an event in the stream (a blit kernel and two barriers: ~10 us
     // between the binning and the compositing pass)
-    if (host_words != nullptr && t0 == 0)
+    if (host_words != nullptr && t0 == 0) {
         *reinterpret_cast<int4*>(host_words) = make_int4(n, status[0], status[1], 0);
+        __threadfence_system();              // (pushed out to the host now, not when the kernel ends)
+    }
     if (n == 0) {
         for (long long i = t0; i <= n_tiles_total; i += nt) offsets[i] = 0;
         return;
@@ -253,8 +255,14 @@ tile_offsets_kernel(const KeyT* __restrict__ keys, const int* __restrict__ n_dev
     for (long long base = 4 * t0; base < n; base += 4 * nt) {
         KeyT k[4];
         const KeyT kp = keys[base > 0 ? base - 1 : 0];
+        if (sizeof(KeyT) == 4 && base + 3 < n) {
+            // one 16-byte load for the four keys (base is a multiple of 4, the array 16-byte aligned)
+            const uint4 q = *reinterpret_cast<const uint4*>(keys + base);
+            k[0] = (KeyT)q.x; k[1] = (KeyT)q.y; k[2] = (KeyT)q.z; k[3] = (KeyT)q.w;
+        } else {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) k[v] = keys[base + v < n ? base + v : n - 1];
+            for (int v = 0; v < 4; ++v) k[v] = keys[base + v < n ? base + v : n - 1];
+        }
         int prev = base > 0 ? lin(kp) : -1;                 // (tile -1: everything up to the first key's tile starts at 0)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {

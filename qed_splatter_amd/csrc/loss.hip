@@ -628,6 +628,22 @@ using namespace qed;
 extern "C" int qed_version(void) { return 1; }
 extern "C" const char* qed_last_error(void) { return g_err; }
 
+// The device-side address of a pinned (page-locked, mapped) host allocation: what a kernel must be given to store into
+// it.  Equal to the host address for hipHostMalloc'ed memory under unified addressing, but not for memory registered
+// after the fact (hipHostRegister; PYTORCH_CUDA_ALLOC_CONF=pinned_use_cuda_host_register) -- ask the runtime.
+extern "C" int qed_host_device_pointer(void* host, void** device) {
+    QED_REQUIRE(host && device, "null pointers");
+    void* d = nullptr;
+    const hipError_t e = hipHostGetDevicePointer(&d, host, 0);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        qed::set_error("qed_host_device_pointer: %s", hipGetErrorString(e));
+        return QED_E_INVALID_ARG;
+    }
+    *device = d;
+    return QED_OK;
+}
+
 static unsigned stream_grid(long long n_items, long long cap = 2048) {
     long long g = (n_items + 255) / 256;
     if (g > cap) g = cap;        // 256 CUs x 8 workgroups, grid-stride the rest

@@ -691,7 +691,7 @@ class QEDSplatterModel(nn.Module):
         # the count of the previous frame (eager or replayed) comes back here; an overflow drops every capture: their
         # buffers are too small, and the next call has to read M back
         ws.poll_pending()
-        if ws.force_sync or not ws.calibrated(shape_key):
+        if ws.force_sync or not ws.calibrated(shape_key) or not ws.host_words_ok:
             cache.drop_all()
             return None
         seg = cache.get(key)

@@ -83,6 +83,7 @@ class _Workspace:
         # was skipped on the device, so that their bias corrections stay in step with their moments
         self.steppers: "weakref.WeakSet" = weakref.WeakSet()
         self.waited_s = 0.0          # host time spent in poll_pending waiting for the device to reach the previous frame's binning
+        self.host_words_ok = True    # False once a count failed to arrive through pinned memory: read-backs by copy from then on
 
     def host_slot(self):
         """A pinned 4-word buffer for one asynchronous read-back, as (numpy view, address): qed_bin_tiles' last list kernel
@@ -92,9 +93,15 @@ class _Workspace:
         pass (a blit kernel and two barrier packets).  At most one read-back is pending at a time (the next call polls it
         before it arms its own), so two slots used in turn are never overwritten in flight."""
         if not self._ring:
+            import ctypes
+            lib = L.load()
             for _ in range(2):
                 host = torch.zeros(4, dtype=torch.int32).pin_memory()
-                self._ring.append((host.numpy(), host.data_ptr(), host))     # (the tensor keeps the memory alive)
+                # the address the KERNEL stores to: the runtime's device-side alias of the pinned block (the same number
+                # under unified addressing, but not for memory pinned by registration)
+                dptr = ctypes.c_void_p()
+                L.check(lib.qed_host_device_pointer(host.data_ptr(), ctypes.addressof(dptr)), "qed_host_device_pointer")
+                self._ring.append((host.numpy(), dptr.value, host))          # (the tensor keeps the memory alive)
         self._ring_at ^= 1
         words, ptr, _keep = self._ring[self._ring_at]
         words[0] = -1
@@ -140,8 +147,14 @@ class _Workspace:
                 if time.monotonic() > deadline:
                     torch.cuda.synchronize(self.device)             # surfaces a device fault as its own error
                     if words[0] < 0:
-                        raise L.QedSplatError("the intersection count of the previous asynchronous rasterization never "
-                                              "arrived (qed_bin_tiles' host_words)")
+                        # the frame has finished and its words are not here: the store into pinned memory does not reach
+                        # this host (a runtime / allocator configuration this was not tested on).  Take the frame's words
+                        # from device memory -- nothing has run since -- and read every later count back by copy.
+                        dev_words = self.words[:3].tolist()
+                        words[0], words[1], words[2] = dev_words[0], dev_words[1], dev_words[2]
+                        self.host_words_ok = False
+                        warnings.warn("qed_splatter_amd: the intersection count did not arrive through pinned host memory; "
+                                      "falling back to a synchronous read-back per call", RuntimeWarning, stacklevel=3)
             self.waited_s += time.monotonic() - t_wait
         M, overflow, watchdog = int(words[0]), int(words[1]), int(words[2])
         if watchdog:
@@ -435,7 +448,7 @@ def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, til
         sync = False
     else:
         ws.poll_pending()
-        if not ws.calibrated(key):
+        if not ws.calibrated(key) or not ws.host_words_ok:
             sync = True                                   # first call of a shape, or the call after an overflow
     if ws.capacity == 0:
         ws.capacity = max(1 << 16, 8 * C * N)

@@ -100,8 +100,11 @@ class OutputsSegment:
         self.generation = 0
         self.holder: list = []
         self._bwd: Dict[bool, Tuple] = {}
+        import ctypes
         host = torch.zeros(4, dtype=torch.int32).pin_memory()
-        self.slot = (host.numpy(), host.data_ptr())
+        dptr = ctypes.c_void_p()                  # the device-side alias of the pinned word (rasterization._Workspace.host_slot)
+        L.check(L.load().qed_host_device_pointer(host.data_ptr(), ctypes.addressof(dptr)), "qed_host_device_pointer")
+        self.slot = (host.numpy(), dptr.value)
         self._keep = host
         self._seen = [None, None, None]           # (source tensor, version) last copied into c2w / intr / bg
 
