@@ -52,3 +52,49 @@ def test_segment_capture_policy_is_ski_rental_and_host_bound_only(monkeypatch):
     c = SegmentCache()
     c.disabled = "RuntimeError: x"
     assert run(c, "a", "always", 50, 1e-3, 0.0) is None
+
+
+def test_step_context_hands_everything_out_once_and_only_to_its_own_outputs():
+    """model.StepContext (CPU: plain tensors): the batch conversion is memoised by source identity + version + downscale
+    factor; the SSIM forward, the accumulator hand-over and a segment's static gradient buffers are each handed out ONCE;
+    `owns` is an identity test on outputs["rgb"]."""
+    import torch
+
+    from qed_splatter_amd.model import StepContext
+    ctx = StepContext()
+    rgb = torch.zeros(4, 5, 3)
+    assert not ctx.owns({"rgb": rgb})                              # nothing bound yet
+    holder: list = []
+    ctx.bind(rgb, holder, 7)
+    assert ctx.owns({"rgb": rgb}) and not ctx.owns({"rgb": rgb.clone()}) and not ctx.owns({})
+    # conversions
+    calls = []
+
+    def convert(img):
+        calls.append(1)
+        return img.float() / 255.0
+    img = torch.full((4, 5, 3), 255, dtype=torch.uint8)
+    a = ctx.gt_image(img, 1, convert)
+    b = ctx.gt_image(img, 1, convert)
+    assert a is b and len(calls) == 1                              # same source, same version, same factor
+    ctx.gt_image(img, 2, convert)
+    assert len(calls) == 2                                         # another downscale factor
+    img.add_(0)                                                    # in-place write: new version
+    ctx.gt_image(img, 2, convert)
+    assert len(calls) == 3
+    ctx.gt_image(img.clone(), 2, convert)
+    assert len(calls) == 4                                         # another tensor
+    # one-shot hand-overs
+    ctx.ssim = {"key": 1}
+    assert ctx.take_ssim() == {"key": 1} and ctx.take_ssim() is None
+    assert ctx.take_grad_buffers() is None                         # no captured segment behind these outputs
+    acc = ctx.take_accumulator()
+    assert acc[0] is holder and acc[1] == 7 and acc[2] is None and ctx.take_accumulator() is None
+    # with a segment's static buffers
+    ctx2 = StepContext()
+    ctx2.bind(rgb, holder, 7)
+    v_rgb, v_depth, vsplat = torch.zeros(4, 5, 3), torch.zeros(4, 5, 1), torch.zeros(7, 16)
+    ctx2.static = (v_rgb, v_depth, vsplat)
+    got = ctx2.take_grad_buffers()
+    assert got[0] is v_rgb and got[1] is v_depth and ctx2.take_grad_buffers() is None
+    assert ctx2.take_accumulator()[2] is vsplat                    # the accumulator survives the gradient buffers' hand-over
