@@ -986,6 +986,16 @@ class QEDSplatterModel(nn.Module):
             out["avg_min_scale"] = nanmean_exp(self.scales[..., -1])                  # model.py:192-194
         return out
 
+    @property
+    def intersection_overflows(self) -> int:
+        """Frames of this device that overflowed their intersection buffer so far (they rendered empty; QedAdam / FlatAdam
+        skipped their updates on the device).  A trainer that steps other optimisers -- torch.optim.Adam is NOT protected
+        by the skip flag: the empty frame's zero gradients still make a momentum-only update -- can watch this count and
+        drop the step when it moves.  The count of a frame arrives one call late (poll_pending).  (An attribute, not a
+        key of the metrics dict: that dict keeps the reference's keys.)"""
+        from .rasterization import _workspace
+        return _workspace(self.device).overflows
+
     def backward_fused(self, losses: Dict[str, Tensor]) -> None:
         """``losses["loss"].backward()`` without the per-step ``ones_like`` fill autograd would launch for the
         seed gradient (the fused loss kernel has already written d loss / d render for a seed of 1)."""

@@ -982,8 +982,8 @@ def _reference_sequence(m, cam, batch, opts, sched=None):
     return out, ld
 
 
-@pytest.mark.parametrize("background", ["black", "random"])
-def test_graphed_get_outputs_trains_like_the_eager_route(cuda, background):
+@pytest.mark.parametrize("background,separate", [("black", False), ("random", False), ("black", True)])
+def test_graphed_get_outputs_trains_like_the_eager_route(cuda, background, separate):
     """config.graph_segments: after a few eager calls of a shape, get_outputs replays a captured forward graph and its
     backward replays a captured backward graph (projection / binning / K6 | ordering / K7 / projection backward).  Same
     kernels on the same data: losses, xys.grad / absgrad and the parameters after ten steps equal the eager route's up to
@@ -997,6 +997,10 @@ def test_graphed_get_outputs_trains_like_the_eager_route(cuda, background):
         R._WORKSPACES.clear()
         torch.manual_seed(5)                                  # the "random" training background draws from the global generator
         m, cam, batch = _model(sc, cuda, background_color=background, graph_segments="always" if graphed else False)
+        if separate:                                          # six tensors that own their storage, as Nerfstudio's parent holds them
+            from qed_splatter_amd.model import QEDSplatterModel
+            m = QEDSplatterModel(m.config, separate_params=True, **{k: sc[k].to(cuda) for k in PARAM_NAMES})
+            m.step = 100
         m.train()
         lrs = FlatAdam.DEFAULT_LRS
         opts = {k: QedAdam([m.gauss_params[k]], lr=lrs[k], eps=1e-15) for k in PARAM_NAMES}
@@ -1009,7 +1013,8 @@ def test_graphed_get_outputs_trains_like_the_eager_route(cuda, background):
         torch.cuda.synchronize()
         cache = m.__dict__.get("_segments")
         assert (cache is not None and len(cache.segments) == 1 and cache.disabled is None) == graphed
-        runs[graphed] = (torch.stack(losses).cpu(), m.flat_params.detach().clone(), m.xys.grad.clone(), m.xys.absgrad.clone(),
+        flat = torch.cat([m.gauss_params[k].detach().reshape(-1) for k in m.group_names])
+        runs[graphed] = (torch.stack(losses).cpu(), flat, m.xys.grad.clone(), m.xys.absgrad.clone(),
                          m.radii.clone(), out["rgb"].detach().clone())
         if graphed:
             with pytest.raises(RuntimeError, match="overwritten"):

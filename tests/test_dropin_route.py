@@ -135,7 +135,7 @@ def test_async_overflow_skips_the_update_warns_and_recovers(cuda):
     with pytest.warns(RuntimeWarning, match="rendered empty"):
         out, _ = _api_step(m, cam, batch, opts, 4)              # regrown, synchronous, trained on
     torch.cuda.synchronize()
-    assert ws.overflows == 1 and ws.capacity >= 2 * M and int(ws.status[0]) == 0
+    assert ws.overflows == 1 and m.intersection_overflows == 1 and ws.capacity >= 2 * M and int(ws.status[0]) == 0
     assert float(out["accumulation"].sum()) > 0.0
     assert not torch.equal(m.flat_params, before)
     # five step() calls, four updates: the host step counters (bias corrections, torch-layout checkpoints) were told
