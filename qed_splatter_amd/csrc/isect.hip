@@ -22,8 +22,17 @@ isect_scan_kernel(const int* __restrict__ block_sums, int n_blocks, int* __restr
     for (int base = 0; base < n_blocks; base += 1024 * kScanPer) {
         const int i0 = base + tid * kScanPer;
         int v[kScanPer];
+        const bool vec = (((uintptr_t)block_sums | (uintptr_t)block_offsets) & 15) == 0;
+        if (vec && i0 + kScanPer <= n_blocks) {                    // eight 16-byte loads instead of thirty-two scalar ones
 #pragma unroll
-        for (int j = 0; j < kScanPer; ++j) v[j] = block_sums[i0 + j < n_blocks ? i0 + j : n_blocks - 1];
+            for (int j = 0; j < kScanPer / 4; ++j) {
+                const int4 q = reinterpret_cast<const int4*>(block_sums + i0)[j];
+                v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kScanPer; ++j) v[j] = block_sums[i0 + j < n_blocks ? i0 + j : n_blocks - 1];
+        }
         long long mine = 0;
 #pragma unroll
         for (int j = 0; j < kScanPer; ++j) mine += i0 + j < n_blocks ? v[j] : 0;
@@ -40,11 +49,23 @@ isect_scan_kernel(const int* __restrict__ block_sums, int n_blocks, int* __restr
         for (int w = 0; w < wid; ++w) wbase += wave_tot[w];
         const long long carry = carry_s;
         long long run = carry + wbase + x - mine;             // exclusive prefix of this thread's first sum
+        if (vec && i0 + kScanPer <= n_blocks) {
 #pragma unroll
-        for (int j = 0; j < kScanPer; ++j) {
-            if (i0 + j < n_blocks) {
-                block_offsets[i0 + j] = (int)min(run, (long long)0x7fffffff);
-                run += v[j];
+            for (int j = 0; j < kScanPer / 4; ++j) {
+                int4 q;
+                q.x = (int)min(run, (long long)0x7fffffff); run += v[4 * j];
+                q.y = (int)min(run, (long long)0x7fffffff); run += v[4 * j + 1];
+                q.z = (int)min(run, (long long)0x7fffffff); run += v[4 * j + 2];
+                q.w = (int)min(run, (long long)0x7fffffff); run += v[4 * j + 3];
+                reinterpret_cast<int4*>(block_offsets + i0)[j] = q;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kScanPer; ++j) {
+                if (i0 + j < n_blocks) {
+                    block_offsets[i0 + j] = (int)min(run, (long long)0x7fffffff);
+                    run += v[j];
+                }
             }
         }
         __syncthreads();
