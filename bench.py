@@ -835,6 +835,16 @@ def main():
                 "api_path_separate_params_ms_per_step": "QedAdam on six SEPARATELY held Parameters (how Nerfstudio's parent "
                                                         "class keeps them): torch.optim.Adam's per-parameter state, one "
                                                         "fused launch per group",
+                "api_path_host_enqueue_ms_per_step": "wall time until the last step was enqueued / steps.  The host can run at most ONE "
+                                                     "frame ahead of the device (every get_outputs first looks at the previous "
+                                                     "frame's intersection count), so this reads ~ the step time whenever the "
+                                                     "device is the slower side, whatever the host costs",
+                "api_path_host_busy_ms_per_step": "enqueue minus the time spent waiting for that count: what the host really spends "
+                                                  "per step (of the form api_path_ms_per_step was timed on)",
+                "api_path_eager_* / api_path_segments_*": "the route with every call eager / with get_outputs and its backward "
+                                                          "replayed from captured hipGraphs behind one autograd node "
+                                                          "(segments.py); api_path_graph_segments says which of the two the "
+                                                          "default capture policy settles on for this box and why",
                 "iters_per_s": 1e3 / api_qed}
             log(f"reference-shaped route: {api_qed:.3f} ms/step (QedAdam), {api_torch:.3f} ms/step (torch.optim.Adam), "
                 f"{api_sep:.3f} ms/step (QedAdam, separate Parameters)")
