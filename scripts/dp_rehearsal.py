@@ -17,8 +17,8 @@ import torch.distributed as dist  # noqa: E402
 
 from qed_splatter_amd import _lib as L  # noqa: E402
 from qed_splatter_amd.model import FlatAdam, PinholeCameras, QEDSplatterModel, QEDSplatterModelConfig  # noqa: E402
-from qed_splatter_amd.parallel import (allreduce_and_step, allreduce_flat_grad, exchange_grads_compact,  # noqa: E402
-                                       exchange_grads_compact_begin)
+from qed_splatter_amd.parallel import (allreduce_and_step, allreduce_flat_grad, backward_with_early_gather,  # noqa: E402
+                                       exchange_grads_compact, exchange_grads_compact_begin)
 from qed_splatter_amd.scene import synthetic_scene  # noqa: E402
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -32,7 +32,7 @@ names = ("means", "scales", "quats", "opacities", "features_dc", "features_rest"
 K = sc["Ks"][0]
 cam = PinholeCameras(sc["camera_to_worlds"][rank:rank + 1].to(dev), float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), w, h)
 batch = {"image": sc["gt_rgb"].to(dev), "depth_image": sc["gt_depth"].to(dev)}
-models = [QEDSplatterModel(QEDSplatterModelConfig.synthetic(sh_degree_interval=1), **{k: sc[k].to(dev) for k in names}) for _ in range(5)]
+models = [QEDSplatterModel(QEDSplatterModelConfig.synthetic(sh_degree_interval=1), **{k: sc[k].to(dev) for k in names}) for _ in range(6)]
 opts = [FlatAdam(m, means_schedule=FlatAdam.MEANS_SCHEDULE) for m in models]
 for m in models:
     m.step = 30000
@@ -40,7 +40,11 @@ for step in range(4):
     for i, (m, o) in enumerate(zip(models, opts)):
         for p in m.parameters():
             p.grad = None
-        m.backward_fused(m.fused_loss(cam, batch, compact_sh_grad=(i >= 2)))
+        losses_i = m.fused_loss(cam, batch, compact_sh_grad=(i >= 2))
+        if i == 5:                              # the all-gather leaves between the compositing and the projection backward
+            backward_with_early_gather(m, losses_i, world)
+        else:
+            m.backward_fused(losses_i)
         if i == 0:
             allreduce_flat_grad(m, world)
             o.step()
@@ -78,8 +82,13 @@ dist.all_gather(gathered4, models[4].flat_params.detach())
 replicas4 = all(torch.equal(gathered4[0], t) for t in gathered4)
 print(f"rank {rank}: overlapped exchange (gather | SH part | all-reduce | leading part) == plain: {same4}; "
       f"replicas identical: {replicas4}", flush=True)
-same = same and same2 and same3 and same4
-replicas = replicas and replicas4
+same5 = bool(((models[0].flat_params - models[5].flat_params).abs() <= 1e-5 + 1e-4 * models[0].flat_params.abs()).all())
+gathered6 = [torch.empty_like(models[5].flat_params) for _ in range(world)]
+dist.all_gather(gathered6, models[5].flat_params.detach())
+replicas5 = all(torch.equal(gathered6[0], t) for t in gathered6)
+print(f"rank {rank}: all-gather issued ahead of the projection backward == plain: {same5}; replicas identical: {replicas5}", flush=True)
+same = same and same2 and same3 and same4 and same5
+replicas = replicas and replicas4 and replicas5
 
 # ---- one rank's frame overflows its intersection buffer: EVERY rank must skip that step ----------------
 # Per-rank cameras make the list length rank dependent, so an overflow need not hit all ranks in the same step; the rank
