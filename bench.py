@@ -434,12 +434,14 @@ def main():
     dp_compact = not args.dp_plain and not args.plain_adam
     fused_sh = dp_compact
 
-    def exchange_and_step(adam_sh, adam_leading, adam_all):
+    def exchange_and_step(adam_sh, adam_leading, adam_all, in_graph=False):
         """N > 1.  Compact exchange: the all-gather of the colour gradients is issued first and the SH part of the
         optimiser (two thirds of its time) runs behind it while the geometry all-reduce is still on the links; the
         leading groups follow that all-reduce.  --dp-plain: one all-reduce of the flat gradient, then the step."""
         if dp_compact:
-            ex = exchange_grads_compact_begin(model, world)
+            # in_graph: the message was assembled at the end of the forward+backward graph and the SH graph folds the
+            # gathered overflow words itself (four eager launches less per step)
+            ex = exchange_grads_compact_begin(model, world, prepared=in_graph, fold=not in_graph)
             ex.wait_views()
             adam_sh()
             ex.wait_geometry()
@@ -538,6 +540,15 @@ def main():
             opt.step(device_state=True, fused_sh=True, part=1)
             return {}
 
+        def fwd_bwd_message():
+            losses = fwd_bwd()
+            P.prepare_compact_message(model, world)
+            return losses
+
+        def fold_adam_sh_part():
+            P.fold_skip_words(model)
+            return adam_sh_part()
+
         def adam_leading_part():
             opt.step(device_state=True, fused_sh=True, part=2)
             return {}
@@ -583,19 +594,19 @@ def main():
                     opt.drop_tick()
                     one_graph[0] = False
             if split:
-                g_fb = GraphedTrainStep(fwd_bwd, dev, warmup=3, check_every=0)
+                g_fb = GraphedTrainStep(fwd_bwd_message if multi and dp_compact else fwd_bwd, dev, warmup=3, check_every=0)
                 g_fb.replay()                          # fills the captured (static) .grad buffers before Adam's
                                                        # warm-up run reads them; keep the replicas identical
                 if multi and dp_compact:
-                    ex = exchange_grads_compact_begin(model, world)
+                    ex = exchange_grads_compact_begin(model, world, prepared=True)
                     ex.wait_views()
                     ex.wait_geometry()
-                    g_sh = GraphedTrainStep(adam_sh_part, dev, warmup=1, check_every=0)
+                    g_sh = GraphedTrainStep(fold_adam_sh_part, dev, warmup=1, check_every=0)
                     g_lead = GraphedTrainStep(adam_leading_part, dev, warmup=1, check_every=0)
 
                     def run_():
                         g_fb.replay()
-                        exchange_and_step(g_sh.replay, g_lead.replay, None)
+                        exchange_and_step(g_sh.replay, g_lead.replay, None, in_graph=True)
                     return run_, ("three hipGraphs (fwd+bwd | Adam SH groups | Adam leading groups): all-gather, SH groups "
                                   "behind it while the geometry all-reduce is on the links, leading groups"), [g_fb, g_sh, g_lead]
                 if multi:
@@ -715,14 +726,14 @@ def main():
 
     if rank == 0:
         ms_step = dt2 / args.steps * 1e3
-        P = w * h
+        n_px = w * h
         # dominant kernel = compositing backward; algorithmic bytes: 92 B per list entry the launch
         # processed + 28 B per pixel.  The list shrinks as training proceeds (config.intersections ->
         # intersections_after_timed_steps), so the mean of the two ends of the run is used.
         dom = "qed_composite_bwd"
         dom_ms = kern.get(dom, (0, float("nan")))[1]
         M_proc = 0.5 * (M + M_end)
-        alg_bytes = 92.0 * M_proc + 28.0 * P
+        alg_bytes = 92.0 * M_proc + 28.0 * n_px
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         # Counter-derived figures of that kernel come from COMMITTED rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
         # cannot share a pass and counters cannot be read from inside this process): valid only for this workload and
@@ -746,7 +757,7 @@ def main():
                 # the same launch priced on the list the REFERENCE operator would have walked for this image (SURVEY 8d's
                 # unit is gsplat's intersection): a shorter list for the same image lowers `frac` while the kernel gets
                 # faster, so both are given; `achieved` / `frac` stay on what the launch really processed
-                "frac_at_reference_list": (92.0 * M_ref * (M_proc / max(M, 1)) + 28.0 * P) / (dom_ms * 1e-3) / 1e9 / 8000.0,
+                "frac_at_reference_list": (92.0 * M_ref * (M_proc / max(M, 1)) + 28.0 * n_px) / (dom_ms * 1e-3) / 1e9 / 8000.0,
                 "note": "algorithmic bytes = 92 B x (list entries this launch processed) + 28 B x pixels (SURVEY 8d).  The "
                         "reference (gsplat) would list list_entries_reference entries for the same image; this run lists "
                         "only the tiles in which some pixel can reach alpha >= 1/255 (exact per-tile test).  The kernel is "

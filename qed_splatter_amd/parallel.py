@@ -223,7 +223,25 @@ def _message_buffers(model, row: int, n_rows: int, device):
     return bufs
 
 
-def exchange_grads_compact_begin(model, world_size: int, group=None) -> CompactExchange:
+def prepare_compact_message(model, world_size: int) -> None:
+    """Assemble this rank's message (colour gradients, view matrix, overflow word) in the persistent send buffer.  What
+    ``exchange_grads_compact_begin`` does first; as a call of its own it can be CAPTURED at the end of the forward+backward
+    graph (three small launches that then cost graph nodes, not eager dispatches) -- pass ``prepared=True`` to the exchange."""
+    g = model.flat_grad()
+    if g is None or not getattr(model, "last_compact", False):
+        raise RuntimeError("prepare_compact_message needs gradients from fused_loss(..., compact_sh_grad=True)")
+    _compact_buffers(model, g, max(world_size, 1), fill=True)
+
+
+def fold_skip_words(model) -> None:
+    """The gathered overflow words -> ``model._dp_skip`` (``exchange_grads_compact_begin(..., fold=False)`` leaves this to
+    the caller, who can capture it in front of the optimiser launches that read the flag)."""
+    bufs = model._dp_buffers
+    _fold_skip_words(model, bufs[1], bufs[0].numel() - 20)
+
+
+def exchange_grads_compact_begin(model, world_size: int, group=None, prepared: bool = False,
+                                 fold: bool = True) -> CompactExchange:
     """``exchange_grads_compact(..., rebuild=False)`` with both collectives left in flight, the all-gather of the
     colour gradients FIRST: the SH part of the optimiser (88 us at 500 k Gaussians, two thirds of the Adam pass) needs
     only that message and runs while the geometry all-reduce is still on the links:
@@ -233,7 +251,11 @@ def exchange_grads_compact_begin(model, world_size: int, group=None) -> CompactE
         ex.wait_geometry(); optimizer.step(fused_sh=True, part=2)      # means, scales, quats, opacities
 
     xGMI is point to point, so the two messages share the same links and are issued back to back, not concurrently.
-    Same result as exchange_grads_compact + step(fused_sh=True)."""
+    Same result as exchange_grads_compact + step(fused_sh=True).
+
+    ``prepared``: the message is in the send buffer already (prepare_compact_message, e.g. captured behind the backward
+    pass).  ``fold=False``: the caller folds the gathered overflow words itself (fold_skip_words) after wait_views() and
+    before the optimiser launches -- in a captured optimiser graph that is a graph node instead of an eager launch."""
     g = model.flat_grad()
     if g is None:
         raise RuntimeError("no gradients to exchange: call backward() first")
@@ -241,7 +263,7 @@ def exchange_grads_compact_begin(model, world_size: int, group=None) -> CompactE
         raise RuntimeError("exchange_grads_compact_begin needs gradients from fused_loss(..., compact_sh_grad=True)")
     early = getattr(model, "_early_gather", None)
     model._early_gather = None
-    geo, send, recv, nv, row = _compact_buffers(model, g, max(world_size, 1), fill=early is None)
+    geo, send, recv, nv, row = _compact_buffers(model, g, max(world_size, 1), fill=early is None and not prepared)
     if _single(world_size):
         model.sh_views = (1, send[nv:nv + 16].view(1, 16), row, send.view(1, row), row, 1.0)
         model._dp_skip = None
@@ -261,7 +283,7 @@ def exchange_grads_compact_begin(model, world_size: int, group=None) -> CompactE
     model.sh_views = (n_views, recv[:, nv:], row, recv, row, 1.0 / n_views)
     _dp_skip_word(model, g.device)              # (exists before anything captures an optimiser launch that reads it)
     return CompactExchange(w_gather, w_reduce, geo, 1.0 if nccl else 1.0 / n_views,
-                           fold=lambda: _fold_skip_words(model, recv, nv))
+                           fold=(lambda: _fold_skip_words(model, recv, nv)) if fold else None)
 
 
 def _fold_skip_words(model, recv: torch.Tensor, nv: int) -> None:

@@ -73,7 +73,7 @@ def _worker(rank, world, port, q):
         allreduce_flat_grad(m, world)
         ok = ok and int(m._dp_skip) == 77
         results = []
-        for overlapped in (False, True):
+        for overlapped in (False, True, "prepared"):
             m2 = QEDSplatterModel(None, **{k: sc[k] for k in PARAM_NAMES})
             flat2 = (torch.arange(total, dtype=torch.float32) + 1.0) * (rank + 1)
             off = 0
@@ -83,7 +83,14 @@ def _worker(rank, world, port, q):
                 off += p.numel()
             m2.last_compact = True
             m2.last_viewmat = torch.eye(4).reshape(1, 4, 4) * (rank + 2)
-            if overlapped:
+            if overlapped == "prepared":                             # message assembled and skip words folded by the caller
+                P.prepare_compact_message(m2, world)                 # (what bench.py captures inside its graphs)
+                ex = exchange_grads_compact_begin(m2, world, prepared=True, fold=False)
+                ex.wait_views()
+                ok = ok and int(m2._dp_skip) == 0                    # not folded yet
+                P.fold_skip_words(m2)
+                ex.wait_geometry()
+            elif overlapped:
                 ex = exchange_grads_compact_begin(m2, world)
                 ex.wait_views()
                 ex.wait_geometry()
@@ -103,7 +110,8 @@ def _worker(rank, world, port, q):
                 ok = ok and torch.equal(recv[r, :nv], (torch.arange(b[4], b[5], dtype=torch.float32) + 1.0) * (r + 1))
                 ok = ok and torch.equal(recv[r, nv:nv + 16], (torch.eye(4) * (r + 2)).reshape(-1))
                 ok = ok and int(recv[r, nv + 16:nv + 17].view(torch.int32)) == (77 if r == world - 1 else 0)
-        ok = ok and torch.equal(results[0][0][:b[4]], results[1][0][:b[4]]) and torch.equal(results[0][1], results[1][1])
+        for other in results[1:]:
+            ok = ok and torch.equal(results[0][0][:b[4]], other[0][:b[4]]) and torch.equal(results[0][1], other[1])
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
