@@ -89,6 +89,13 @@ class QEDSplatterModelConfig:
     # benchmarks); False = never.  A captured step's outputs live in static buffers that the next get_outputs overwrites
     # (using older outputs raises)
     graph_segments: Union[bool, str] = True
+    # Training steps whose six groups are stepped by QedAdam keep the SH gradients of features_dc / features_rest in the
+    # compact form of the fused step (3 floats per Gaussian + the view; the optimiser evaluates b_k(dir) x colour gradient
+    # itself) instead of writing and re-reading 48 N floats: 26 us of 57 in the projection backward at 500 k Gaussians.
+    # ``.grad`` of the two Parameters stays correct for every Python reader: reading it materialises the full gradients in
+    # place (_LazySHGradParameter); after QedAdam has consumed the compact form it is None (as after zero_grad()).  False:
+    # always write the full gradients
+    lazy_sh_grad: bool = True
 
     @classmethod
     def synthetic(cls, **kw) -> "QEDSplatterModelConfig":
@@ -484,6 +491,53 @@ class _FusedImageLoss(torch.autograd.Function):
         return v_render, v_alpha, None, None, None, None, None, None, None, None, None
 
 
+def write_sh_grads(means: Tensor, viewmat: Tensor, sh_degree: int, v_color: Tensor, v_rest: Tensor) -> None:
+    """In place: ``v_color`` [N,3] (the clamp-masked colour gradient qed_project_bwd leaves with QED_F_SH_GRAD_COMPACT)
+    becomes the gradient of features_dc, ``v_rest`` [N,KR,3] receives the active coefficients' gradients (one view)."""
+    n = v_color.shape[0]
+    with torch.no_grad():
+        L.check(L.load().qed_sh_grad_from_views(
+            n, 1, L.ptr(means), L.ptr(viewmat), 16, L.ptr(v_color), 3 * n, int(sh_degree), 1.0,
+            L.ptr(v_color), 3, L.ptr(v_rest), v_rest.numel() // max(n, 1), _stream()), "qed_sh_grad_from_views")
+
+
+_RAW_GRAD = torch.Tensor.grad                 # the C-level descriptor: reads / writes the field without the subclass's hooks
+
+
+def _raw_grad(p: Tensor) -> Optional[Tensor]:
+    return _RAW_GRAD.__get__(p)
+
+
+class _LazySHGradParameter(nn.Parameter):
+    """features_dc / features_rest of a flat-buffer model.  A backward pass may leave their gradients in the compact form
+    (QEDSplatterModel._lazy_sh: clamp-masked colour gradient + view); the autograd engine then stores the views of the flat
+    gradient allocation in the ``.grad`` FIELD as always, but the memory does not hold the coefficient gradients yet.
+    ``.grad`` read from Python first writes them there (one qed_sh_grad_from_views launch, in place), so every reader --
+    torch.optim.*, clip_grad_norm_, GradScaler.unscale_, logging -- sees what the reference's backward pass produces; only
+    QedAdam, which evaluates the product itself, looks at the field without asking for that."""
+
+    @property
+    def grad(self):
+        owner = self.__dict__.get("_qed_owner")
+        if owner is not None:
+            m = owner()
+            if m is not None and m.__dict__.get("_lazy_sh") is not None:
+                m._materialise_sh_grads()
+        return _RAW_GRAD.__get__(self)
+
+    @grad.setter
+    def grad(self, value):
+        owner = self.__dict__.get("_qed_owner")
+        m = owner() if owner is not None else None
+        if m is not None and m.__dict__.get("_lazy_sh") is not None:
+            if value is not None:                    # (somebody assigns one of the two: give the other its values first)
+                m._materialise_sh_grads()
+            _RAW_GRAD.__set__(self, value)
+            m._lazy_sh_dropped()
+            return
+        _RAW_GRAD.__set__(self, value)
+
+
 class QEDSplatterModel(nn.Module):
     """Mirror of QEDSplatterModel (model.py:50-321) for the render hot path."""
 
@@ -521,11 +575,83 @@ class QEDSplatterModel(nn.Module):
             src = srcs[name]
             n = src.numel()
             flat[off:off + n] = src.reshape(-1).to(torch.float32)
-            params[name] = nn.Parameter(flat[off:off + n].view(src.shape))
+            params[name] = self._make_param(name, flat[off:off + n].view(src.shape))
             off += n
             self.group_begin.append(off)
         self._flat = flat
         self.gauss_params = nn.ParameterDict(params)          # same container name as SplatfactoModel
+
+    def _make_param(self, name: str, view: Tensor) -> nn.Parameter:
+        """A leaf view of the flat buffer; the two SH groups can hold their gradient in compact form (lazy_sh_grad)."""
+        if name not in ("features_dc", "features_rest"):
+            return nn.Parameter(view)
+        p = _LazySHGradParameter(view)
+        p._qed_owner = weakref.ref(self)
+        return p
+
+    # ---- lazy SH gradients (config.lazy_sh_grad) ----
+    def _lazy_sh_wanted(self, sh_degree_to_use, crop_ids) -> bool:
+        """May THIS training step's backward pass leave the SH gradients compact?  Only when all six groups of the flat
+        buffer are stepped by QedAdam instances (their fused launch runs the SH groups before it moves the means the SH basis
+        is evaluated at), nothing waits in the two ``.grad`` fields and the whole Gaussian set is rendered."""
+        attrs = self.__dict__
+        if attrs.get("_lazy_sh") is not None and self.training and torch.is_grad_enabled():
+            # an earlier backward pass's compact gradients are still in the fields (no zero_grad in between): the pass that
+            # follows this forward will be ADDED to them, so they are completed now
+            self._materialise_sh_grads()
+            return False
+        if not (self.config.lazy_sh_grad and self.training and sh_degree_to_use is not None and crop_ids is None
+                and attrs.get("_flat") is not None and torch.is_grad_enabled()):
+            return False
+        dc, rest = self.gauss_params["features_dc"], self.gauss_params["features_rest"]
+        if type(dc) is not _LazySHGradParameter or type(rest) is not _LazySHGradParameter \
+                or not (dc.requires_grad and rest.requires_grad and self.gauss_params["means"].requires_grad):
+            return False
+        st = _FLAT_STATES.get(self._flat.untyped_storage().data_ptr())
+        if st is None or len(st.members) != len(self.group_names):
+            return False
+        return attrs.get("_lazy_sh") is None and _raw_grad(dc) is None and _raw_grad(rest) is None
+
+    def _lazy_sh_begin(self, v_sh0: Tensor, v_shN: Optional[Tensor], viewmats: Tensor, sh_degree: int) -> bool:
+        """Asked by the projection backward (rasterization(_lazy_sh=...)) right before its launch: True = write the compact
+        form into ``v_sh0`` (and leave ``v_shN``'s active coefficients unwritten), recorded here until it is consumed
+        (QedAdam), materialised (a ``.grad`` read) or dropped (``.grad = None``).  False (gradients of an earlier backward
+        pass are waiting in the fields: autograd is about to ADD to them): those are completed first and this pass writes
+        full gradients."""
+        dc, rest = self.gauss_params["features_dc"], self.gauss_params["features_rest"]
+        if self.__dict__.get("_lazy_sh") is not None:
+            self._materialise_sh_grads()
+            return False
+        if _raw_grad(dc) is not None or _raw_grad(rest) is not None or v_shN is None or viewmats.shape[0] != 1:
+            return False
+        means = self.gauss_params["means"]
+        # (aliases of the two views, not the objects themselves: the engine adopts an incoming gradient as the .grad field
+        # without a copy only while nobody else holds that tensor object -- a reference kept here would make it clone)
+        self.__dict__["_lazy_sh"] = {"v_color": v_sh0.detach(), "v_rest": v_shN.detach(), "viewmat": viewmats,
+                                     "deg": int(sh_degree),
+                                     "n": int(v_sh0.shape[0]), "means_version": means._version,
+                                     "means_ptr": means.data_ptr()}
+        return True
+
+    def _lazy_sh_dropped(self) -> None:
+        """A ``.grad`` field of the two was overwritten: with both empty the compact form is gone."""
+        if _raw_grad(self.gauss_params["features_dc"]) is None and _raw_grad(self.gauss_params["features_rest"]) is None:
+            self.__dict__["_lazy_sh"] = None
+
+    def _materialise_sh_grads(self) -> None:
+        """Write the coefficient gradients the compact form stands for into the very allocation the ``.grad`` fields view
+        (features_dc: b_0 x colour gradient in place of the colour gradient; features_rest: the active coefficients)."""
+        rec = self.__dict__.get("_lazy_sh")
+        if rec is None:
+            return
+        self.__dict__["_lazy_sh"] = None
+        means = self.gauss_params["means"]
+        if means._version != rec["means_version"] or means.data_ptr() != rec["means_ptr"] or means.shape[0] != rec["n"]:
+            raise RuntimeError(
+                "lazy SH gradients: the means were modified after the backward pass and before the gradients of features_dc "
+                "/ features_rest were read (the SH basis is evaluated at the means of the forward pass).  Step all six groups "
+                "with QedAdam, read the gradients before stepping, or set config.lazy_sh_grad = False")
+        write_sh_grads(means, rec["viewmat"], rec["deg"], rec["v_color"], rec["v_rest"])
 
     def rebind_flat(self, flat: Tensor, n_points: int) -> None:
         """Adopt a new flat parameter buffer (densification changes N): the six Parameters are
@@ -539,11 +665,12 @@ class QEDSplatterModel(nn.Module):
         params, begin, off = {}, [0], 0
         for name in self.group_names:
             n = n_points * widths[name]
-            params[name] = nn.Parameter(flat[off:off + n].view(shapes[name]))
+            params[name] = self._make_param(name, flat[off:off + n].view(shapes[name]))
             off += n
             begin.append(off)
         self._flat = flat
         self.group_begin = begin
+        self.__dict__["_lazy_sh"] = None
         self.gauss_params = nn.ParameterDict(params)
 
     # ---- parameter groups (same names as the reference reads at model.py:227-239) ----
@@ -699,8 +826,12 @@ class QEDSplatterModel(nn.Module):
             return seg
         if not cache.should_capture(key, self.config.graph_segments, ws):
             return None
-        return cache.capture(key, lambda: OutputsSegment(self.device, ps, render_fn, shape_key), cam_c2w[0], cam_c2w[1],
-                             background)
+        def make():
+            seg = OutputsSegment(self.device, ps, render_fn, shape_key)
+            seg.lazy_owner = weakref.ref(self) if (flags & L.F_SH_GRAD_COMPACT) else None
+            return seg
+
+        return cache.capture(key, make, cam_c2w[0], cam_c2w[1], background)
 
     # ---- a2-a10: get_outputs (model.py:199-321) ----
     def get_outputs(self, camera) -> Dict[str, Union[Tensor, List]]:
@@ -781,6 +912,11 @@ class QEDSplatterModel(nn.Module):
             colors, sh_rest = features_dc_crop, None
             flags |= L.F_SIGMOID_COLORS                                       # torch.sigmoid(colors) fused
 
+        # the SH gradients of this step may stay compact until somebody reads them (config.lazy_sh_grad)
+        lazy = self._lazy_sh_wanted(sh_degree_to_use, crop_ids)
+        if lazy:
+            flags |= L.F_SH_GRAD_COMPACT
+
         background = self._get_background_color()
         holder: list = []         # (get_loss_dict's backward launch leaves the compositing backward's zeroed accumulator here)
 
@@ -820,6 +956,8 @@ class QEDSplatterModel(nn.Module):
                 _means2d_leaf=True,     # xys is only retained and read (below; densify.py): its gradient arrives as a view
                 _capture_slot=capture_slot,
                 _manual=manual,
+                # (a captured backward pass always writes the compact form; _SegmentFn.backward asks per replay)
+                _lazy_sh=self._lazy_sh_begin if (lazy and manual is None) else None,
             )
 
         seg = None
@@ -1009,6 +1147,8 @@ class QEDSplatterModel(nn.Module):
         for an upstream gradient of 1); the two parts are detached views for logging.  Numerically the
         same quantities as get_outputs + get_loss_dict."""
         assert camera.shape[0] == 1, "Only one camera at a time"
+        if self.__dict__.get("_lazy_sh") is not None and torch.is_grad_enabled():
+            self._materialise_sh_grads()          # (compact gradients of a get_outputs step nobody consumed: see there)
         cfg = self.config
         self.__dict__["_step"] = StepContext()   # (conversions of the batch are shared within a step, never across steps)
         # the coarse-to-fine schedule of get_outputs (model.py:244-250): render at 1/d of the camera's resolution
@@ -1532,7 +1672,7 @@ class QedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         p = self.param_groups[0]["params"][0]
-        if p.grad is None:
+        if _raw_grad(p) is None:               # (the field itself: a compact SH gradient is not materialised by asking)
             return loss
         with torch.no_grad():
             if p.storage_offset() == 0 and not self._is_flat_view(p):
@@ -1610,10 +1750,10 @@ class QedAdam(torch.optim.Optimizer):
         if st is not None and st.pending:
             self._launch(st, sorted(st.pending))
         p = self.param_groups[0]["params"][0]
-        g = p.grad
+        g = _raw_grad(p)
         if g is not None:
             if set_to_none:
-                p.grad = None
+                p.grad = None                          # (through the subclass's setter: drops a compact form nobody read)
             else:
                 if g.grad_fn is not None:
                     g.detach_()
@@ -1627,7 +1767,15 @@ class QedAdam(torch.optim.Optimizer):
         lib = L.load()
         members = [st.members[o] for o in offs]
         ps = [m.param_groups[0]["params"][0] for m in members]
-        gs = [p.grad for p in ps]
+        # compact SH gradients (QEDSplatterModel, lazy_sh_grad): consumed as they are when this launch covers all six
+        # groups in one run (below); any other launch first has the coefficient gradients written out
+        owner = ps[-1].__dict__.get("_qed_owner")
+        model = owner() if owner is not None else None
+        lazy = model.__dict__.get("_lazy_sh") if model is not None else None
+        if lazy is not None and len(offs) != len(st.members):
+            model._materialise_sh_grads()
+            lazy = None
+        gs = [_raw_grad(p) for p in ps]
         for mem, p in zip(members, ps):
             if not mem._views_intact(p):
                 mem._expose_views(st)          # (re-creates the views, or refuses moments that were replaced from outside)
@@ -1651,6 +1799,10 @@ class QedAdam(torch.optim.Optimizer):
         skip = _skip_flag(ps[0].device)
         flat_ptr = st.flat_ptr
         m_ptr, v_ptr = st.exp_avg.data_ptr(), st.exp_avg_sq.data_ptr()
+        if lazy is not None and not (len(runs) == 1 and offs[0] == 0 and gptr[0] % 16 == 0
+                                     and gs[0].is_contiguous() and gs[0].dtype == torch.float32):
+            model._materialise_sh_grads()              # (the six groups do not form one run: plain gradients, then)
+            lazy = None
         for run in runs:
             first, last = run[0], run[-1]
             lo, hi = offs[first], offs[last] + n_el[last]
@@ -1676,9 +1828,22 @@ class QedAdam(torch.optim.Optimizer):
             k = len(run)
             h_begin = (C.c_int64 * (k + 1))(*[offs[i] - lo for i in run], hi - lo)
             h_lr = (C.c_float * k)(*[st.pending[offs[i]] for i in run])
-            L.check(lib.qed_adam_step(flat_ptr + 4 * lo, gptr[first], m_ptr + 4 * lo, v_ptr + 4 * lo, k,
-                                      C.cast(h_begin, C.c_void_p), C.cast(h_lr, C.c_void_p), float(beta1), float(beta2),
-                                      float(eps), t, skip, stream), "qed_adam_step")
+            if lazy is not None:
+                # the fused step's optimiser launches: the SH groups from the colour gradient + the view (before the means
+                # move), then the leading groups.  The two fields are emptied: the compact form is used up
+                n = lazy["n"]
+                L.check(lib.qed_adam_step_sh(
+                    flat_ptr, gptr[first], m_ptr, v_ptr, k, C.cast(h_begin, C.c_void_p), C.cast(h_lr, C.c_void_p), None,
+                    float(beta1), float(beta2), float(eps), t, None, -1, 0.0, 0.0, 0, n, lazy["deg"], flat_ptr + 4 * offs[0],
+                    1, L.ptr(lazy["viewmat"]), 16, L.ptr(lazy["v_color"]), 0, 1.0, 3, skip, stream), "qed_adam_step_sh")
+                model.__dict__["_lazy_sh"] = None
+                _RAW_GRAD.__set__(ps[-1], None)
+                _RAW_GRAD.__set__(ps[-2], None)
+                lazy = None
+            else:
+                L.check(lib.qed_adam_step(flat_ptr + 4 * lo, gptr[first], m_ptr + 4 * lo, v_ptr + 4 * lo, k,
+                                          C.cast(h_begin, C.c_void_p), C.cast(h_lr, C.c_void_p), float(beta1), float(beta2),
+                                          float(eps), t, skip, stream), "qed_adam_step")
             ft = float(t)
             for i in run:
                 st.t[offs[i]] = t

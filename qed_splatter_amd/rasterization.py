@@ -259,8 +259,9 @@ def manual_backward(manual, v_render=None, v_alpha=None, v_rgb=None, v_depth=Non
 class _ProjectSH(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, quats, scales, opacities, sh0, shN, viewmats, Ks, width, height, tile_w, tile_h,
-                sh_degree, flags, eps2d, near_plane, far_plane, radius_clip, c2w=None, intr=None):
+                sh_degree, flags, eps2d, near_plane, far_plane, radius_clip, c2w=None, intr=None, lazy_sh=None):
         lib = L.load()
+        ctx.lazy_sh = lazy_sh
         # undefined output gradients arrive as None instead of freshly zero-filled tensors (autograd would
         # otherwise fill one per output per step, the 24 MB splat record included)
         ctx.set_materialize_grads(False)
@@ -367,6 +368,12 @@ class _ProjectSH(torch.autograd.Function):
         v_viewmats = None
         if ctx.needs_input_grad[6]:
             v_viewmats = torch.zeros_like(viewmats)
+        # QED_F_SH_GRAD_COMPACT asked for by a caller that keeps the Gaussians' SH gradients in compact form until somebody
+        # reads them (model.QEDSplatterModel, lazy_sh_grad): it is asked NOW whether this backward pass may still write that
+        # form -- not when gradients of an earlier pass are waiting to be added to
+        lazy = getattr(ctx, "lazy_sh", None)
+        if (flags & L.F_SH_GRAD_COMPACT) and lazy is not None and not lazy(v_sh0, v_shN, viewmats, sh_degree):
+            flags &= ~L.F_SH_GRAD_COMPACT
         if PRE_PROJECT_BWD is not None and sh_jac is not None and (flags & L.F_SH_GRAD_COMPACT):
             PRE_PROJECT_BWD(vsplat, sh_jac, C * N)
         L.check(lib.qed_project_bwd(
@@ -375,7 +382,7 @@ class _ProjectSH(torch.autograd.Function):
             L.ptr(vsplat), L.ptr(v_means), L.ptr(v_quats), L.ptr(v_scales), L.ptr(v_opacities), v_sh0_ptr,
             v_sh0_stride, v_shN_ptr, v_shN_stride, L.ptr(v_viewmats), L.ptr(sh_jac), _stream()), "qed_project_bwd")
         v_opacities = v_opacities.view(ctx.opac_shape)
-        return (v_means, v_quats, v_scales, v_opacities, v_sh0, v_shN, v_viewmats, None) + (None,) * 12
+        return (v_means, v_quats, v_scales, v_opacities, v_sh0, v_shN, v_viewmats, None) + (None,) * 13
 
 
 _VSPLAT_REGISTRY: "weakref.WeakValueDictionary[int, Tensor]" = weakref.WeakValueDictionary()
@@ -620,7 +627,7 @@ def rasterization(
     backgrounds: Optional[Tensor] = None, _flags: int = 0, _sh_rest: Optional[Tensor] = None,
     _sync: bool = True, _vsplat_holder: Optional[list] = None, _c2w: Optional[Tuple[Tensor, Tensor]] = None,
     _post_background: Optional[Tensor] = None, _means2d_leaf: bool = False, _capture_slot=None,
-    _manual: Optional[list] = None,
+    _manual: Optional[list] = None, _lazy_sh=None,
 ) -> Tuple[Tensor, Tensor, Dict]:
     """Same call surface as the reference's call (model.py:267-288).
 
@@ -679,7 +686,7 @@ def rasterization(
         _ProjectSH, _manual, None,
         means, quats, scales, opacities, sh0, shN, viewmats, Ks, int(width), int(height), tile_w, tile_h, deg, flags,
         float(eps2d), float(near_plane), float(far_plane), float(radius_clip),
-        *(_c2w if _c2w is not None else (None, None)))
+        *(_c2w if _c2w is not None else (None, None)), _lazy_sh)
 
     # the packed tile rectangles of the records save the emit pass a recomputation; with F_TIGHT_TILES they
     # are the only place the (smaller) rectangles exist

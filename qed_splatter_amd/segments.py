@@ -77,6 +77,19 @@ class _SegmentFn(torch.autograd.Function):
             seg.vsplat.zero_()
         del seg.holder[:]
         graph.replay()
+        owner = getattr(seg, "lazy_owner", None)
+        if owner is not None:
+            # the captured projection backward wrote the SH gradients in compact form (config.lazy_sh_grad): they stay so
+            # until somebody reads them -- unless gradients of an earlier pass wait in the fields, which autograd is about
+            # to add these to: then the coefficient gradients are written out now, in place
+            c_proj = seg.manual[0]
+            i_dc = seg.param_names.index("features_dc")
+            v_dc, v_rest = grads[i_dc], grads[i_dc + 1]
+            viewmats, deg = c_proj.saved_tensors[6], c_proj.meta[4]
+            m = owner()
+            if m is None or not m._lazy_sh_begin(v_dc, v_rest, viewmats, deg):
+                from .model import write_sh_grads
+                write_sh_grads(seg.params[seg.param_names.index("means")], viewmats, deg, v_dc, v_rest)
         leaf = seg.info["means2d"]
         if leaf.requires_grad:                           # model.py:289-292: xys.grad / xys.absgrad for the densifier
             leaf.grad, leaf.absgrad = seg.leaf_grad, seg.leaf_absgrad

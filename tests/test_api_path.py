@@ -1061,3 +1061,148 @@ def test_graphed_get_outputs_follows_shape_changes_and_other_losses(cuda):
             assert len(m._segments.segments) == 2
     for k in PARAM_NAMES:
         assert_close(grads[True][k], grads[False][k].double().cpu(), 2e-5, f"grad {k} (custom loss through the segment)")
+
+
+# ---- SH gradients kept compact until somebody reads them (config.lazy_sh_grad) --------------------------------------
+def _six_qed_adams(m):
+    from qed_splatter_amd.model import FlatAdam, QedAdam
+    return {k: QedAdam([m.gauss_params[k]], lr=FlatAdam.DEFAULT_LRS[k], eps=1e-15) for k in
+            ("means", "features_dc", "features_rest", "opacities", "scales", "quats")}        # config.py's order
+
+
+def _flat(m):
+    return torch.cat([m.gauss_params[k].detach().reshape(-1) for k in m.group_names])
+
+
+@pytest.mark.parametrize("graphed", [False, True])
+def test_lazy_sh_gradients_train_like_written_out_ones(cuda, graphed):
+    """With six QedAdam instances on the flat buffer the backward pass of the reference-shaped route leaves the SH gradients
+    in the fused step's compact form (the projection backward neither writes nor the optimiser reads 48 N floats): from the
+    second step on (the first registers the optimisers) the two ``.grad`` fields are consumed by the step and read None
+    afterwards; parameters and moments after eight steps equal those of config.lazy_sh_grad = False."""
+    from qed_splatter_amd import rasterization as R
+    from qed_splatter_amd.model import _raw_grad
+    w, h, n = 200, 136, 6000
+    sc = scene(n, w, h, seed=31)
+    runs = {}
+    for lazy in (False, True):
+        R._WORKSPACES.clear()
+        m, cam, batch = _model(sc, cuda, lazy_sh_grad=lazy, graph_segments="always" if graphed else False)
+        m.train()
+        opts = _six_qed_adams(m)
+        consumed = 0
+        for step in range(8):
+            _reference_sequence(m, cam, batch, opts)
+            dc, rest = m.gauss_params["features_dc"], m.gauss_params["features_rest"]
+            if _raw_grad(dc) is None and _raw_grad(rest) is None:
+                consumed += 1
+                assert dc.grad is None and rest.grad is None and m.means.grad is not None
+        torch.cuda.synchronize()
+        assert consumed == (7 if lazy else 0)                   # (the first step runs before any optimiser has registered)
+        if graphed:
+            cache = m.__dict__["_segments"]
+            assert len(cache.segments) >= 1 and cache.disabled is None
+        st = opts["means"]._shared
+        runs[lazy] = (_flat(m), st.exp_avg.clone(), st.exp_avg_sq.clone())
+    b = m.group_begin
+    for name, x1, x0 in zip(("params", "exp_avg", "exp_avg_sq"), runs[True], runs[False]):
+        assert_close(x1[:b[4]], x0[:b[4]].double(), 2e-5, f"geometry {name}")
+        assert_close(x1[b[4]:b[5]], x0[b[4]:b[5]].double(), 2e-5, f"features_dc {name}")
+        assert_close(x1[b[5]:], x0[b[5]:].double(), 2e-5, f"features_rest {name}")
+    assert bool((runs[True][1][b[5]:] != 0).any())
+
+
+def test_lazy_sh_gradients_read_as_the_full_gradients(cuda):
+    """Every Python reader of ``.grad`` sees the reference's gradients: reading either field between backward and step
+    writes the coefficient gradients in place (then the step is the plain one); two backward passes without zero_grad add
+    up; zero_grad drops an unread compact form; a group stepped out of turn, or torch.optim.Adam on some group, never meets
+    the compact form."""
+    from qed_splatter_amd import rasterization as R
+    from qed_splatter_amd.model import QedAdam, _raw_grad
+    w, h, n = 160, 112, 3000
+    sc = scene(n, w, h, seed=32)
+
+    def one_backward(m, cam, batch):
+        out = m.get_outputs(cam)
+        ld = m.get_loss_dict(out, batch, m.get_metrics_dict(out, batch))
+        sum(ld.values()).backward()
+
+    def prepared(lazy):
+        R._WORKSPACES.clear()
+        m, cam, batch = _model(sc, cuda, lazy_sh_grad=lazy, graph_segments=False)
+        m.train()
+        opts = _six_qed_adams(m)
+        _reference_sequence(m, cam, batch, opts)                 # registers the optimisers (and moves the parameters)
+        for o in opts.values():
+            o.zero_grad(set_to_none=True)
+        return m, cam, batch, opts
+
+    m0, cam, batch, opts0 = prepared(False)
+    one_backward(m0, cam, batch)
+    want = {k: m0.gauss_params[k].grad.clone() for k in m0.group_names}
+
+    # (1) a read between backward and step
+    m1, cam, batch, opts1 = prepared(True)
+    one_backward(m1, cam, batch)
+    assert m1.__dict__["_lazy_sh"] is not None                   # compact: nobody has asked yet
+    got_rest = m1.gauss_params["features_rest"].grad             # ... now somebody has
+    assert m1.__dict__["_lazy_sh"] is None
+    assert_close(got_rest, want["features_rest"].double(), 1e-5, "features_rest.grad (materialised)")
+    assert_close(m1.gauss_params["features_dc"].grad, want["features_dc"].double(), 1e-5, "features_dc.grad (materialised)")
+    assert_close(m1.means.grad, want["means"].double(), 1e-5, "means.grad")
+    for o in opts0.values():
+        o.step()
+    for o in opts1.values():
+        o.step()
+    assert_close(_flat(m1), _flat(m0).double(), 1e-5, "parameters after a step on materialised gradients")
+    assert m1.gauss_params["features_rest"].grad is not None     # (a plain step leaves the fields alone)
+
+    # (2) accumulation over two backward passes
+    for o in (*opts0.values(), *opts1.values()):
+        o.zero_grad(set_to_none=True)
+    one_backward(m0, cam, batch)
+    one_backward(m0, cam, batch)
+    one_backward(m1, cam, batch)
+    assert m1.__dict__["_lazy_sh"] is not None
+    one_backward(m1, cam, batch)                                 # completes the first pass's gradients, then adds its own
+    assert m1.__dict__["_lazy_sh"] is None
+    for k in ("features_dc", "features_rest", "means"):
+        assert_close(m1.gauss_params[k].grad, m0.gauss_params[k].grad.double(), 2e-5, f"{k}.grad summed over two passes")
+
+    # (3) zero_grad drops a compact form nobody read; model.zero_grad() (nn.Module's) too
+    for o in opts1.values():
+        o.zero_grad(set_to_none=True)
+    one_backward(m1, cam, batch)
+    assert m1.__dict__["_lazy_sh"] is not None
+    for o in opts1.values():
+        o.zero_grad(set_to_none=True)
+    assert m1.__dict__["_lazy_sh"] is None and _raw_grad(m1.gauss_params["features_dc"]) is None
+    one_backward(m1, cam, batch)
+    m1.zero_grad()
+    assert m1.__dict__["_lazy_sh"] is None and all(p.grad is None for p in m1.parameters())
+
+    # (4) a group stepped out of turn: the waiting groups are launched alone -> plain gradients first
+    for o in (*opts0.values(), *opts1.values()):
+        o.zero_grad(set_to_none=True)
+    one_backward(m0, cam, batch)
+    one_backward(m1, cam, batch)
+    for opts in (opts0, opts1):
+        opts["means"].step()
+        opts["means"].step()                                     # second call: launches the first alone
+        for k in ("features_dc", "features_rest", "opacities", "scales", "quats"):
+            opts[k].step()
+        opts["means"].flush()
+    assert_close(_flat(m1), _flat(m0).double(), 2e-5, "parameters after an out-of-turn step")
+
+    # (5) torch.optim.Adam on one group: fewer than six QedAdam members -> the backward pass writes full gradients
+    R._WORKSPACES.clear()
+    m2, cam, batch = _model(sc, cuda, lazy_sh_grad=True, graph_segments=False)
+    m2.train()
+    opts2 = _six_qed_adams(m2)
+    del opts2["features_rest"]
+    import gc
+    gc.collect()
+    opts2["features_rest"] = torch.optim.Adam([m2.gauss_params["features_rest"]], lr=1e-3, eps=1e-15)
+    for _ in range(3):
+        _reference_sequence(m2, cam, batch, opts2)
+        assert m2.__dict__.get("_lazy_sh") is None and _raw_grad(m2.gauss_params["features_rest"]) is not None
