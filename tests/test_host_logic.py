@@ -98,3 +98,63 @@ def test_step_context_hands_everything_out_once_and_only_to_its_own_outputs():
     got = ctx2.take_grad_buffers()
     assert got[0] is v_rgb and got[1] is v_depth and ctx2.take_grad_buffers() is None
     assert ctx2.take_accumulator()[2] is vsplat                    # the accumulator survives the gradient buffers' hand-over
+
+
+def test_lazy_sh_gradient_parameters_complete_the_gradients_for_every_python_reader(monkeypatch):
+    """model._LazySHGradParameter (config.lazy_sh_grad): while the model holds a compact SH gradient, READING ``.grad`` of
+    features_dc / features_rest first has the full gradients written (here: a stand-in that counts), ``.grad = None`` on both
+    drops the compact form, assigning a tensor completes the other field first, and the four geometry groups are plain
+    Parameters.  The device side of it is tests/test_api_path.py::test_lazy_sh_gradients_*."""
+    import copy
+    import torch
+    from qed_splatter_amd.model import QEDSplatterModel, _LazySHGradParameter, _raw_grad
+    from tests.util import PARAM_NAMES, scene
+    sc = scene(40, 32, 32, seed=3)
+    m = QEDSplatterModel(None, **{k: sc[k] for k in PARAM_NAMES})
+    dc, rest = m.gauss_params["features_dc"], m.gauss_params["features_rest"]
+    assert type(dc) is _LazySHGradParameter and type(rest) is _LazySHGradParameter
+    assert all(type(m.gauss_params[k]) is torch.nn.Parameter for k in ("means", "scales", "quats", "opacities"))
+    assert dc.data_ptr() == m.flat_params.data_ptr() + 4 * m.group_begin[4]           # still views of the flat buffer
+    calls = []
+
+    def fake_materialise():
+        calls.append(1)
+        m.__dict__["_lazy_sh"] = None
+    monkeypatch.setattr(m, "_materialise_sh_grads", fake_materialise)
+
+    def pend():
+        _raw_grad_set(dc, torch.zeros_like(dc))
+        _raw_grad_set(rest, torch.zeros_like(rest))
+        m.__dict__["_lazy_sh"] = {"stand-in": True}
+
+    from qed_splatter_amd.model import _RAW_GRAD
+    _raw_grad_set = _RAW_GRAD.__set__
+    # no compact form: plain behaviour
+    assert dc.grad is None and not calls
+    # a read completes the gradients, once
+    pend()
+    assert rest.grad is not None and len(calls) == 1
+    assert dc.grad is not None and len(calls) == 1
+    # the raw accessor (what QedAdam uses) does not
+    pend()
+    assert _raw_grad(dc) is not None and len(calls) == 1
+    # .grad = None on both drops the compact form without completing it
+    dc.grad = None
+    assert m.__dict__["_lazy_sh"] is not None and len(calls) == 1
+    rest.grad = None
+    assert m.__dict__["_lazy_sh"] is None and len(calls) == 1
+    # assigning a tensor to one field completes the other first
+    pend()
+    dc.grad = torch.ones_like(dc)
+    assert len(calls) == 2 and float(_raw_grad(dc).sum()) == dc.numel()
+    # nn.Module.zero_grad and torch.optim see ordinary Parameters
+    pend()
+    m.zero_grad()
+    assert len(calls) == 3 and _raw_grad(dc) is None and _raw_grad(rest) is None
+    # a deep copy is a Parameter of the same class without an owner: plain behaviour
+    c = copy.deepcopy(dc)
+    assert isinstance(c, torch.nn.Parameter) and c.grad is None
+    # after densification (rebind_flat) the new Parameters are lazy ones again and nothing is pending
+    m.__dict__["_lazy_sh"] = {"stand-in": True}
+    m.rebind_flat(m.flat_params.detach().clone(), m.num_points)
+    assert m.__dict__["_lazy_sh"] is None and type(m.gauss_params["features_rest"]) is _LazySHGradParameter
