@@ -305,7 +305,10 @@ sort_global_hist_kernel(const KeyT* __restrict__ keys, const int* __restrict__ n
 
 // Measured on MI355X at M = 4.7e6 (round 1): the decoupled look-back pass takes 33 us against 28 us
 // for histogram + scan + scatter (its per-digit look-back walks predecessors one ~1.5 us global load
-// at a time), so the three-kernel pass is what the library runs; a build with -DQED_SORT_LOOKBACK selects the
+// at a time), so the three-kernel pass is what the library runs.  Round 4, config D (27.5 M pairs): 121 us per look-back
+// pass against 70 for the three kernels, and requesting eight predecessors per round trip + walking only after the LDS
+// reorder changed nothing -- with ~1 000 tiles in flight that all started together, nearly every predecessor is itself
+// still looking back, so the walk is as long as the number of tiles in flight whatever a hop costs; a build with -DQED_SORT_LOOKBACK selects the
 // look-back pass (a compile-time choice: the library reads no environment and keeps no state).
 static constexpr bool sort_use_lookback() {
 #ifdef QED_SORT_LOOKBACK
@@ -373,9 +376,12 @@ static int sort_pairs_impl(KeyT* keys, int* vals, KeyT* keys_alt, int* vals_alt,
         if (rc != QED_OK) return rc;
         return passes & 1;
     }
-    for (int p = 0; p < passes; ++p) {
-        const int shift = p * kRadixBits;
-        const int bits = min(kRadixBits, end_bit - shift);
+    // the key bits are dealt EVENLY over the passes (13 tile bits: 7 + 6, not 8 + 5): a pass's write runs are
+    // (pairs per workgroup / buckets) long, and the pass with the most buckets has the shortest.  Measured: config D's
+    // binning 786 -> 776 us, config B's 112 -> 110.5
+    const int even_bits = (end_bit + passes - 1) / passes;
+    for (int p = 0, shift = 0; p < passes; ++p) {
+        const int bits = min(even_bits, end_bit - shift);
         const unsigned mask = (1u << bits) - 1u;
         hipLaunchKernelGGL((sort_hist_kernel<KeyT, KPT>), dim3(nblocks_max), dim3(kSortThreads), 0, st, kin, n_dev,
                            shift, mask, nblocks_max, hist);
@@ -386,6 +392,7 @@ static int sort_pairs_impl(KeyT* keys, int* vals, KeyT* keys_alt, int* vals_alt,
                            (unsigned*)nullptr, (int*)nullptr, (int*)nullptr);
         KeyT* tk = kin; kin = kout; kout = tk;
         int* tv = vin; vin = vout; vout = tv;
+        shift += bits;
     }
     const int rc = check_launch("qed_sort_pairs");
     if (rc != QED_OK) return rc;
