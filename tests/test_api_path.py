@@ -1074,6 +1074,14 @@ def _flat(m):
     return torch.cat([m.gauss_params[k].detach().reshape(-1) for k in m.group_names])
 
 
+def _same_training(x1, x0, what):
+    """Two runs of the same steps: equal up to what the run-to-run order of K7's float atomics does to an early Adam step
+    (an update of +-lr wherever a gradient sits at the noise floor): loose on the largest element, tight on the mean."""
+    d, ref = (x1 - x0).abs(), float(x0.abs().max())
+    assert float(d.max()) <= 2e-3 * ref and float(d.mean()) <= 1e-5 * ref, \
+        f"{what}: max {float(d.max()) / ref:.2e}, mean {float(d.mean()) / ref:.2e} of the largest element"
+
+
 @pytest.mark.parametrize("graphed", [False, True])
 def test_lazy_sh_gradients_train_like_written_out_ones(cuda, graphed):
     """With six QedAdam instances on the flat buffer the backward pass of the reference-shaped route leaves the SH gradients
@@ -1105,10 +1113,13 @@ def test_lazy_sh_gradients_train_like_written_out_ones(cuda, graphed):
         st = opts["means"]._shared
         runs[lazy] = (_flat(m), st.exp_avg.clone(), st.exp_avg_sq.clone())
     b = m.group_begin
+    # (eight Adam steps amplify the last bits of the gradients -- the order of K7's float atomics differs from run to run --
+    # so the bound on the largest element is loose and the one on the mean tight; a wrong SH gradient is off by O(1))
     for name, x1, x0 in zip(("params", "exp_avg", "exp_avg_sq"), runs[True], runs[False]):
-        assert_close(x1[:b[4]], x0[:b[4]].double(), 2e-5, f"geometry {name}")
-        assert_close(x1[b[4]:b[5]], x0[b[4]:b[5]].double(), 2e-5, f"features_dc {name}")
-        assert_close(x1[b[5]:], x0[b[5]:].double(), 2e-5, f"features_rest {name}")
+        for part, lo, hi in (("geometry", 0, b[4]), ("features_dc", b[4], b[5]), ("features_rest", b[5], b[6])):
+            d, ref = (x1[lo:hi] - x0[lo:hi]).abs(), float(x0[lo:hi].abs().max())
+            assert float(d.max()) <= 2e-3 * ref and float(d.mean()) <= 1e-5 * ref, \
+                f"{part} {name}: max {float(d.max()) / ref:.2e}, mean {float(d.mean()) / ref:.2e} of the largest element"
     assert bool((runs[True][1][b[5]:] != 0).any())
 
 
@@ -1154,7 +1165,7 @@ def test_lazy_sh_gradients_read_as_the_full_gradients(cuda):
         o.step()
     for o in opts1.values():
         o.step()
-    assert_close(_flat(m1), _flat(m0).double(), 1e-5, "parameters after a step on materialised gradients")
+    _same_training(_flat(m1), _flat(m0), "parameters after a step on materialised gradients")
     assert m1.gauss_params["features_rest"].grad is not None     # (a plain step leaves the fields alone)
 
     # (2) accumulation over two backward passes
@@ -1192,7 +1203,7 @@ def test_lazy_sh_gradients_read_as_the_full_gradients(cuda):
         for k in ("features_dc", "features_rest", "opacities", "scales", "quats"):
             opts[k].step()
         opts["means"].flush()
-    assert_close(_flat(m1), _flat(m0).double(), 2e-5, "parameters after an out-of-turn step")
+    _same_training(_flat(m1), _flat(m0), "parameters after an out-of-turn step")
 
     # (5) torch.optim.Adam on one group: fewer than six QedAdam members -> the backward pass writes full gradients
     R._WORKSPACES.clear()
