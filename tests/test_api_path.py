@@ -1082,8 +1082,8 @@ def _same_training(x1, x0, what):
         f"{what}: max {float(d.max()) / ref:.2e}, mean {float(d.mean()) / ref:.2e} of the largest element"
 
 
-@pytest.mark.parametrize("graphed", [False, True])
-def test_lazy_sh_gradients_train_like_written_out_ones(cuda, graphed):
+@pytest.mark.parametrize("graphed,deg", [(False, 3), (True, 3), (False, 0), (False, 1), (True, 2)])
+def test_lazy_sh_gradients_train_like_written_out_ones(cuda, graphed, deg):
     """With six QedAdam instances on the flat buffer the backward pass of the reference-shaped route leaves the SH gradients
     in the fused step's compact form (the projection backward neither writes nor the optimiser reads 48 N floats): from the
     second step on (the first registers the optimisers) the two ``.grad`` fields are consumed by the step and read None
@@ -1095,8 +1095,8 @@ def test_lazy_sh_gradients_train_like_written_out_ones(cuda, graphed):
     runs = {}
     for lazy in (False, True):
         R._WORKSPACES.clear()
-        m, cam, batch = _model(sc, cuda, lazy_sh_grad=lazy, graph_segments="always" if graphed else False)
-        m.train()
+        m, cam, batch = _model(sc, cuda, step=deg, lazy_sh_grad=lazy, graph_segments="always" if graphed else False)
+        m.train()                                               # (sh_degree_interval = 1: the active SH degree is `deg`)
         opts = _six_qed_adams(m)
         consumed = 0
         for step in range(8):
@@ -1120,7 +1120,7 @@ def test_lazy_sh_gradients_train_like_written_out_ones(cuda, graphed):
             d, ref = (x1[lo:hi] - x0[lo:hi]).abs(), float(x0[lo:hi].abs().max())
             assert float(d.max()) <= 2e-3 * ref and float(d.mean()) <= 1e-5 * ref, \
                 f"{part} {name}: max {float(d.max()) / ref:.2e}, mean {float(d.mean()) / ref:.2e} of the largest element"
-    assert bool((runs[True][1][b[5]:] != 0).any())
+    assert bool((runs[True][1][b[5]:] != 0).any()) == (deg > 0)    # (degree 0: no coefficient beyond features_dc is active)
 
 
 def test_lazy_sh_gradients_read_as_the_full_gradients(cuda):
