@@ -22,10 +22,28 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # committed rocprofv3 --pmc summaries the roofline objects quote (re-taken whenever the compositing kernels change)
-PMC_TRAFFIC = "r04_hbm_traffic_pmc.json"
-PMC_VALU = "r04_valu_issue_pmc.json"
+PMC_TRAFFIC = "r05_hbm_traffic_pmc.json"
+PMC_VALU = "r05_valu_issue_pmc.json"
 
 import torch  # noqa: E402
+
+
+def committed_counters(name, root=ROOT):
+    """A committed rocprofv3 --pmc summary under profiles/, or None when it does not describe THIS tree's kernels: the
+    summary records sha256 of the kernel sources it was taken on (scripts/pmc_to_json.py: `source_sha256`), and a
+    summary without that record, or whose sources have changed since, is not quoted."""
+    import hashlib
+    try:
+        prof = json.load(open(os.path.join(root, "profiles", name)))
+        hashes = prof["source_sha256"]
+        if not hashes:
+            return None
+        for rel, want in hashes.items():
+            if hashlib.sha256(open(os.path.join(root, rel), "rb").read()).hexdigest() != want:
+                return None
+        return prof
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
 
 
 def parse():
@@ -740,15 +758,19 @@ def main():
         # for the kernel version named in the profile; null otherwise.
         traffic = valu_frac = prof_note = None
         if (n, w, h) == (500_000, 1920, 1080):
+            prof, vp = committed_counters(PMC_TRAFFIC), committed_counters(PMC_VALU)
             try:
-                prof = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC)))
-                kk = prof["kernels"]["qed::composite_bwd_kernel<4>"]
-                traffic = (2.0 * kk["fetch_size_kb"] + kk["write_size_kb"]) * 1024.0    # gfx950: FETCH_SIZE counts half
-                vp = json.load(open(os.path.join(ROOT, "profiles", PMC_VALU)))
-                valu_frac = vp["kernels"]["qed::composite_bwd_kernel<4>"]["valu_issue_frac"]
-                prof_note = f"from committed profiles {PMC_TRAFFIC} / {PMC_VALU} (kernels {prof.get('kernels_version', '?')}), " \
-                            "not measured in this run"
-            except (OSError, KeyError, ValueError):
+                if prof is not None:
+                    kk = prof["kernels"]["qed::composite_bwd_kernel<4>"]
+                    traffic = (2.0 * kk["fetch_size_kb"] + kk["write_size_kb"]) * 1024.0    # gfx950: FETCH_SIZE counts half
+                if vp is not None:
+                    valu_frac = vp["kernels"]["qed::composite_bwd_kernel<4>"]["valu_issue_frac"]
+                if prof is not None or vp is not None:
+                    prof_note = f"from committed profiles {PMC_TRAFFIC} / {PMC_VALU} (kernels " \
+                                f"{(prof or vp).get('kernels_version', '?')}; source hashes match this tree), not measured in this run"
+                else:
+                    prof_note = f"{PMC_TRAFFIC} / {PMC_VALU} were taken on other kernel sources (sha256 mismatch): not quoted"
+            except (KeyError, TypeError):
                 pass
         roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                 "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": prof_note,

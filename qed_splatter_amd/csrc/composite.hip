@@ -31,7 +31,19 @@
 //     fixed order and issues ONE 64-byte-row atomic request per (tile, Gaussian) that contributed.
 //     The launch hands its tiles out costliest first (tile_order_kernel), from the forward pass's own
 //     per-tile visit counts.
+#include <type_traits>
+
 #include "qed_common.h"
+
+#ifndef QED_K6_FORM
+#define QED_K6_FORM 2
+#endif
+#ifndef QED_K7_FORM
+#define QED_K7_FORM 2
+#endif
+#ifndef QED_K7_FETCH
+#define QED_K7_FETCH 2
+#endif
 
 namespace qed {
 
@@ -55,17 +67,26 @@ constexpr int kRecFloats = 12;      // LDS record stride (floats): 10 used + the
 // (6 v_permlane16_swap + 6 adds: 32 partial sums per value); the partials of up to four Gaussians are parked in LDS
 // (stores are issued beside the vector pipe, not on it) and the flush -- one lane per (Gaussian, value) -- adds the 32
 // partials with plain adds before its atomic: ~87 cycles per Gaussian.
-#ifndef QED_PARK_SLOTS
-#define QED_PARK_SLOTS 3
+#ifndef QED_K7_REDUCE
+#define QED_K7_REDUCE 1
 #endif
-#ifndef QED_PARK_SLOT_FLOATS
-#define QED_PARK_SLOT_FLOATS 448
-#endif
-constexpr int kParkSlots = QED_PARK_SLOTS;   // Gaussians parked per flush (16 lanes each)
+#if QED_K7_REDUCE == 0
+// (round-4 form, kept for the A/B measurement: one halving level in the wave, 32 partials per value, three slots)
+constexpr int kParkSlots = 3;                // Gaussians parked per flush (16 lanes each)
 constexpr int kParkStride = 36;              // floats per (Gaussian, value): 32 partials + 4 pad, and
-constexpr int kParkSlot = QED_PARK_SLOT_FLOATS;   // floats per parked Gaussian (12 values, padded to a multiple of 64): the
+constexpr int kParkSlot = 448;               // floats per parked Gaussian (12 values, padded to a multiple of 64): the
                                              // 16-byte reads of the flush (lane groups {0-3,12-15,20-27}, ...) then hit
                                              // 16 different 4-bank groups
+#else
+// NO halving level in the wave: every lane parks its own 12 sums (12 ds_write_b32, issued beside the vector pipe: the
+// six v_permlane16_swap + six adds per Gaussian were 18 issue quad-cycles of the pipe this kernel is bound by), and the
+// flush -- two lanes per (Gaussian, value) -- adds the 64 partials in a fixed order.
+constexpr int kParkSlots = 2;                // Gaussians parked per flush: 24 rows, two lanes each
+constexpr int kParkStride = 68;              // floats per (Gaussian, value) row: 64 partials + 4 pad: the 16-byte reads of the
+                                             // flush (row = lane >> 1, half = lane & 1; ds_read_b128 lane groups
+                                             // {0-3,12-15,20-27}, ...) hit 16 different 4-bank slots: slot = row + 8 half + j mod 16
+constexpr int kParkSlot = 12 * kParkStride;  // floats per parked Gaussian
+#endif
 
 // Diagnostic build only (-DQED_COMPOSITE_STATS; scripts/composite_stats.py): how much work each stage of the
 // compositing kernels really does.  Wave-uniform counts, added by lane 0.
@@ -136,12 +157,13 @@ __device__ __forceinline__ u64 uniform_u64(u64 v) {
     return ((u64)hi << 32) | lo;
 }
 
-// p = -sigma log2(e) = A dx^2 + B dx dy + C dy^2 with (A, C) = AC pre-scaled by -log2(e)/2 and B by -log2(e)
-__device__ __forceinline__ float neg_sigma_log2e(f2 d, f2 AC, float B) {
-    const f2 t = AC * d;                                // (A dx, C dy)
-    const float u = __builtin_fmaf(B, d.y, t.x);        // A dx + B dy
-    const f2 m = d * (f2){u, t.y};                      // (dx (A dx + B dy), C dy^2)
-    return m.x + m.y;
+// The conic reaches the per-pixel code as the two rows of M' = k [[a, b], [b, c]], k = -log2(e)/2 (scaled once per lane at
+// staging): w = M' d, and p = d . w = -sigma log2(e).  The backward pass needs M d for the gradient of the mean as well:
+// it is w / k, so the same two packed instructions serve both (the factor 1 / k is applied once per (tile, Gaussian), at
+// the flush).
+constexpr float kConicScale = -0.5f * kLog2e;
+__device__ __forceinline__ f2 conic_times_d(f2 R0, f2 R1, f2 d) {
+    return R0 * (f2){d.x, d.x} + R1 * (f2){d.y, d.y};  // (k (a dx + b dy), k (b dx + c dy))
 }
 
 // get_outputs' post-processing folded into the compositing kernels (model.py:295-297, 304-306; the reference-shaped route):
@@ -167,13 +189,37 @@ struct FwdPixel {
     int cur;
 };
 
-template <int CH>
-__device__ __forceinline__ void fwd_quadrant(f2 pq, f2 XY, f2 AC, float B, float op, f2 col01, f2 col23, int idx_v,
-                                             u64& done, FwdPixel& s) {
+// Two forms of the per-pixel alpha, chosen per GAUSSIAN (wave-uniform, from the record alone, so the forward and the
+// backward kernel take the same form for the same Gaussian):
+//   general  a = min(0.999, o exp2(p)), skipped where p > 0 (sigma < 0) -- Appendix A.6 as written;
+//   FAST     a = exp2(p + log2 o): for a Gaussian with o <= 0.998 and a conic that is positive definite by a margin
+//            (b^2 <= 0.998 a c, so sigma >= 0.0005 (a dx^2 + c dy^2): no rounding of the fp32 evaluation can make it
+//            negative) the clamp can never bite and sigma < 0 can never happen: the v_min, the multiply by the
+//            opacity (folded into the exponent: the last add of the polynomial becomes the addend of an fma) and one
+//            compare per pixel go.  Every Gaussian of an ordinary scene takes this form (sigmoid(4) = 0.982).
+// `lo` carries the opacity (general form) or log2 of it (fast form).
+__device__ __forceinline__ bool gaussian_is_fast(float ca, float cb, float cc, float op) {
+    return (op <= 0.998f) & (cb * cb <= 0.998f * (ca * cc));       // (false for NaNs: they take the general form)
+}
+// MIXED = false: every Gaussian of the batch takes the fast form (no test at all); true: `slow` (wave-uniform) decides.
+template <int CH, bool MIXED>
+__device__ __forceinline__ void fwd_quadrant(f2 pq, f2 XY, f2 R0, f2 R1, float lo, f2 col01, f2 col23, int idx_v,
+                                             unsigned slow, u64& done, FwdPixel& s) {
     const f2 d = XY - pq;
-    const float p = neg_sigma_log2e(d, AC, B);
-    const float a = fminf(kAlphaMax, op * __builtin_amdgcn_exp2f(p));
-    const u64 m_ok = __ballot(p <= 0.f) & __ballot(a >= kAlphaMin) & ~done;
+    const f2 md = conic_times_d(R0, R1, d);
+    float a;
+    u64 m_ok;
+    // (a scalar branch around the alpha, the rest is shared.  The empty asm keeps the flag a 32-bit scalar at every
+    // use: hoisted into ONE lane-mask bool the compiler re-materialised it through a VGPR per quadrant)
+    if constexpr (MIXED) asm volatile("" : "+s"(slow));
+    if (!MIXED || __builtin_expect(slow == 0, 1)) {
+        a = __builtin_amdgcn_exp2f(__builtin_fmaf(d.x, md.x, __builtin_fmaf(d.y, md.y, lo)));
+        m_ok = __ballot(a >= kAlphaMin) & ~done;
+    } else {
+        const float p = __builtin_fmaf(d.x, md.x, d.y * md.y);
+        a = fminf(kAlphaMax, lo * __builtin_amdgcn_exp2f(p));
+        m_ok = __ballot(p <= 0.f) & __ballot(a >= kAlphaMin) & ~done;
+    }
     const float at = a * s.T;
     const float nT = s.T - at;
     const u64 m_term = m_ok & __ballot(nT <= kTMin);
@@ -264,13 +310,18 @@ __device__ __forceinline__ void fwd_tile(int tile, int qf, float (*s_rec)[kRecFl
         for (int q = 0; q < NQ; ++q) mq[q] = done[q] == ~0ull ? 0ull : uniform_u64(mq[q]);
         u64 km = or_masks(mq);
         QED_STAT(0, 1); QED_STAT(1, min(kBatch, end - (start + b * kBatch))); QED_STAT(2, __builtin_popcountll(km));
-        const float gx = r0.x, gy = r0.y;
-        const float gA = -0.5f * kLog2e * r0.z, gB = -kLog2e * r0.w, gC = -0.5f * kLog2e * r1.x;
-        const float gop = r1.y, gr = r1.z, gg = r1.w, gb = r2.x, gd = r2.y;
-        if (km) {                                       // park this lane's (pre-scaled) Gaussian for the broadcast reads
-            *reinterpret_cast<float4*>(&s_rec[lane][0]) = make_float4(gx, gy, gA, gC);
-            *reinterpret_cast<float4*>(&s_rec[lane][4]) = make_float4(gB, gop, gr, gg);
-            *reinterpret_cast<float2*>(&s_rec[lane][8]) = make_float2(gb, gd);
+        // which per-pixel form this Gaussian takes (see fwd_quadrant); the record carries log2(opacity) for the fast one
+#if QED_K6_FORM == 0
+        const bool fast = false;
+#else
+        const bool fast = gaussian_is_fast(r0.z, r0.w, r1.x, r1.y);
+#endif
+        const u64 m_slow = uniform_u64(__ballot(!fast));
+        if (km) {                                       // park this lane's (pre-scaled) Gaussian for the broadcast reads:
+            const float bh = kConicScale * r0.w;        // {x, y, k a, k b | k b, k c, r, g | b, depth, opacity or its log2, -}
+            *reinterpret_cast<float4*>(&s_rec[lane][0]) = make_float4(r0.x, r0.y, kConicScale * r0.z, bh);
+            *reinterpret_cast<float4*>(&s_rec[lane][4]) = make_float4(bh, kConicScale * r1.x, r1.z, r1.w);
+            *reinterpret_cast<float4*>(&s_rec[lane][8]) = make_float4(r2.x, r2.y, fast ? __builtin_amdgcn_logf(r1.y) : r1.y, 0.f);
         }
         __syncthreads();                                // single wave: orders the stores before the reads below
         // issue the gather of the next batch (its ids arrived a batch ago) and the id load of the one after
@@ -279,35 +330,47 @@ __device__ __forceinline__ void fwd_tile(int tile, int qf, float (*s_rec)[kRecFl
         const int rid_nn = id_at(start + (b + 2) * kBatch + lane);
         const int batch_start = start + b * kBatch;
         // composite Gaussian t (its scalars in XY .. col23): the quadrants whose mask holds it, in turn
-        auto visit = [&](int t, u64 bit, f2 XY, f2 AC, float B, float op, f2 col01, f2 col23) {
-            QED_STAT(4, 1);
-            int idx_v;                                  // one VGPR copy per Gaussian, not per quadrant
-            asm volatile("v_mov_b32 %0, %1" : "=v"(idx_v) : "s"(batch_start + t));
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                if (!(mq[q] & bit)) continue;           // wave-uniform: this quadrant cannot see Gaussian t
-                QED_STAT(3, 1);
-                asm volatile("s_add_u32 %0, %0, 1" : "+s"(n_vis));      // (a scalar counter: as `++n_vis` it took a VGPR and spilled)
-                fwd_quadrant<CH>(pq[q], XY, AC, B, op, col01, col23, idx_v, done[q], px[q]);
-                if (done[q] == ~0ull) {                 // quadrant finished: drop it from the masks
-                    mq[q] = 0;
-                    km &= or_masks(mq);
-                }
-            }
-        };
+        // composite Gaussian t (its scalars in XY .. col23): the quadrants whose mask holds it, in turn.  Two copies of
+        // the walk: a batch whose Gaussians all take the fast form (every batch of an ordinary scene) runs without any
+        // per-visit test of the form.
         // (A version that fetched the NEXT surviving record before compositing the current one -- two register sets,
         // loop unrolled by two -- measured slower, 154 vs 150 us at 5 waves per SIMD and 146 vs 141 us at 6: the
         // extra scalar bookkeeping costs more than the LDS latency the other resident waves already hide.)
-        while (km) {
-            const int t = __builtin_ctzll(km);
-            const u64 bit = 1ull << t;
-            km &= ~bit;
-            // broadcast Gaussian t: every lane reads the same LDS record
-            const float4 q0 = *reinterpret_cast<const float4*>(&s_rec[t][0]);
-            const float4 q1 = *reinterpret_cast<const float4*>(&s_rec[t][4]);
-            const float2 q2 = *reinterpret_cast<const float2*>(&s_rec[t][8]);
-            visit(t, bit, (f2){q0.x, q0.y}, (f2){q0.z, q0.w}, q1.x, q1.y, (f2){q1.z, q1.w}, (f2){q2.x, CH == 4 ? q2.y : 0.f});
-        }
+        auto walk = [&](auto mixed) {
+            constexpr bool MIXED = decltype(mixed)::value;
+            while (km) {
+                const int t = __builtin_ctzll(km);
+                const u64 bit = 1ull << t;
+                km &= ~bit;
+                // broadcast Gaussian t: every lane reads the same LDS record
+                const float4 q0 = *reinterpret_cast<const float4*>(&s_rec[t][0]);
+                const float4 q1 = *reinterpret_cast<const float4*>(&s_rec[t][4]);
+                const float4 q2 = *reinterpret_cast<const float4*>(&s_rec[t][8]);
+                const f2 XY = {q0.x, q0.y}, R0 = {q0.z, q0.w}, R1 = {q1.x, q1.y}, col01 = {q1.z, q1.w};
+                const f2 col23 = {q2.x, CH == 4 ? q2.y : 0.f};
+                QED_STAT(4, 1);
+                int idx_v;                              // one VGPR copy per Gaussian, not per quadrant
+                asm volatile("v_mov_b32 %0, %1" : "=v"(idx_v) : "s"(batch_start + t));
+                const unsigned slow = MIXED ? __builtin_amdgcn_readfirstlane((unsigned)(m_slow >> t) & 1u) : 0u;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    if (!(mq[q] & bit)) continue;       // wave-uniform: this quadrant cannot see Gaussian t
+                    QED_STAT(3, 1);
+                    asm volatile("s_add_u32 %0, %0, 1" : "+s"(n_vis));  // (a scalar counter: as `++n_vis` it took a VGPR and spilled)
+                    fwd_quadrant<CH, MIXED>(pq[q], XY, R0, R1, q2.z, col01, col23, idx_v, slow, done[q], px[q]);
+                    if (done[q] == ~0ull) {             // quadrant finished: drop it from the masks
+                        mq[q] = 0;
+                        km &= or_masks(mq);
+                    }
+                }
+            }
+        };
+#if QED_K6_FORM == 2
+        if (m_slow == 0) walk(std::false_type{});
+        else walk(std::true_type{});
+#else
+        walk(std::true_type{});
+#endif
         all_done = and_done() == ~0ull;                 // (a finished quadrant empties its mask, so km ran out by itself)
         r0 = n0; r1 = n1; r2 = n2;                      // rotate the pipeline (the wave waits HERE, not above)
         rid_n = rid_nn;
@@ -450,15 +513,25 @@ struct BwdPixel {
     int bin_final;
 };
 
-template <int CH>
-__device__ __forceinline__ void bwd_quadrant(f2 pq, f2 XY, f2 AC, float B, float op, f2 cab, f2 cbc, f2 col01, f2 col23,
-                                             int idx, BwdPixel& s, u64& any_valid, GradAcc& g) {
+// MIXED / slow / lo: as fwd_quadrant.
+template <int CH, bool MIXED>
+__device__ __forceinline__ void bwd_quadrant(f2 pq, f2 XY, f2 R0, f2 R1, float lo, f2 col01, f2 col23, int idx,
+                                             unsigned slow, BwdPixel& s, u64& any_valid, GradAcc& g) {
     const f2 d = XY - pq;
-    const float p = neg_sigma_log2e(d, AC, B);
-    const float vis = __builtin_amdgcn_exp2f(p);
-    const float opv = op * vis;
-    const float a = fminf(kAlphaMax, opv);
-    const u64 m_valid = __ballot(s.bin_final >= idx) & __ballot(p <= 0.f) & __ballot(a >= kAlphaMin);
+    const f2 w = conic_times_d(R0, R1, d);
+    float opv, a;
+    u64 m_valid, m_vs;
+    if constexpr (MIXED) asm volatile("" : "+s"(slow));
+    if (!MIXED || __builtin_expect(slow == 0, 1)) {
+        opv = a = __builtin_amdgcn_exp2f(__builtin_fmaf(d.x, w.x, __builtin_fmaf(d.y, w.y, lo)));
+        m_vs = m_valid = __ballot(s.bin_final >= idx) & __ballot(a >= kAlphaMin);
+    } else {
+        const float p = __builtin_fmaf(d.x, w.x, d.y * w.y);
+        opv = lo * __builtin_amdgcn_exp2f(p);
+        a = fminf(kAlphaMax, opv);
+        m_valid = __ballot(s.bin_final >= idx) & __ballot(p <= 0.f) & __ballot(a >= kAlphaMin);
+        m_vs = m_valid & __ballot(opv <= kAlphaMax);
+    }
     any_valid |= m_valid;
     QED_STAT(14, __builtin_popcountll(m_valid)); QED_STAT(15, m_valid == 0 ? 1 : 0);
     // branch-free: an invalid pixel contributes zeros and keeps its state -- through ONE select: with alpha = 0 the
@@ -482,10 +555,14 @@ __device__ __forceinline__ void bwd_quadrant(f2 pq, f2 XY, f2 AC, float B, float
     else g.bd.x += s.vr23.x * fac;
     const float v_a = __builtin_fmaf(Tn, cv, -(ra * s.bufv));      // mul + fma (the packed form needs a register copy)
     s.bufv = __builtin_fmaf(fac, cv, s.bufv);
-    const u64 m_vs = m_valid & __ballot(opv <= kAlphaMax);
-    const float vs = sel(m_vs, -opv * v_a, 0.f);
-    const f2 sv = d * (f2){vs, vs};                     // (v_sigma dx, v_sigma dy)
-    const f2 v = cab * (f2){sv.x, sv.x} + cbc * (f2){sv.y, sv.y};   // (ca sx + cb sy, cb sx + cc sy)
+    // v_sigma = -o e^(-sigma) v_alpha where the pixel is valid and alpha not clamped.  In the fast form that is every valid
+    // pixel, and a_eff already is o e^(-sigma) there and 0 elsewhere: no select
+    float vs;
+    if (!MIXED || __builtin_expect(slow == 0, 1)) vs = -a_eff * v_a;
+    else vs = sel(m_vs, -opv * v_a, 0.f);
+    const f2 vv = {vs, vs};
+    const f2 v = w * vv;                                // k (M d) v_sigma = k x the gradient of the mean (1 / k at the flush)
+    const f2 sv = d * vv;                               // (v_sigma dx, v_sigma dy)
     g.vxy += v;
     // |.| as a source modifier of a plain add (the compiler's and + and + packed add is one instruction more)
     asm("v_add_f32_e64 %0, %0, |%1|" : "+v"(g.ax) : "v"(v.x));
@@ -495,20 +572,32 @@ __device__ __forceinline__ void bwd_quadrant(f2 pq, f2 XY, f2 AC, float B, float
     g.s0 += vs;
 }
 
-// Flush of the parked Gaussians: one lane per (parked Gaussian, value) adds its 32 partials in a
-// fixed order, scales, and the wave issues one 64-byte row per Gaussian in a single atomic request.
-__device__ __forceinline__ void flush_parked(int n_parked, int pt0, int pt1, int pt2, int pt3,
+// Flush of the parked Gaussians: the lanes of a (parked Gaussian, value) add its partials in a fixed order, scale, and
+// the wave issues one 64-byte row per Gaussian in a single atomic request.
+// the values leave the wave in the units they were accumulated in; one lane per (Gaussian, value) converts:
+//   0, 1  k x v_mean -> x 1/k;   2, 3  |k| x |v_mean| -> x -1/k;   4, 6  sum v_sigma d^2 -> x 1/2;
+//   7     sum v_sigma -> x -1/opacity (the record holds the opacity, or log2 of it for a fast-form Gaussian)
+__device__ __forceinline__ float flush_scale(int k, float v, float lo, bool slow) {
+    if (k < 2) v *= 1.f / kConicScale;
+    else if (k < 4) v *= -1.f / kConicScale;
+    else if (k == 4 || k == 6) v *= 0.5f;
+    else if (k == 7) v = -v * (slow ? __builtin_amdgcn_rcpf(lo) : __builtin_amdgcn_exp2f(-lo));  // (an IEEE division is 11 instructions)
+    return v;
+}
+
+#if QED_K7_REDUCE == 0
+__device__ __forceinline__ void flush_parked(int n_parked, int pt0, int pt1, int pt2, u64 m_slow,
                                              const float* __restrict__ s_part, const float (*s_rec)[kRecFloats],
                                              float* __restrict__ vsplat, int lane) {
     QED_STAT(13, 1);
     __syncthreads();                                    // single wave: orders the parking stores before these reads
     const int grp = lane >> 4, k = lane & 15;
-    const int tg = grp == 0 ? pt0 : grp == 1 ? pt1 : grp == 2 ? pt2 : pt3;
+    const int tg = grp == 0 ? pt0 : grp == 1 ? pt1 : pt2;
     if (grp < n_parked && k < 12) {
         const float4* src = reinterpret_cast<const float4*>(s_part + grp * kParkSlot + k * kParkStride);
         const float4 a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3], a4 = src[4], a5 = src[5], a6 = src[6], a7 = src[7];
-        const int id = __float_as_int(s_rec[tg][10]);
-        const float opac = s_rec[tg][5];
+        const int id = __float_as_int(s_rec[tg][11]);
+        const float lo = s_rec[tg][10];
         const float4 b0 = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
         const float4 b1 = make_float4(a2.x + a3.x, a2.y + a3.y, a2.z + a3.z, a2.w + a3.w);
         const float4 b2 = make_float4(a4.x + a5.x, a4.y + a5.y, a4.z + a5.z, a4.w + a5.w);
@@ -516,10 +605,148 @@ __device__ __forceinline__ void flush_parked(int n_parked, int pt0, int pt1, int
         const float4 c0 = make_float4(b0.x + b1.x, b0.y + b1.y, b0.z + b1.z, b0.w + b1.w);
         const float4 c1 = make_float4(b2.x + b3.x, b2.y + b3.y, b2.z + b3.z, b2.w + b3.w);
         float v = ((c0.x + c1.x) + (c0.y + c1.y)) + ((c0.z + c1.z) + (c0.w + c1.w));
-        if (k == 4 || k == 6) v *= 0.5f;
-        if (k == 7) v = -v * __builtin_amdgcn_rcpf(opac);   // (an IEEE division is 11 instructions for the whole wave)
+        v = flush_scale(k, v, lo, (m_slow >> tg) & 1);
         if (v != 0.f) atomicAdd(&vsplat[(size_t)id * QED_VSPLAT_FLOATS + k], v);
     }
+}
+#else
+__device__ __forceinline__ void flush_parked(int n_parked, int pt0, int pt1, int /*pt2*/, u64 m_slow,
+                                             const float* __restrict__ s_part, const float (*s_rec)[kRecFloats],
+                                             float* __restrict__ vsplat, int lane) {
+    QED_STAT(13, 1);
+    __syncthreads();                                    // single wave: orders the parking stores before these reads
+    const int row = lane >> 1, half = lane & 1;         // row = 12 slot + value; lanes 2 row, 2 row + 1 share it
+    const int slot = row >= 12 ? 1 : 0, k = row - 12 * slot;
+    const bool mine = row < 12 * n_parked;
+    float v = 0.f;
+    if (mine) {
+        const float4* src = reinterpret_cast<const float4*>(s_part + row * kParkStride + 32 * half);
+        const float4 a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3], a4 = src[4], a5 = src[5], a6 = src[6], a7 = src[7];
+        const float4 b0 = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+        const float4 b1 = make_float4(a2.x + a3.x, a2.y + a3.y, a2.z + a3.z, a2.w + a3.w);
+        const float4 b2 = make_float4(a4.x + a5.x, a4.y + a5.y, a4.z + a5.z, a4.w + a5.w);
+        const float4 b3 = make_float4(a6.x + a7.x, a6.y + a7.y, a6.z + a7.z, a6.w + a7.w);
+        const float4 c0 = make_float4(b0.x + b1.x, b0.y + b1.y, b0.z + b1.z, b0.w + b1.w);
+        const float4 c1 = make_float4(b2.x + b3.x, b2.y + b3.y, b2.z + b3.z, b2.w + b3.w);
+        v = ((c0.x + c1.x) + (c0.y + c1.y)) + ((c0.z + c1.z) + (c0.w + c1.w));
+    }
+    // the other half's 32 partials: lanes l and l ^ 1 (quad_perm [1, 0, 3, 2]); every lane takes part
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+    if (mine && half == 0) {
+        const int tg = slot == 0 ? pt0 : pt1;
+        const int id = __float_as_int(s_rec[tg][11]);
+        v = flush_scale(k, v, s_rec[tg][10], (m_slow >> tg) & 1);
+        if (v != 0.f) atomicAdd(&vsplat[(size_t)id * QED_VSPLAT_FLOATS + k], v);
+    }
+}
+#endif
+
+// ---- the walk over one staged batch's surviving Gaussians (plain functions, not lambdas: a closure that refers to another
+// closure kept every local they captured in scratch memory) -----------------------------------------------------------
+struct ParkState { int n, t0, t1, t2; };                // parked Gaussians (lane indices of this batch)
+struct BwdRec { float4 q0, q1, q2; };                   // one Gaussian's record as the loop's register pairs (bwd_tile)
+
+__device__ __forceinline__ void bwd_fetch(BwdRec& r, const float (*s_rec)[kRecFloats], int tt) {
+    r.q0 = *reinterpret_cast<const float4*>(&s_rec[tt][0]);
+    r.q1 = *reinterpret_cast<const float4*>(&s_rec[tt][4]);
+    r.q2 = *reinterpret_cast<const float4*>(&s_rec[tt][8]);
+}
+
+// the pixels of Gaussian t (record r), then its twelve sums parked for the flush
+template <int CH, int NQ, bool MIXED>
+__device__ __forceinline__ void bwd_gaussian(BwdRec& r, int t, u64 bit, u64 km, const u64 (&mq)[NQ], const f2 (&pq)[NQ],
+                                             BwdPixel (&px)[NQ], int batch_hi, u64 m_slow, ParkState& park,
+                                             float* park_lane, const float* __restrict__ s_part,
+                                             const float (*s_rec)[kRecFloats], float* __restrict__ vsplat, int lane) {
+    const f2 XY = {r.q0.x, r.q0.y}, R0 = {r.q0.z, r.q0.w}, R1 = {r.q1.x, r.q1.y};
+    const f2 col23 = {r.q1.z, CH == 4 ? r.q1.w : 0.f}, col01 = {r.q2.x, r.q2.y};
+    const float lo = r.q2.z;
+    const int idx = batch_hi - t;
+    const unsigned slow = MIXED ? __builtin_amdgcn_readfirstlane((unsigned)(m_slow >> t) & 1u) : 0u;
+    GradAcc g;
+    g.vxy = g.c01 = g.rg = g.bd = (f2){0.f, 0.f};
+    g.ax = g.ay = g.c2 = g.s0 = 0.f;
+    u64 any_valid = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (!(mq[q] & bit)) continue;                   // wave-uniform: this quadrant cannot see Gaussian t
+        QED_STAT(11, 1);
+        bwd_quadrant<CH, MIXED>(pq[q], XY, R0, R1, lo, col01, col23, idx, slow, px[q], any_valid, g);
+    }
+#if QED_K7_FETCH == 1
+    if (km) bwd_fetch(r, s_rec, __builtin_ctzll(km));
+#endif
+    if (any_valid == 0) return;
+    QED_STAT(12, 1);
+    {
+        float gv[12] = {g.vxy.x, g.vxy.y, g.ax, g.ay, g.c01.x, g.c01.y, g.c2, g.s0, g.rg.x, g.rg.y, g.bd.x, g.bd.y};
+        float* dst = park_lane + park.n * kParkSlot;
+#if QED_K7_REDUCE == 0
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            // a = [a.r0, b.r0, a.r2, b.r2], b = [a.r1, b.r1, a.r3, b.r3]: a + b holds, per 16-lane row, the sum of a
+            // row pair of value 2 i (rows 0, 2) or 2 i + 1 (rows 1, 3)
+            swap16(gv[2 * i], gv[2 * i + 1]);
+            dst[i * 2 * kParkStride] = gv[2 * i] + gv[2 * i + 1];
+        }
+#else
+#pragma unroll
+        for (int i = 0; i < 12; ++i) dst[i * kParkStride] = gv[i];
+#endif
+    }
+    // (selects, not an if-chain: the compiler turned the chain into an indexed store to the struct -- in scratch memory)
+    park.t0 = park.n == 0 ? t : park.t0;
+    park.t1 = park.n == 1 ? t : park.t1;
+    if constexpr (kParkSlots > 2) park.t2 = park.n == 2 ? t : park.t2;
+    if (++park.n == kParkSlots) {
+        flush_parked(park.n, park.t0, park.t1, park.t2, m_slow, s_part, s_rec, vsplat, lane);
+        park.n = 0;
+    }
+}
+
+// QED_K7_FETCH 2: the record of a surviving Gaussian is requested one Gaussian AHEAD, into a second set of registers (the
+// walk is unrolled by two so that the sets alternate without copies): the LDS latency (~130 cycles) runs beside the
+// pixels of the current Gaussian.  1 (the round-4 form): requested behind the current one's pixels into the very
+// registers they were read from -- the latency ran beside the in-wave reduction, which is gone (kParkSlots).  0: on demand.
+template <int CH, int NQ, bool MIXED>
+__device__ __forceinline__ void bwd_walk(u64 km, const u64 (&mq)[NQ], const f2 (&pq)[NQ], BwdPixel (&px)[NQ], int batch_hi,
+                                         u64 m_slow, ParkState& park, float* park_lane, const float* __restrict__ s_part,
+                                         const float (*s_rec)[kRecFloats], float* __restrict__ vsplat, int lane) {
+    BwdRec ra, rb;
+    ra.q0 = ra.q1 = ra.q2 = rb.q0 = rb.q1 = rb.q2 = make_float4(0.f, 0.f, 0.f, 0.f);
+#if QED_K7_FETCH == 2
+    if (km) bwd_fetch(ra, s_rec, __builtin_ctzll(km));
+    while (km) {
+        {
+            const int t = __builtin_ctzll(km);
+            const u64 bit = 1ull << t;
+            km &= ~bit;
+            if (km) bwd_fetch(rb, s_rec, __builtin_ctzll(km));
+            bwd_gaussian<CH, NQ, MIXED>(ra, t, bit, km, mq, pq, px, batch_hi, m_slow, park, park_lane, s_part, s_rec, vsplat, lane);
+        }
+        if (!km) break;
+        {
+            const int t = __builtin_ctzll(km);
+            const u64 bit = 1ull << t;
+            km &= ~bit;
+            if (km) bwd_fetch(ra, s_rec, __builtin_ctzll(km));
+            bwd_gaussian<CH, NQ, MIXED>(rb, t, bit, km, mq, pq, px, batch_hi, m_slow, park, park_lane, s_part, s_rec, vsplat, lane);
+        }
+    }
+#else
+#if QED_K7_FETCH == 1
+    if (km) bwd_fetch(ra, s_rec, __builtin_ctzll(km));
+#endif
+    while (km) {
+        const int t = __builtin_ctzll(km);
+        const u64 bit = 1ull << t;
+        km &= ~bit;
+#if QED_K7_FETCH == 0
+        bwd_fetch(ra, s_rec, t);
+#endif
+        bwd_gaussian<CH, NQ, MIXED>(ra, t, bit, km, mq, pq, px, batch_hi, m_slow, park, park_lane, s_part, s_rec, vsplat, lane);
+    }
+#endif
 }
 
 // vsplat row layout (QED_VSPLAT_FLOATS = 16):
@@ -682,77 +909,43 @@ __device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_rec)[kRecFl
         for (int q = 0; q < NQ; ++q) km |= mq[q];
         QED_STAT(8, 1); QED_STAT(9, min(kBatch, batch_hi + 1 - start)); QED_STAT(10, __builtin_popcountll(km));
         QED_STAT(NQ == 4 ? 16 : 17, b == 0 ? 1 : 0);
-        const float gx = r0.x, gy = r0.y, gca = r0.z, gcb = r0.w, gcc = r1.x;
-        const float gop = r1.y, gr = r1.z, gg = r1.w, gb = r2.x, gd = r2.y;
-        const int gid = rid;
-        if (km) {                                       // park this lane's Gaussian (+ its id, for the flush)
-            *reinterpret_cast<float4*>(&s_rec[lane][0]) = make_float4(gx, gy, gca, gcb);
-            *reinterpret_cast<float4*>(&s_rec[lane][4]) = make_float4(gcc, gop, gr, gg);
-            *reinterpret_cast<float4*>(&s_rec[lane][8]) = make_float4(gb, gd, __int_as_float(gid), 0.f);
+        // the per-pixel form of this lane's Gaussian: the forward kernel's decision, from the same record (fwd_quadrant)
+#if QED_K7_FORM == 0
+        const bool fast = false;
+#else
+        const bool fast = gaussian_is_fast(r0.z, r0.w, r1.x, r1.y);
+#endif
+        const u64 m_slow = uniform_u64(__ballot(!fast));
+        if (km) {                                       // park this lane's Gaussian, laid out as the loop's register pairs:
+            const float bh = kConicScale * r0.w;        // {x, y, k a, k b | k b, k c, b, depth | r, g, opacity or its log2, id}
+            *reinterpret_cast<float4*>(&s_rec[lane][0]) = make_float4(r0.x, r0.y, kConicScale * r0.z, bh);
+            *reinterpret_cast<float4*>(&s_rec[lane][4]) = make_float4(bh, kConicScale * r1.x, r2.x, r2.y);
+            *reinterpret_cast<float4*>(&s_rec[lane][8]) = make_float4(r1.z, r1.w, fast ? __builtin_amdgcn_logf(r1.y) : r1.y,
+                                                                       __int_as_float(rid));
         }
         __syncthreads();
         const float4 n0 = splats[3 * (size_t)rid_n], n1 = splats[3 * (size_t)rid_n + 1],
                      n2 = splats[3 * (size_t)rid_n + 2];
         const int rid_nn = id_at(batch_hi - 2 * kBatch - lane);
-        int n_parked = 0, pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0;      // parked Gaussians (lane indices of this batch)
+#if QED_K7_REDUCE == 0
         // this lane's slot in a parked Gaussian's partials: [value = 2 i + (row & 1)][half = row >> 1][lane & 15]
         float* const park_lane = s_part + ((lane >> 4) & 1) * kParkStride + (lane >> 5) * 16 + (lane & 15);
-        // The record of the NEXT surviving Gaussian is requested right after the current one's pixels are done, into
-        // the very registers they were read from: the LDS latency (~130 cycles) then runs beside the reduction of the
-        // current Gaussian instead of in front of the next one's arithmetic.
-        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
-        float2 q2 = make_float2(0.f, 0.f);
-        auto fetch = [&](int tt) {
-            q0 = *reinterpret_cast<const float4*>(&s_rec[tt][0]);
-            q1 = *reinterpret_cast<const float4*>(&s_rec[tt][4]);
-            q2 = *reinterpret_cast<const float2*>(&s_rec[tt][8]);
-        };
-        if (km) fetch(__builtin_ctzll(km));
-        while (km) {
-            const int t = __builtin_ctzll(km);
-            const u64 bit = 1ull << t;
-            km &= ~bit;
-            const f2 XY = {q0.x, q0.y};
-            const float ca = q0.z, cb = q0.w, cc = q1.x, op = q1.y;
-            const f2 col01 = {q1.z, q1.w};
-            const f2 col23 = {q2.x, CH == 4 ? q2.y : 0.f};
-            const f2 AC = {-0.5f * kLog2e * ca, -0.5f * kLog2e * cc};
-            const float B = -kLog2e * cb;
-            const f2 cab = {ca, cb}, cbc = {cb, cc};
-            const int idx = batch_hi - t;
-            GradAcc g;
-            g.vxy = g.c01 = g.rg = g.bd = (f2){0.f, 0.f};
-            g.ax = g.ay = g.c2 = g.s0 = 0.f;
-            u64 any_valid = 0;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                if (!(mq[q] & bit)) continue;           // wave-uniform: this quadrant cannot see Gaussian t
-                QED_STAT(11, 1);
-                bwd_quadrant<CH>(pq[q], XY, AC, B, op, cab, cbc, col01, col23, idx, px[q], any_valid, g);
-            }
-            if (km) fetch(__builtin_ctzll(km));
-            if (any_valid == 0) continue;
-            QED_STAT(12, 1);
-            {
-                float gv[12] = {g.vxy.x, g.vxy.y, g.ax, g.ay, g.c01.x, g.c01.y, g.c2, g.s0,
-                                g.rg.x, g.rg.y, g.bd.x, g.bd.y};
-                float* dst = park_lane + n_parked * kParkSlot;
-#pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    // a = [a.r0, b.r0, a.r2, b.r2], b = [a.r1, b.r1, a.r3, b.r3]: a + b holds, per 16-lane row, the sum of a
-                    // row pair of value 2 i (rows 0, 2) or 2 i + 1 (rows 1, 3)
-                    swap16(gv[2 * i], gv[2 * i + 1]);
-                    dst[i * 2 * kParkStride] = gv[2 * i] + gv[2 * i + 1];
-                }
-            }
-            if (n_parked == 0) pt0 = t; else if (n_parked == 1) pt1 = t; else if (n_parked == 2) pt2 = t; else pt3 = t;
-            if (++n_parked == kParkSlots) {
-                flush_parked(n_parked, pt0, pt1, pt2, pt3, s_part, s_rec, vsplat, lane);
-                n_parked = 0;
-            }
-        }
+#else
+        float* const park_lane = s_part + lane;         // [slot][value][lane]
+#endif
+        // two copies of the walk, as in the forward kernel: a batch whose Gaussians all take the fast form carries no test
+        ParkState park{0, 0, 0, 0};
+#if QED_K7_FORM == 3                        // (experiment: fast form only -- wrong for slow-form Gaussians)
+        bwd_walk<CH, NQ, false>(km, mq, pq, px, batch_hi, m_slow, park, park_lane, s_part, s_rec, vsplat, lane);
+#elif QED_K7_FORM == 2
+        if (m_slow == 0) bwd_walk<CH, NQ, false>(km, mq, pq, px, batch_hi, m_slow, park, park_lane, s_part, s_rec, vsplat, lane);
+        else bwd_walk<CH, NQ, true>(km, mq, pq, px, batch_hi, m_slow, park, park_lane, s_part, s_rec, vsplat, lane);
+#else
+        bwd_walk<CH, NQ, true>(km, mq, pq, px, batch_hi, m_slow, park, park_lane, s_part, s_rec, vsplat, lane);
+#endif
+        const int n_parked = park.n, pt0 = park.t0, pt1 = park.t1, pt2 = park.t2;
         if (n_parked)                                   // before the next batch overwrites s_rec (ids, opacities)
-            flush_parked(n_parked, pt0, pt1, pt2, pt3, s_part, s_rec, vsplat, lane);
+            flush_parked(n_parked, pt0, pt1, pt2, m_slow, s_part, s_rec, vsplat, lane);
         r0 = n0; r1 = n1; r2 = n2;                      // rotate the pipeline
         rid = rid_n; rid_n = rid_nn;
         present = batch_hi - kBatch - lane >= start;

@@ -32,7 +32,7 @@ import torch
 from torch import Tensor, nn
 
 from . import _lib as L
-from .rasterization import rasterization, _stream
+from .rasterization import rasterization, _stream, _workspace
 
 
 _FLIP_CACHE: Dict = {}
@@ -501,7 +501,24 @@ def write_sh_grads(means: Tensor, viewmat: Tensor, sh_degree: int, v_color: Tens
             L.ptr(v_color), 3, L.ptr(v_rest), v_rest.numel() // max(n, 1), _stream()), "qed_sh_grad_from_views")
 
 
+def _counted_step(opt, device) -> None:
+    """Tell the device's workspace that ``opt`` has counted a step behind the current frame (see _Workspace.counted_step)."""
+    if device.type == "cuda":
+        from .rasterization import _workspace
+        _workspace(device).counted_step(opt)
+
+
 _RAW_GRAD = torch.Tensor.grad                 # the C-level descriptor: reads / writes the field without the subclass's hooks
+
+
+def _dist_world_size() -> int:
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _has_grad_hooks(p: Tensor) -> bool:
+    """Tensor hooks (``register_hook``) or post-accumulate-grad hooks on a Parameter: both are handed the raw gradient."""
+    return bool(getattr(p, "_backward_hooks", None)) or bool(getattr(p, "_post_accumulate_grad_hooks", None))
 
 
 def _raw_grad(p: Tensor) -> Optional[Tensor]:
@@ -606,6 +623,14 @@ class QEDSplatterModel(nn.Module):
         dc, rest = self.gauss_params["features_dc"], self.gauss_params["features_rest"]
         if type(dc) is not _LazySHGradParameter or type(rest) is not _LazySHGradParameter \
                 or not (dc.requires_grad and rest.requires_grad and self.gauss_params["means"].requires_grad):
+            return False
+        # Only PYTHON reads of .grad complete a compact gradient.  Readers that take the field in C++ never pass through
+        # the property: DistributedDataParallel's reducer copies variable.grad() into its buckets from autograd hooks
+        # (Nerfstudio wraps the model in DDP for multi-GPU training), tensor hooks and post-accumulate-grad hooks receive
+        # the raw tensor.  With more than one rank in the default process group, or with hooks on either Parameter, the
+        # gradients are therefore always written out.  (This package's own data-parallel step, parallel.py, does not come
+        # through here: it exchanges the compact form itself.)
+        if _dist_world_size() > 1 or _has_grad_hooks(dc) or _has_grad_hooks(rest):
             return False
         st = _FLAT_STATES.get(self._flat.untyped_storage().data_ptr())
         if st is None or len(st.members) != len(self.group_names):
@@ -977,6 +1002,11 @@ class QEDSplatterModel(nn.Module):
             # own over the image in either direction (_PostProcess above is the stand-alone form of the same statements)
             rgb = info.pop("post_rgb")
             depth_im = info.pop("post_depth")
+        # The frame BEFORE this one overflowed its intersection buffer (asynchronous count, one call late): it rendered
+        # empty, so its outputs, loss and gradients were those of an empty image.  QedAdam / FlatAdam skipped their update
+        # on the device; a trainer that steps torch.optim.* (the reference's own config.py:44-68) sees it here -- in the
+        # dict the reference stores as self.info (model.py:267) -- and can drop that iteration's step / restore its state
+        info["intersection_overflow_previous_frame"] = _workspace(self.device).take_overflow_flag()
         attrs["info"] = info
         attrs["last_compact"] = False
         if self.training and info["means2d"].requires_grad:                   # model.py:289-290 (a no-op on the leaf)
@@ -1378,6 +1408,7 @@ class FlatAdam:
             self.lr[i] = exponential_decay_lr(self.t, self._means_lr_init, lr_final, max_steps)
             self._lr[i] = self.lr[i]
         self.t += 1
+        _counted_step(self, self.model.device)
 
     @torch.no_grad()
     def step_range(self, lo: int, hi: int) -> None:
@@ -1431,6 +1462,7 @@ class FlatAdam:
                 self._lr[i] = self.lr[i]
         if part & 1:
             self.t += 1
+            _counted_step(self, self.model.device)
         if fused_sh:
             m = self.model
             if not getattr(m, "last_compact", False):
@@ -1707,6 +1739,7 @@ class QedAdam(torch.optim.Optimizer):
             m = state["exp_avg"] = m.contiguous()
             v = state["exp_avg_sq"] = v.contiguous()
         state["step"] += 1
+        _counted_step(self, p.device)
         t = int(state["step"])
         if g.dtype != torch.float32 or not g.is_contiguous():
             g = g.to(torch.float32).contiguous()
@@ -1767,6 +1800,8 @@ class QedAdam(torch.optim.Optimizer):
         lib = L.load()
         members = [st.members[o] for o in offs]
         ps = [m.param_groups[0]["params"][0] for m in members]
+        for mem in members:
+            _counted_step(mem, ps[0].device)
         # compact SH gradients (QEDSplatterModel, lazy_sh_grad): consumed as they are when this launch covers all six
         # groups in one run (below); any other launch first has the coefficient gradients written out
         owner = ps[-1].__dict__.get("_qed_owner")

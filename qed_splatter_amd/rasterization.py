@@ -75,7 +75,9 @@ class _Workspace:
         self.n_isect = self.words[:1]
         self.status = self.words[1:]
         self._ring, self._ring_at = [], 0     # pinned read-back buffers of the asynchronous calls, reused
-        self.pending = None          # (pinned host words [M, overflow, watchdog, 0], shape key) of an async call
+        self.pending = None          # (pinned host words [M, overflow, watchdog, 0], shape key, frame) of an async call
+        self.frame = 0               # counts the asynchronous frames armed on this device (arm_pending)
+        self.last_overflow = False   # an asynchronous frame overflowed and nobody has been told yet (take_overflow_flag)
         self.m_seen: Dict[tuple, int] = {}   # shape key -> longest list read back for that shape
         self.force_sync = False      # the next call reads M back (an asynchronous frame overflowed)
         self.overflows = 0           # asynchronous frames that rendered empty (diagnostics / tests)
@@ -125,10 +127,26 @@ class _Workspace:
         """Device address of the overflow word: what the optimiser launches take as ``skip_flag``."""
         return self.status.data_ptr()
 
+    def arm_pending(self, words, key) -> None:
+        """An asynchronous frame has been enqueued whose {M, overflow} will land in ``words``: the next call looks."""
+        self.frame += 1
+        self.pending = (words, key, self.frame)
+
+    def counted_step(self, opt) -> None:
+        """An optimiser with a host step counter has counted a step whose launch sits behind the current frame (and takes
+        its overflow word as skip_flag): if that frame turns out to have overflowed, THAT optimiser takes the step back --
+        not every optimiser of the device (another model's, one that did not step this iteration)."""
+        opt.__dict__["_qed_frame"] = self.frame
+
+    def take_overflow_flag(self) -> bool:
+        """Did an asynchronous frame overflow since this was last asked?  (get_outputs puts it into ``info``.)"""
+        flag, self.last_overflow = self.last_overflow, False
+        return flag
+
     def poll_pending(self) -> None:
         if self.pending is None:
             return
-        words, key = self.pending
+        words, key, frame = self.pending
         self.pending = None
         if words[0] < 0:
             # the host is a frame ahead of the device: wait for that frame's binning.  A few looks back to back (the word
@@ -169,8 +187,11 @@ class _Workspace:
             self.force_sync = True
             old = self.capacity
             self.saw(key, overflow)
+            self.last_overflow = True
             for opt in list(self.steppers):                        # (the host is at most one frame ahead: ONE step was skipped)
-                opt.on_skipped_step()
+                if opt.__dict__.get("_qed_frame") == frame:        # ... by the optimisers that stepped behind THAT frame
+                    opt.__dict__["_qed_frame"] = None
+                    opt.on_skipped_step()
             warnings.warn(f"qed_splatter_amd: an asynchronous rasterization needed {overflow} tile intersections, more "
                           f"than the buffer held ({old}); that frame rendered empty and its optimiser step was skipped "
                           f"on the device.  Capacity raised to {self.capacity}.", RuntimeWarning, stacklevel=3)
@@ -482,7 +503,7 @@ def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, til
             ws.last_n_isect = n_isect                  # device tensor the replaying code polls
             return None, flatten_ids, offsets, None
         if not sync:
-            ws.pending = (host, key)
+            ws.arm_pending(host, key)
             return None, flatten_ids, offsets, None
         # one host read: M, the overflow word and the look-back watchdog word
         host = ws.words[:3].tolist()

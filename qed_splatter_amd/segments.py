@@ -72,6 +72,19 @@ class _SegmentFn(torch.autograd.Function):
                 dst.zero_()
             elif src.data_ptr() != dst.data_ptr() or src.stride() != dst.stride():
                 dst.copy_(src)                          # (a loss other than _ImageLosses: its gradient is copied in)
+        # Gradients of an EARLIER backward pass that still sit in the fields (gradient accumulation, zero_grad(set_to_none=
+        # False), a second backward on retained outputs) are aliases of the static buffers the replay is about to overwrite:
+        # the engine adopted them without a copy.  They are moved out first, so that AccumulateGrad adds the new gradients
+        # to the old values and not to themselves.  (The flat layout of .grad is given up for that step.)
+        from .model import _RAW_GRAD, _raw_grad
+        for p, g in zip(seg.params, grads):
+            old = _raw_grad(p) if g is not None else None
+            if old is not None and old.untyped_storage().data_ptr() == g.untyped_storage().data_ptr():
+                owner_m = getattr(seg, "lazy_owner", None)
+                m_ = owner_m() if owner_m is not None else None
+                if m_ is not None:
+                    m_._materialise_sh_grads()      # (a compact SH gradient waiting there is completed before it is copied)
+                _RAW_GRAD.__set__(p, old.clone())
         # the accumulator K7 adds into: zeroed by the loss's own backward launch when that was _ImageLosses (StepContext)
         if not (seg.holder and seg.holder[0] is seg.vsplat):
             seg.vsplat.zero_()
@@ -183,7 +196,7 @@ class OutputsSegment:
         self.slot[0][0] = -1                      # (the previous replay's word was read by poll_pending before this call)
         del self.holder[:]
         outs = _SegmentFn.apply(self, *self.params)
-        ws.pending = (self.slot[0], self.shape_key)
+        ws.arm_pending(self.slot[0], self.shape_key)
         rgb, alpha = outs[0], outs[1]
         depth = outs[2] if self.depth is not None else None
         return rgb, alpha, depth

@@ -7,9 +7,19 @@
 Per kernel: totals per dispatch (sum over the counter's instances), mean over dispatches.
 """
 import collections
+import hashlib
 import json
+import os
 import sqlite3
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the sources of the kernels the counters describe: bench.py quotes a summary only while these still hash the same
+KERNEL_SOURCES = ("qed_splatter_amd/csrc/composite.hip", "qed_splatter_amd/csrc/qed_common.h")
+
+
+def source_hashes():
+    return {rel: hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest() for rel in KERNEL_SOURCES}
 
 
 def per_kernel(path):
@@ -47,7 +57,7 @@ if mode == "traffic":
     json.dump({"_about": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two separate passes), totals per dispatch, KB as "
                          "reported; gfx950: FETCH_SIZE counts half the bytes of a wide coalesced read (double it), "
                          "WRITE_SIZE is exact for 16-B stores and float atomics (MI355X_MICROARCH.md)",
-               "kernels_version": about, "kernels": kernels}, open(out, "w"), indent=1)
+               "kernels_version": about, "source_sha256": source_hashes(), "kernels": kernels}, open(out, "w"), indent=1)
 else:
     v, out, about = per_kernel(sys.argv[2]), sys.argv[3], sys.argv[4]
     kernels = {}
@@ -62,5 +72,5 @@ else:
             "valu_issue_frac": round(c["SQ_ACTIVE_INST_VALU"] / simd_quads, 3),
             "mean_waves_per_simd": round(c.get("SQ_WAVE_CYCLES", 0.0) / simd_quads, 2)}
     json.dump({"_about": "valu_issue_frac = SQ_ACTIVE_INST_VALU (quad-cycles) / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs / 4)",
-               "kernels_version": about, "kernels": kernels}, open(out, "w"), indent=1)
+               "kernels_version": about, "source_sha256": source_hashes(), "kernels": kernels}, open(out, "w"), indent=1)
 print("wrote", out)

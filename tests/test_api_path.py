@@ -1063,6 +1063,47 @@ def test_graphed_get_outputs_follows_shape_changes_and_other_losses(cuda):
         assert_close(grads[True][k], grads[False][k].double().cpu(), 2e-5, f"grad {k} (custom loss through the segment)")
 
 
+@pytest.mark.parametrize("how", ["accumulate", "zero_in_place", "retain_graph"])
+def test_graphed_backward_adds_to_gradients_that_wait_in_the_fields(cuda, how):
+    """The captured backward pass hands autograd ALIASES of its static gradient buffers, which the engine adopts as .grad
+    without a copy.  A second backward pass while those are still set (gradient accumulation over two get_outputs calls,
+    zero_grad(set_to_none=False), a second backward on retained outputs) must add to the OLD values: the waiting gradients
+    are moved out of the static buffers before the replay overwrites them.  Against the eager route, which allocates."""
+    w, h, n = 160, 112, 3000
+    sc = scene(n, w, h, seed=31)
+    g = torch.Generator().manual_seed(4)
+    w1, w2 = torch.rand(h, w, 3, generator=g).to(cuda), torch.rand(h, w, 3, generator=g).to(cuda)
+    got = {}
+    for graphed in (False, True):
+        m, cam, batch = _model(sc, cuda, graph_segments="always" if graphed else False)
+        m.train()
+        for it in range(6):                                   # (the shape is captured on the fourth call)
+            for p in m.parameters():
+                p.grad = None
+            (m.get_outputs(cam)["rgb"] * w1).sum().backward()
+        if graphed:
+            assert len(m._segments.segments) == 1
+        if how == "accumulate":                               # two forward / backward passes, no zero_grad in between
+            for p in m.parameters():
+                p.grad = None
+            (m.get_outputs(cam)["rgb"] * w1).sum().backward()
+            (m.get_outputs(cam)["rgb"] * w2).sum().backward()
+        elif how == "zero_in_place":                          # the fields keep (zeroed) tensors: still the static buffers
+            for p in m.parameters():
+                if p.grad is not None:
+                    p.grad.zero_()
+            (m.get_outputs(cam)["rgb"] * w2).sum().backward()
+        else:                                                 # two backward passes through ONE step's outputs
+            for p in m.parameters():
+                p.grad = None
+            out = m.get_outputs(cam)
+            (out["rgb"] * w1).sum().backward(retain_graph=True)
+            (out["rgb"] * w2).sum().backward()
+        got[graphed] = {k: m.gauss_params[k].grad.detach().clone() for k in PARAM_NAMES}
+    for k in PARAM_NAMES:
+        assert_close(got[True][k], got[False][k].double().cpu(), 2e-5, f"grad {k} ({how}, through the segment)")
+
+
 # ---- SH gradients kept compact until somebody reads them (config.lazy_sh_grad) --------------------------------------
 def _six_qed_adams(m):
     from qed_splatter_amd.model import FlatAdam, QedAdam

@@ -470,13 +470,15 @@ def test_projection_sh_backward(cuda, mode, deg):
         ad["colors"] = torch.sigmoid(ad["colors"][:, 0, :])
     for k in ("means", "quats", "scales", "opacities", "colors"):
         ad[k].requires_grad_(True)
+    # the oracle takes the radii of the kernels under test (ceil() of a value within fp32 rounding of an integer is a
+    # coin toss and the radius is not differentiable): visibility is then the same on both sides by construction
     radii, m2, depths, conics, comp = O.project_gaussians(
         ad["means"], ad["quats"], ad["scales"], ad["viewmats"], ad["Ks"], w, h,
-        calc_compensations=(mode == "antialiased"))
+        calc_compensations=(mode == "antialiased"), radii_override=info["radii"].cpu())
     opac = ad["opacities"][None].expand(C, -1)
     if comp is not None:
         opac = opac * comp
-    # use the GPU's visibility so that radius-rounding differences do not enter the comparison
+    assert bool((radii > 0).eq(vis).all())
     vm = vis.double()
     if deg is None:
         cols = ad["colors"][None].expand(C, -1, -1)
@@ -485,10 +487,8 @@ def test_projection_sh_backward(cuda, mode, deg):
     ref = dict(means2d=m2, depths=depths, conics=conics, opacities=opac, colors=cols)
     loss_ref = sum((ref[k] * ups[k].double() * (vm[..., None] if ref[k].dim() == 3 else vm)).sum() for k in ups)
     loss_ref.backward()
-    same = bool((radii > 0).eq(vis).all())
-    tol = REL_TOL if same else 5e-3
     for got, name in zip(grads, ("means", "quats", "scales", "opacities", "colors")):
-        assert_close(got, ad[name].grad, tol, f"v_{name} ({mode}, deg={deg})")
+        assert_close(got, ad[name].grad, REL_TOL, f"v_{name} ({mode}, deg={deg})")
 
 
 @pytest.mark.parametrize("deg", [3, 1])

@@ -1,6 +1,7 @@
 """Host-side logic that needs no GPU: when get_outputs' captured segments are worth their capture (segments.SegmentCache)."""
 from __future__ import annotations
 
+import os
 import types
 
 import pytest
@@ -158,3 +159,67 @@ def test_lazy_sh_gradient_parameters_complete_the_gradients_for_every_python_rea
     m.__dict__["_lazy_sh"] = {"stand-in": True}
     m.rebind_flat(m.flat_params.detach().clone(), m.num_points)
     assert m.__dict__["_lazy_sh"] is None and type(m.gauss_params["features_rest"]) is _LazySHGradParameter
+
+
+def test_committed_counters_are_quoted_only_for_the_sources_they_were_taken_on(tmp_path):
+    """bench.py's roofline.traffic / roofline_issue.frac come from committed --pmc summaries: a summary is quoted only
+    while the kernel sources it records (sha256) are the tree's; an edited kernel, a summary without the record or a
+    missing file give None (the bench line then carries traffic: null)."""
+    import hashlib
+    import json
+    import bench
+
+    src = tmp_path / "qed_splatter_amd" / "csrc"
+    src.mkdir(parents=True)
+    (tmp_path / "profiles").mkdir()
+    (src / "composite.hip").write_text("// kernel v1\n")
+    h = hashlib.sha256((src / "composite.hip").read_bytes()).hexdigest()
+    body = {"kernels_version": "t", "source_sha256": {"qed_splatter_amd/csrc/composite.hip": h},
+            "kernels": {"qed::composite_bwd_kernel<4>": {"fetch_size_kb": 1.0, "write_size_kb": 2.0}}}
+    (tmp_path / "profiles" / "good.json").write_text(json.dumps(body))
+    (tmp_path / "profiles" / "nohash.json").write_text(json.dumps({k: v for k, v in body.items() if k != "source_sha256"}))
+    (tmp_path / "profiles" / "empty.json").write_text(json.dumps({**body, "source_sha256": {}}))
+    assert bench.committed_counters("good.json", root=str(tmp_path))["kernels"]
+    assert bench.committed_counters("nohash.json", root=str(tmp_path)) is None
+    assert bench.committed_counters("empty.json", root=str(tmp_path)) is None
+    assert bench.committed_counters("absent.json", root=str(tmp_path)) is None
+    (src / "composite.hip").write_text("// kernel v2\n")                 # the kernel changes: the summary goes stale
+    assert bench.committed_counters("good.json", root=str(tmp_path)) is None
+    # the summaries bench.py names are either absent (not taken yet for this tree) or match it -- never silently stale
+    for name in (bench.PMC_TRAFFIC, bench.PMC_VALU):
+        path = os.path.join(bench.ROOT, "profiles", name)
+        if os.path.exists(path) and bench.committed_counters(name) is None:
+            import warnings
+            warnings.warn(f"{name} does not describe this tree's kernels: bench.py will report traffic: null")
+
+
+def test_lazy_sh_gradients_are_off_whenever_a_c_level_reader_could_see_them(monkeypatch):
+    """Only Python reads of ``.grad`` complete a compact SH gradient.  DistributedDataParallel's reducer and tensor /
+    post-accumulate-grad hooks take the raw field, so with more than one rank in the default process group, or with a hook
+    on either SH Parameter, a training step writes its gradients out."""
+    import types as _types
+    import torch
+    from qed_splatter_amd import model as M
+    from tests.util import PARAM_NAMES, scene
+    sc = scene(40, 32, 32, seed=3)
+    m = M.QEDSplatterModel(None, **{k: sc[k] for k in PARAM_NAMES})
+    m.train()
+    # stand-in for "all six groups are stepped by QedAdam instances" (the registry itself needs GPU tensors)
+    class _Six:                                                          # (WeakValueDictionary: needs a weak-referenceable value)
+        members = [0] * 6
+    six = _Six()
+    monkeypatch.setitem(M._FLAT_STATES, m._flat.untyped_storage().data_ptr(), six)
+    assert m._lazy_sh_wanted(3, None) is True
+    assert m._lazy_sh_wanted(None, None) is False                       # sh_degree 0 in use: colours, no coefficients
+    monkeypatch.setattr(M, "_dist_world_size", lambda: 2)
+    assert m._lazy_sh_wanted(3, None) is False
+    monkeypatch.setattr(M, "_dist_world_size", lambda: 1)
+    assert m._lazy_sh_wanted(3, None) is True
+    h = m.gauss_params["features_rest"].register_hook(lambda g: g)
+    assert m._lazy_sh_wanted(3, None) is False
+    h.remove()
+    assert m._lazy_sh_wanted(3, None) is True
+    h = m.gauss_params["features_dc"].register_post_accumulate_grad_hook(lambda p: None)
+    assert m._lazy_sh_wanted(3, None) is False
+    h.remove()
+    assert m._lazy_sh_wanted(3, None) is True
