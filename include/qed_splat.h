@@ -61,7 +61,13 @@ extern "C" {
                                    (get_viewmat, model.py:22-38: what qed_camera_setup does in a launch of its own) and
                                    writes them to viewmats_out[C,4,4] / Ks_out[C,3,3] for the kernels that follow */
 
-int qed_version(void);
+/* Version of this C ABI: bumped whenever an entry point's argument list or a buffer layout changes incompatibly.
+ *   1  rounds 1-3.
+ *   2  round 4: qed_composite_fwd / qed_composite_bwd gained `t_final` in the middle of their argument lists; the row of
+ *      the compact data-parallel message grew from 3 N + 16 to 3 N + 20 floats (still reported as 1 by that round's
+ *      library).  A caller built against another version must not call further: the pointers would be shifted. */
+#define QED_ABI_VERSION 2
+int qed_version(void);   /* == QED_ABI_VERSION of the header the library was built from */
 const char* qed_last_error(void);
 
 /* Device-side address of a pinned, mapped host allocation (hipHostGetDevicePointer): what qed_bin_tiles' host_words must

@@ -129,8 +129,11 @@ class QedSplatError(RuntimeError):
     pass
 
 
+ABI_VERSION = 2          # include/qed_splat.h: QED_ABI_VERSION (tests/test_abi.py checks the two against each other)
+
+
 def load():
-    """Load the shared library (once).  Raises if it has not been built."""
+    """Load the shared library (once).  Raises if it has not been built, or implements another version of the C ABI."""
     global _LIB
     if _LIB is not None:
         return _LIB
@@ -149,6 +152,10 @@ def load():
         fn.restype = res
         fn.argtypes = args
         ns[name] = _wrap(name, fn) if res is C.c_int and args else fn
+    got = int(cdll.qed_version())
+    if got != ABI_VERSION:
+        raise QedSplatError(f"{path} implements C ABI version {got}, this package binds version {ABI_VERSION} "
+                            "(include/qed_splat.h: QED_ABI_VERSION): rebuild it with `python -m qed_splatter_amd.build --force`")
     _LIB = types.SimpleNamespace(**ns)
     return _LIB
 

@@ -625,7 +625,7 @@ __global__ void lr_exp_decay_kernel(float* __restrict__ lr_slot, const float* __
 
 using namespace qed;
 
-extern "C" int qed_version(void) { return 1; }
+extern "C" int qed_version(void) { return QED_ABI_VERSION; }
 extern "C" const char* qed_last_error(void) { return g_err; }
 
 // The device-side address of a pinned (page-locked, mapped) host allocation: what a kernel must be given to store into

@@ -14,6 +14,15 @@ from torch import Tensor
 from . import _lib as L
 
 
+def frame_intrinsics(contents: dict, frame: dict):
+    """(fx, fy, cx, cy) of one frame of a transforms.json: frame-level values win over the file's, and a missing ``fl_y``
+    falls back to the FRAME's ``fl_x`` before the file's (create_init_pointcloud.py:49-56; pinned by
+    tests/golden/reference_kats.npz ``ip_intrinsics_*``)."""
+    fl_x = float(frame.get("fl_x", contents["fl_x"]))
+    fl_y = float(frame.get("fl_y", contents.get("fl_y", fl_x)))
+    return fl_x, fl_y, float(frame.get("cx", contents["cx"])), float(frame.get("cy", contents["cy"]))
+
+
 @torch.no_grad()
 def backproject_depth(depth: Tensor, fx: float, fy: float, cx: float, cy: float, c2w_opengl: Tensor,
                       depth_max: float = 100.0, stride: int = 1) -> Tensor:

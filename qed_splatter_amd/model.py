@@ -1164,6 +1164,22 @@ class QEDSplatterModel(nn.Module):
         from .rasterization import _workspace
         return _workspace(self.device).overflows
 
+    def frame_overflowed(self) -> bool:
+        """Did the frame the LAST get_outputs / fused_loss call enqueued overflow its intersection buffer (it then rendered
+        empty: zero loss gradients)?  Asked between ``backward()`` and the optimiser steps by a trainer whose optimisers do
+        not take the device-side skip word -- ``torch.optim.Adam``, the reference's own config.py:44-68, would make a
+        momentum-only update from the empty frame -- so that it can drop that iteration's step:
+
+            loss.backward()
+            if not model.frame_overflowed():
+                for o in optimizers.values(): o.step()
+
+        Waits until the device has run that frame's binning (the count lands in pinned memory), not for the frame.  The
+        same fact reaches ``self.info["intersection_overflow_previous_frame"]`` at the next get_outputs."""
+        ws = _workspace(self.device)
+        ws.poll_pending()
+        return bool(ws.last_overflow)
+
     def backward_fused(self, losses: Dict[str, Tensor]) -> None:
         """``losses["loss"].backward()`` without the per-step ``ones_like`` fill autograd would launch for the
         seed gradient (the fused loss kernel has already written d loss / d render for a seed of 1)."""

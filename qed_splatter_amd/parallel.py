@@ -206,7 +206,8 @@ def backward_with_early_gather(model, losses, world_size: int, group=None) -> No
     loss = losses["loss"]
     g = torch.autograd.grad(loss, inter, grad_outputs=_unit_grad(loss.device), allow_unused=True)
     vsplat = _VSPLAT_REGISTRY.get(g[0].untyped_storage().data_ptr())
-    sh_jac = node.saved_tensors[9]
+    from .rasterization import _ProjectSH
+    sh_jac = _ProjectSH.saved(node, "sh_jac")
     eg = early_gather(model, world_size, group)
     if vsplat is not None and sh_jac is not None and getattr(model, "last_compact", False):
         model._early_gather = None

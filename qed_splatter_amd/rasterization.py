@@ -278,6 +278,21 @@ def manual_backward(manual, v_render=None, v_alpha=None, v_rgb=None, v_depth=Non
 # projection + SH
 # ==================================================================================================
 class _ProjectSH(torch.autograd.Function):
+    # what forward saves, by NAME: code outside this class (segments.py, parallel.py) asks saved(ctx, "sh_jac") instead of
+    # counting positions -- a reordering of the two statements in forward only has to keep these two tuples in step
+    SAVED = ("means", "quats", "scales", "opacities", "sh0", "shN", "viewmats", "Ks", "radii", "sh_jac")
+    META = ("N", "C", "width", "height", "sh_degree", "flags", "eps2d", "sh0_stride", "shN_stride")
+
+    @classmethod
+    def saved(cls, ctx, name: str):
+        """A saved tensor or meta value of a forward context / backward node of this Function, by name."""
+        if name in cls.SAVED:
+            t = ctx.saved_tensors
+            assert len(t) == len(cls.SAVED)
+            return t[cls.SAVED.index(name)]
+        assert len(ctx.meta) == len(cls.META)
+        return ctx.meta[cls.META.index(name)]
+
     @staticmethod
     def forward(ctx, means, quats, scales, opacities, sh0, shN, viewmats, Ks, width, height, tile_w, tile_h,
                 sh_degree, flags, eps2d, near_plane, far_plane, radius_clip, c2w=None, intr=None, lazy_sh=None):
@@ -340,8 +355,8 @@ class _ProjectSH(torch.autograd.Function):
             L.ptr(viewmats) if c2w is not None else None, L.ptr(Ks) if c2w is not None else None, L.ptr(sh_jac),
             _stream()), "qed_project_fwd")
         flags &= ~L.F_CAMERA_C2W                  # (the backward pass reads the view matrices the kernel wrote)
-        ctx.save_for_backward(means, quats, scales, opacities, sh0, shN, viewmats, Ks, radii, sh_jac)
-        ctx.meta = (N, C, width, height, sh_degree, flags, eps2d, sh0_stride, shN_stride)
+        ctx.save_for_backward(means, quats, scales, opacities, sh0, shN, viewmats, Ks, radii, sh_jac)      # order: SAVED
+        ctx.meta = (N, C, width, height, sh_degree, flags, eps2d, sh0_stride, shN_stride)                  # order: META
         ctx.opac_shape = opac_shape
         if tile_masks is None:
             tile_masks = _NO_MASKS.get(dev)

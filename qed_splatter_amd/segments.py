@@ -98,7 +98,8 @@ class _SegmentFn(torch.autograd.Function):
             c_proj = seg.manual[0]
             i_dc = seg.param_names.index("features_dc")
             v_dc, v_rest = grads[i_dc], grads[i_dc + 1]
-            viewmats, deg = c_proj.saved_tensors[6], c_proj.meta[4]
+            from .rasterization import _ProjectSH
+            viewmats, deg = _ProjectSH.saved(c_proj, "viewmats"), _ProjectSH.saved(c_proj, "sh_degree")
             m = owner()
             if m is None or not m._lazy_sh_begin(v_dc, v_rest, viewmats, deg):
                 from .model import write_sh_grads

@@ -11,6 +11,12 @@ functions whose bodies are entirely the reference's own torch code are then exec
   * get_viewmat                         /root/reference/qed_splatter/model.py:22-38
   * QEDSplatterModel.get_loss_dict      model.py:73-118   (depth-L1 term; parent loss stubbed to {})
   * DepthMetrics.forward                /root/reference/qed_splatter/metrics.py:126-156
+  * _opengl_c2w_to_opencv_w2c, _frame_intrinsics   /root/reference/qed_splatter/create_init_pointcloud.py:49-70
+                                        (open3d / tyro / PIL satisfied with empty placeholders; nothing of them runs)
+  * QEDSplatterModel.get_metrics_dict   model.py:120-197, the d = 1 branch: ground-truth selection ([..., :3] of an RGBA
+                                        image), rgb_mse, the seven depth metrics through the reference's own DepthMetrics,
+                                        avg_min_scale, gaussian_count and the KEY SET.  PSNR / SSIM / LPIPS come from
+                                        torchmetrics (absent): a stand-in returns constants, which are not recorded
 The rasterizer (gsplat) cannot be exercised this way -> rasterizer parity stays "unpinned".
 Output: tests/golden/reference_kats.npz (data only: inputs and the reference's outputs).
 """
@@ -59,6 +65,11 @@ def install_placeholders():
     _placeholder("torchmetrics")
     _placeholder("torchmetrics.image", PeakSignalNoiseRatio=dummy, StructuralSimilarityIndexMeasure=dummy)
     _placeholder("torchmetrics.image.lpip", LearnedPerceptualImagePatchSimilarity=dummy)
+    # create_init_pointcloud.py:24-27 (annotations are strings there: nothing of these is touched at import)
+    _placeholder("open3d")
+    _placeholder("tyro", cli=lambda *a, **k: None)
+    _placeholder("PIL", Image=types.SimpleNamespace())
+    sys.modules["PIL.Image"] = sys.modules["PIL"].Image
 
 
 def main():
@@ -132,6 +143,66 @@ def main():
     out["dm_pred"] = pred.numpy()
     out["dm_gt"] = gt.numpy()
     out["dm_out"] = np.array([float(v) for v in dm(pred, gt)], dtype=np.float64)
+
+    # ---- qed-init-pc's pose / intrinsics helpers (create_init_pointcloud.py:49-70) ----
+    import json
+    import qed_splatter.create_init_pointcloud as CP
+    qq = torch.randn(6, 4, generator=g, dtype=torch.float64)
+    qq = qq / qq.norm(dim=-1, keepdim=True)
+    w, x, y, z = qq.unbind(-1)
+    Rm = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                      2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                      2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1).reshape(6, 3, 3)
+    poses = torch.eye(4, dtype=torch.float64)[None].repeat(6, 1, 1)
+    poses[:, :3, :3] = Rm
+    poses[:, :3, 3] = torch.randn(6, 3, generator=g, dtype=torch.float64) * 4
+    poses[0] = torch.eye(4, dtype=torch.float64)
+    poses[0, :3, 3] = torch.tensor([1.0, 2.0, 3.0], dtype=torch.float64)
+    out["ip_c2w_opengl"] = poses.numpy()
+    out["ip_w2c_opencv"] = np.stack([CP._opengl_c2w_to_opencv_w2c(p_) for p_ in poses.numpy()])
+    # (contents, frame) pairs: frame-level values win, fl_y falls back to the FRAME's fl_x, then the file's
+    intr_cases = [
+        ({"fl_x": 500.0, "fl_y": 510.0, "cx": 320.0, "cy": 240.0}, {}),
+        ({"fl_x": 500.0, "cx": 320.0, "cy": 240.0}, {}),
+        ({"fl_x": 500.0, "fl_y": 510.0, "cx": 320.0, "cy": 240.0}, {"fl_x": 777.5, "cx": 300.25}),
+        ({"fl_x": 500.0, "cx": 320.0, "cy": 240.0}, {"fl_x": 640.0}),
+        ({"fl_x": 500.0, "fl_y": 510.0, "cx": 320.0, "cy": 240.0}, {"fl_x": 600.0, "fl_y": 601.0, "cx": 1.5, "cy": 2.5}),
+    ]
+    out["ip_intrinsics_cases"] = np.array(json.dumps(intr_cases))
+    out["ip_intrinsics_out"] = np.stack([CP._frame_intrinsics(c, f) for c, f in intr_cases])
+
+    # ---- get_metrics_dict, d = 1 (model.py:120-197) ----
+    class _RGBStandIn(torch.nn.Module):                     # torchmetrics is absent: constants, never recorded
+        def forward(self, pred, gt):
+            return torch.tensor(1.0), torch.tensor(2.0), torch.tensor(3.0)
+    mm = M.QEDSplatterModel.__new__(M.QEDSplatterModel)
+    torch.nn.Module.__init__(mm)
+    mm.rgb_metrics, mm.depth_metrics, mm.mse_loss = _RGBStandIn(), DepthMetrics(), torch.nn.MSELoss()
+    mm._get_downscale_factor = lambda: 1
+    n_pts = 37
+    mm.gauss_params = torch.nn.ParameterDict({"scales": torch.nn.Parameter(torch.randn(n_pts, 3, generator=g) - 3.0),
+                                              "means": torch.nn.Parameter(torch.zeros(n_pts, 3))})
+    type(mm).scales = property(lambda self: self.gauss_params["scales"])
+    type(mm).num_points = property(lambda self: self.gauss_params["means"].shape[0])
+    type(mm).device = property(lambda self: torch.device("cpu"))
+    with torch.no_grad():
+        mm.gauss_params["scales"][3, 2] = float("nan")       # nanmean (model.py:193)
+    Hh, Ww = 20, 28
+    md_rgb = torch.rand(Hh, Ww, 3, generator=g)
+    md_depth = torch.rand(Hh, Ww, 1, generator=g) * 8 + 0.5
+    md_img = torch.rand(Hh, Ww, 4, generator=g)                # RGBA ground truth: [..., :3] is compared
+    md_gt_depth = torch.rand(Hh, Ww, 1, generator=g) * 8
+    md_gt_depth[md_gt_depth < 0.8] = 0.0
+    for tag, batch in (("md", {"image": md_img, "depth_image": md_gt_depth}), ("mdn", {"image": md_img})):
+        got = mm.get_metrics_dict({"rgb": md_rgb, "depth": md_depth}, batch)
+        out[f"{tag}_keys"] = np.array(json.dumps(list(got.keys())))
+        out[f"{tag}_types"] = np.array(json.dumps({k: type(v).__name__ for k, v in got.items()}))
+        for k, v in got.items():
+            if k not in ("rgb_psnr", "rgb_ssim", "rgb_lpips"):
+                out[f"{tag}_{k}"] = np.float64(float(v))
+    out["md_rgb"], out["md_depth"], out["md_image"], out["md_gt_depth"] = (md_rgb.numpy(), md_depth.numpy(), md_img.numpy(),
+                                                                           md_gt_depth.numpy())
+    out["md_scales"] = mm.gauss_params["scales"].detach().numpy()
 
     np.savez_compressed(OUT, **out)
     print(f"wrote {OUT}: {sorted(out)}")

@@ -35,7 +35,13 @@ def test_exports_are_plain_c(lib):
 
 
 def test_host_only_entry_points(lib):
-    assert lib.qed_version() == 1
+    # the library, the header it was built from and the Python binding agree on the ABI version (a direct C-ABI caller
+    # built against another header must refuse to go on: argument lists have changed between versions)
+    import re
+    from qed_splatter_amd import _lib
+    header = open(HEADER).read()
+    declared = int(re.search(r"#define\s+QED_ABI_VERSION\s+(\d+)", header).group(1))
+    assert lib.qed_version() == declared == _lib.ABI_VERSION == 2
     # workspace sizing is pure host arithmetic: monotone, and enough for 256 counters per block
     a, b = lib.qed_sort_workspace_bytes(1), lib.qed_sort_workspace_bytes(10_000_000)
     assert 0 < a < b and b >= 256 * 4 * (10_000_000 // 2048)

@@ -1063,6 +1063,42 @@ def test_graphed_get_outputs_follows_shape_changes_and_other_losses(cuda):
         assert_close(grads[True][k], grads[False][k].double().cpu(), 2e-5, f"grad {k} (custom loss through the segment)")
 
 
+@pytest.mark.parametrize("training", [False, True])
+def test_reference_get_metrics_dict_kats_keys_values_and_writer_shape(cuda, training):
+    """get_metrics_dict against the reference's own (model.py:120-197, d = 1 branch, executed by
+    tests/golden/make_reference_kats.py): the same KEYS in the same order, rgb_mse on the first three channels of an RGBA
+    ground truth, the seven depth metrics, avg_min_scale (nanmean), gaussian_count -- with and without a depth image in
+    the batch.  The mirror returns 0-dim device tensors where the reference returns Python floats (a deliberate
+    deviation: no sync per entry); what a writer does with them must work: ``float(v)`` on every entry and a JSON dump."""
+    import json
+    from qed_splatter_amd.model import QEDSplatterModel, QEDSplatterModelConfig
+    k = np.load(os.path.join(GOLD, "reference_kats.npz"))
+    scales = torch.from_numpy(k["md_scales"])
+    n = scales.shape[0]
+    g = torch.Generator().manual_seed(1)
+    m = QEDSplatterModel(QEDSplatterModelConfig.synthetic(), means=torch.randn(n, 3, generator=g).to(cuda),
+                         scales=scales.to(cuda), quats=torch.randn(n, 4, generator=g).to(cuda),
+                         opacities=torch.zeros(n, 1).to(cuda), features_dc=torch.zeros(n, 3).to(cuda),
+                         features_rest=torch.zeros(n, 15, 3).to(cuda))
+    m.train(training)
+    outputs = {"rgb": torch.from_numpy(k["md_rgb"]).to(cuda), "depth": torch.from_numpy(k["md_depth"]).to(cuda)}
+    image = torch.from_numpy(k["md_image"]).to(cuda)
+    for tag, batch in (("md", {"image": image, "depth_image": torch.from_numpy(k["md_gt_depth"]).to(cuda)}),
+                       ("mdn", {"image": image})):
+        got = m.get_metrics_dict(outputs, batch)
+        assert list(got.keys()) == json.loads(str(k[f"{tag}_keys"])), tag
+        as_floats = {key: float(v) for key, v in got.items()}            # what a writer does with every entry
+        json.dumps(as_floats)
+        assert as_floats["gaussian_count"] == float(k[f"{tag}_gaussian_count"]) == n
+        for key in got:
+            if key in ("rgb_psnr", "rgb_ssim", "rgb_lpips", "gaussian_count"):   # torchmetrics' / no weights offline
+                continue
+            assert as_floats[key] == pytest.approx(float(k[f"{tag}_{key}"]), rel=2e-5), (tag, key)
+        # PSNR follows from the pinned MSE (data range 1)
+        assert as_floats["rgb_psnr"] == pytest.approx(-10.0 * math.log10(float(k[f"{tag}_rgb_mse"])), rel=1e-5)
+        assert 0.0 < as_floats["rgb_ssim"] < 1.0 and math.isnan(as_floats["rgb_lpips"])
+
+
 @pytest.mark.parametrize("how", ["accumulate", "zero_in_place", "retain_graph"])
 def test_graphed_backward_adds_to_gradients_that_wait_in_the_fields(cuda, how):
     """The captured backward pass hands autograd ALIASES of its static gradient buffers, which the engine adopts as .grad

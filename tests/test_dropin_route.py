@@ -151,6 +151,60 @@ def test_async_overflow_skips_the_update_warns_and_recovers(cuda):
     assert float(out["accumulation"].sum()) > 0.0
 
 
+def test_overflow_is_visible_to_a_trainer_that_steps_torch_adam(cuda):
+    """The reference's own optimisers (torch.optim.Adam per group, config.py:44-68) do not take the device-side skip word:
+    an empty (overflowed) frame's zero gradients would still move the parameters by the momentum.  The trainer can see the
+    overflow in time -- ``model.frame_overflowed()`` between backward and the steps -- and drop the step; the frame after
+    carries ``info["intersection_overflow_previous_frame"]`` (the dict the reference keeps as self.info, model.py:267)."""
+    from qed_splatter_amd import rasterization as R
+    R._WORKSPACES.clear()
+    n, w, h = 8_000, 320, 240
+    sc = _big_splat_scene(n, w, h, seed=33, grow=math.log(4.0))
+    m, cam, batch, _ = _setup(sc, cuda, num_downscales=0, lazy_sh_grad=False)
+    lrs = {"means": 1.6e-4, "scales": 0.005, "quats": 0.001, "opacities": 0.05, "features_dc": 0.0025,
+           "features_rest": 0.0025 / 20}
+    opts = {k: torch.optim.Adam([m.gauss_params[k]], lr=lrs[k], eps=1e-15) for k in m.group_names}
+    m.train()
+
+    def iteration(step):
+        m.step = step
+        for o in opts.values():
+            o.zero_grad()
+        out = m.get_outputs(cam)
+        flag_prev = m.info["intersection_overflow_previous_frame"]
+        sum(m.get_loss_dict(out, batch).values()).backward()
+        dropped = m.frame_overflowed()
+        if not dropped:
+            for o in opts.values():
+                o.step()
+        return out, flag_prev, dropped
+
+    for step in range(3):
+        out, flag_prev, dropped = iteration(step)
+        assert not flag_prev and not dropped
+    torch.cuda.synchronize()
+    ws = R._workspace(cuda)
+    M = int(m.info["tiles_per_gauss"].sum())
+    ws.capacity = max(M // 3, 1024)
+    before = m.flat_params.clone()
+    mom = {k: opts[k].state[m.gauss_params[k]]["exp_avg"].clone() for k in m.group_names}
+    steps_before = {k: float(opts[k].state[m.gauss_params[k]]["step"]) for k in m.group_names}
+    with pytest.warns(RuntimeWarning, match="rendered empty"):
+        out, flag_prev, dropped = iteration(3)                  # overflows; the trainer sees it and drops the step
+    torch.cuda.synchronize()
+    assert dropped and not flag_prev and float(out["accumulation"].sum()) == 0.0
+    assert torch.equal(m.flat_params, before)
+    for k in m.group_names:
+        st = opts[k].state[m.gauss_params[k]]
+        assert torch.equal(st["exp_avg"], mom[k]) and float(st["step"]) == steps_before[k], k
+    out, flag_prev, dropped = iteration(4)                      # regrown, synchronous, trained on; the dict says what happened
+    torch.cuda.synchronize()
+    assert flag_prev and not dropped and float(out["accumulation"].sum()) > 0.0
+    assert not torch.equal(m.flat_params, before)
+    out, flag_prev, dropped = iteration(5)
+    assert not flag_prev and not dropped
+
+
 def test_graphed_step_overflow_is_skipped_and_recaptured(cuda):
     """The same guarantee for a replayed hipGraph, whose buffers cannot grow: replays that overflow train nothing,
     check() re-captures with room and returns False, the replays after it train."""

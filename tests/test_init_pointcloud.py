@@ -77,3 +77,44 @@ def test_backproject_no_valid_depth(cuda):
     d = torch.full((32, 32), float("nan"), device=cuda)
     d[0, :4] = 0.0
     assert backproject_depth(d, 30.0, 30.0, 16.0, 16.0, torch.eye(4)).shape == (0, 3)
+
+
+# ---- pinned by the reference's own helpers (tests/golden/make_reference_kats.py: create_init_pointcloud.py:49-70) ----
+def _kats():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.npz"))
+
+
+def test_pose_conversion_and_intrinsics_match_the_reference_vectors():
+    """`_opengl_c2w_to_opencv_w2c` and `_frame_intrinsics` executed from the reference: the oracle's restatement of the
+    first and the product's host helper for the second give the same numbers."""
+    import json
+    from qed_splatter_amd.init_pointcloud import frame_intrinsics
+    k = _kats()
+    for c2w, w2c in zip(k["ip_c2w_opengl"], k["ip_w2c_opencv"]):
+        np.testing.assert_allclose(B.opengl_c2w_to_opencv_w2c(c2w), w2c.astype(np.float64), rtol=0, atol=2e-6)
+    for (contents, frame), want in zip(json.loads(str(k["ip_intrinsics_cases"])), k["ip_intrinsics_out"]):
+        fx, fy, cx, cy = frame_intrinsics(contents, frame)
+        np.testing.assert_array_equal(np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], dtype=np.float32), want)
+
+
+@pytest.mark.gpu
+def test_backprojected_points_return_to_their_pixels_through_the_reference_w2c(cuda):
+    """qed_backproject_depth takes the OpenGL camera-to-world pose; the reference hands Open3D the OpenCV world-to-camera
+    matrix it derives from it.  With the reference's OWN matrices (known-answer vectors): every point the kernel emits,
+    carried back by that matrix, is the pinhole un-projection of its pixel ((u - cx) d / fx, (v - cy) d / fy, d)."""
+    from qed_splatter_amd.init_pointcloud import backproject_depth
+    k = _kats()
+    h, w = 37, 53
+    rng = np.random.default_rng(11)
+    depth = rng.uniform(0.5, 9.0, size=(h, w)).astype(np.float32)
+    depth[rng.uniform(size=(h, w)) < 0.15] = 0.0
+    fx, fy, cx, cy = 61.5, 63.25, 26.0, 18.5
+    vs, us = np.nonzero(depth > 0)
+    d = depth[vs, us].astype(np.float64)
+    cam = np.stack([(us - cx) * d / fx, (vs - cy) * d / fy, d], -1)
+    for c2w, w2c in zip(k["ip_c2w_opengl"], k["ip_w2c_opencv"]):
+        pts = backproject_depth(torch.from_numpy(depth).to(cuda), fx, fy, cx, cy, torch.from_numpy(c2w)).cpu().numpy()
+        assert pts.shape == cam.shape
+        back = pts.astype(np.float64) @ w2c[:3, :3].astype(np.float64).T + w2c[:3, 3].astype(np.float64)
+        np.testing.assert_allclose(back, cam, rtol=0, atol=2e-4 * float(np.abs(c2w[:3, 3]).max() + 9.0))
