@@ -44,6 +44,9 @@
 #ifndef QED_K7_FETCH
 #define QED_K7_FETCH 2
 #endif
+#ifndef QED_K6_FETCH
+#define QED_K6_FETCH 0
+#endif
 
 namespace qed {
 
@@ -235,6 +238,107 @@ __device__ __forceinline__ void fwd_quadrant(f2 pq, f2 XY, f2 R0, f2 R1, float l
     s.cur = sel(m_acc, idx_v, s.cur);
 }
 
+// ---- the walk over one staged batch's surviving Gaussians (forward) -------------------------------------------------
+struct FwdRec { float4 q0, q1, q2; };                   // {x, y, k a, k b | k b, k c, r, g | b, depth, opacity or its log2, -}
+
+__device__ __forceinline__ void fwd_fetch(FwdRec& r, const float (*s_rec)[kRecFloats], int tt) {
+    // broadcast Gaussian tt: every lane reads the same LDS record
+    r.q0 = *reinterpret_cast<const float4*>(&s_rec[tt][0]);
+    r.q1 = *reinterpret_cast<const float4*>(&s_rec[tt][4]);
+    r.q2 = *reinterpret_cast<const float4*>(&s_rec[tt][8]);
+}
+
+// composite Gaussian t (record r): the quadrants whose mask holds it, in turn.  A quadrant that finishes is dropped from
+// the masks, which can take later Gaussians out of km.
+template <int CH, int NQ, bool MIXED>
+__device__ __forceinline__ void fwd_gaussian(const FwdRec& r, int t, u64 bit, u64& km, u64 (&mq)[NQ], const f2 (&pq)[NQ],
+                                             FwdPixel (&px)[NQ], u64 (&done)[NQ], int batch_start, u64 m_slow, int& n_vis) {
+    const f2 XY = {r.q0.x, r.q0.y}, R0 = {r.q0.z, r.q0.w}, R1 = {r.q1.x, r.q1.y}, col01 = {r.q1.z, r.q1.w};
+    const f2 col23 = {r.q2.x, CH == 4 ? r.q2.y : 0.f};
+    QED_STAT(4, 1);
+    int idx_v;                                          // one VGPR copy per Gaussian, not per quadrant
+    asm volatile("v_mov_b32 %0, %1" : "=v"(idx_v) : "s"(batch_start + t));
+    const unsigned slow = MIXED ? __builtin_amdgcn_readfirstlane((unsigned)(m_slow >> t) & 1u) : 0u;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (!(mq[q] & bit)) continue;                   // wave-uniform: this quadrant cannot see Gaussian t
+        QED_STAT(3, 1);
+        asm volatile("s_add_u32 %0, %0, 1" : "+s"(n_vis));              // (a scalar counter: as `++n_vis` it took a VGPR and spilled)
+        fwd_quadrant<CH, MIXED>(pq[q], XY, R0, R1, r.q2.z, col01, col23, idx_v, slow, done[q], px[q]);
+        if (done[q] == ~0ull) {                         // quadrant finished: drop it from the masks
+            mq[q] = 0;
+            u64 m = 0;
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) m |= mq[k];
+            km &= m;
+        }
+    }
+}
+
+// QED_K6_FETCH 0: the record is read when its Gaussian's turn comes (the other resident waves hide the LDS latency).
+// 2: one Gaussian ahead into a second register set, the walk unrolled by two (a prefetched record that a finishing
+// quadrant made unnecessary is simply read over).
+template <int CH, int NQ, bool MIXED>
+__device__ __forceinline__ void fwd_walk(u64& km, u64 (&mq)[NQ], const f2 (&pq)[NQ], FwdPixel (&px)[NQ], u64 (&done)[NQ],
+                                         int batch_start, u64 m_slow, int& n_vis, const float (*s_rec)[kRecFloats]) {
+#if QED_K6_FETCH == 2
+    if (!km) return;
+    FwdRec ra, rb;
+    int tn = __builtin_ctzll(km);
+    fwd_fetch(ra, s_rec, tn);
+    while (true) {
+        {
+            const int t = tn;
+            const u64 bit = 1ull << t;
+            km &= ~bit;
+            int tp = -1;
+            if (km) { tp = __builtin_ctzll(km); fwd_fetch(rb, s_rec, tp); }
+            fwd_gaussian<CH, NQ, MIXED>(ra, t, bit, km, mq, pq, px, done, batch_start, m_slow, n_vis);
+            if (!km) break;
+            tn = __builtin_ctzll(km);
+            if (tn != tp) fwd_fetch(rb, s_rec, tn);
+        }
+        {
+            const int t = tn;
+            const u64 bit = 1ull << t;
+            km &= ~bit;
+            int tp = -1;
+            if (km) { tp = __builtin_ctzll(km); fwd_fetch(ra, s_rec, tp); }
+            fwd_gaussian<CH, NQ, MIXED>(rb, t, bit, km, mq, pq, px, done, batch_start, m_slow, n_vis);
+            if (!km) break;
+            tn = __builtin_ctzll(km);
+            if (tn != tp) fwd_fetch(ra, s_rec, tn);
+        }
+    }
+#else
+    while (km) {
+        const int t = __builtin_ctzll(km);
+        const u64 bit = 1ull << t;
+        km &= ~bit;
+        FwdRec r;
+        fwd_fetch(r, s_rec, t);
+        fwd_gaussian<CH, NQ, MIXED>(r, t, bit, km, mq, pq, px, done, batch_start, m_slow, n_vis);
+    }
+#endif
+}
+
+template <int NQ>
+struct FwdWalkState { u64 km; int n_vis; u64 mq[NQ], done[NQ]; FwdPixel px[NQ]; f2 pq[NQ]; };
+
+template <int CH, int NQ>
+__device__ __attribute__((noinline)) void fwd_walk_mixed(FwdWalkState<NQ>* st, int batch_start, u64 m_slow,
+                                                         const float (*s_rec)[kRecFloats]) {
+    FwdWalkState<NQ> w = *st;
+    // (arguments and loaded values arrive in vector registers: the wave-uniform ones back into scalar registers)
+    w.km = uniform_u64(w.km);
+    w.n_vis = __builtin_amdgcn_readfirstlane(w.n_vis);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { w.mq[q] = uniform_u64(w.mq[q]); w.done[q] = uniform_u64(w.done[q]); }
+    fwd_walk<CH, NQ, true>(w.km, w.mq, w.pq, w.px, w.done, __builtin_amdgcn_readfirstlane(batch_start), uniform_u64(m_slow),
+                           w.n_vis, s_rec);
+    *st = w;
+}
+
 // ================================================================================================
 // forward
 // ================================================================================================
@@ -329,47 +433,31 @@ __device__ __forceinline__ void fwd_tile(int tile, int qf, float (*s_rec)[kRecFl
         const float4 n0 = splats[3 * g_n], n1 = splats[3 * g_n + 1], n2 = splats[3 * g_n + 2];
         const int rid_nn = id_at(start + (b + 2) * kBatch + lane);
         const int batch_start = start + b * kBatch;
-        // composite Gaussian t (its scalars in XY .. col23): the quadrants whose mask holds it, in turn
-        // composite Gaussian t (its scalars in XY .. col23): the quadrants whose mask holds it, in turn.  Two copies of
-        // the walk: a batch whose Gaussians all take the fast form (every batch of an ordinary scene) runs without any
-        // per-visit test of the form.
-        // (A version that fetched the NEXT surviving record before compositing the current one -- two register sets,
-        // loop unrolled by two -- measured slower, 154 vs 150 us at 5 waves per SIMD and 146 vs 141 us at 6: the
-        // extra scalar bookkeeping costs more than the LDS latency the other resident waves already hide.)
-        auto walk = [&](auto mixed) {
-            constexpr bool MIXED = decltype(mixed)::value;
-            while (km) {
-                const int t = __builtin_ctzll(km);
-                const u64 bit = 1ull << t;
-                km &= ~bit;
-                // broadcast Gaussian t: every lane reads the same LDS record
-                const float4 q0 = *reinterpret_cast<const float4*>(&s_rec[t][0]);
-                const float4 q1 = *reinterpret_cast<const float4*>(&s_rec[t][4]);
-                const float4 q2 = *reinterpret_cast<const float4*>(&s_rec[t][8]);
-                const f2 XY = {q0.x, q0.y}, R0 = {q0.z, q0.w}, R1 = {q1.x, q1.y}, col01 = {q1.z, q1.w};
-                const f2 col23 = {q2.x, CH == 4 ? q2.y : 0.f};
-                QED_STAT(4, 1);
-                int idx_v;                              // one VGPR copy per Gaussian, not per quadrant
-                asm volatile("v_mov_b32 %0, %1" : "=v"(idx_v) : "s"(batch_start + t));
-                const unsigned slow = MIXED ? __builtin_amdgcn_readfirstlane((unsigned)(m_slow >> t) & 1u) : 0u;
+        // the walk over the batch's survivors (fwd_walk): two copies -- a batch whose Gaussians all take the fast form
+        // (every batch of an ordinary scene) runs without any per-visit test of the form
+#if QED_K6_FORM == 3                        // (experiment: fast form only -- wrong for slow-form Gaussians)
+        fwd_walk<CH, NQ, false>(km, mq, pq, px, done, batch_start, m_slow, n_vis, s_rec);
+#elif QED_K6_FORM == 2
+        if (m_slow == 0) fwd_walk<CH, NQ, false>(km, mq, pq, px, done, batch_start, m_slow, n_vis, s_rec);
+        else fwd_walk<CH, NQ, true>(km, mq, pq, px, done, batch_start, m_slow, n_vis, s_rec);
+#elif QED_K6_FORM == 4
+        if (__builtin_expect(m_slow == 0, 1)) {
+            fwd_walk<CH, NQ, false>(km, mq, pq, px, done, batch_start, m_slow, n_vis, s_rec);
+        } else {
+            // a batch with a slow-form Gaussian (rare): the walk that tests the form per Gaussian is an OUT-OF-LINE function
+            // on a COPY of the state -- inlined beside the fast walk it cost the hot path registers (scratch spills), and
+            // handing it the state itself would pin that state in memory for the whole kernel
+            FwdWalkState<NQ> st;
+            st.km = km; st.n_vis = n_vis;
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    if (!(mq[q] & bit)) continue;       // wave-uniform: this quadrant cannot see Gaussian t
-                    QED_STAT(3, 1);
-                    asm volatile("s_add_u32 %0, %0, 1" : "+s"(n_vis));  // (a scalar counter: as `++n_vis` it took a VGPR and spilled)
-                    fwd_quadrant<CH, MIXED>(pq[q], XY, R0, R1, q2.z, col01, col23, idx_v, slow, done[q], px[q]);
-                    if (done[q] == ~0ull) {             // quadrant finished: drop it from the masks
-                        mq[q] = 0;
-                        km &= or_masks(mq);
-                    }
-                }
-            }
-        };
-#if QED_K6_FORM == 2
-        if (m_slow == 0) walk(std::false_type{});
-        else walk(std::true_type{});
+            for (int q = 0; q < NQ; ++q) { st.mq[q] = mq[q]; st.done[q] = done[q]; st.px[q] = px[q]; st.pq[q] = pq[q]; }
+            fwd_walk_mixed<CH, NQ>(&st, batch_start, m_slow, s_rec);
+            km = uniform_u64(st.km); n_vis = __builtin_amdgcn_readfirstlane(st.n_vis);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { mq[q] = uniform_u64(st.mq[q]); done[q] = uniform_u64(st.done[q]); px[q] = st.px[q]; }
+        }
 #else
-        walk(std::true_type{});
+        fwd_walk<CH, NQ, true>(km, mq, pq, px, done, batch_start, m_slow, n_vis, s_rec);
 #endif
         all_done = and_done() == ~0ull;                 // (a finished quadrant empties its mask, so km ran out by itself)
         r0 = n0; r1 = n1; r2 = n2;                      // rotate the pipeline (the wave waits HERE, not above)
@@ -561,12 +649,11 @@ __device__ __forceinline__ void bwd_quadrant(f2 pq, f2 XY, f2 R0, f2 R1, float l
     if (!MIXED || __builtin_expect(slow == 0, 1)) vs = -a_eff * v_a;
     else vs = sel(m_vs, -opv * v_a, 0.f);
     const f2 vv = {vs, vs};
-    const f2 v = w * vv;                                // k (M d) v_sigma = k x the gradient of the mean (1 / k at the flush)
     const f2 sv = d * vv;                               // (v_sigma dx, v_sigma dy)
-    g.vxy += v;
-    // |.| as a source modifier of a plain add (the compiler's and + and + packed add is one instruction more)
-    asm("v_add_f32_e64 %0, %0, |%1|" : "+v"(g.ax) : "v"(v.x));
-    asm("v_add_f32_e64 %0, %0, |%1|" : "+v"(g.ay) : "v"(v.y));
+    g.vxy += w * vv;                                    // k (M d) v_sigma = k x the gradient of the mean (1 / k at the flush)
+    // its absolute value without forming it: |w v_sigma| = |w| |v_sigma| bit for bit, as source modifiers of an fma
+    asm("v_fma_f32 %0, |%1|, |%2|, %0" : "+v"(g.ax) : "v"(w.x), "v"(vs));
+    asm("v_fma_f32 %0, |%1|, |%2|, %0" : "+v"(g.ay) : "v"(w.y), "v"(vs));
     g.c01 += d * (f2){sv.x, sv.x};                      // (sx dx, sx dy)
     g.c2 = __builtin_fmaf(sv.y, d.y, g.c2);
     g.s0 += vs;
@@ -747,6 +834,24 @@ __device__ __forceinline__ void bwd_walk(u64 km, const u64 (&mq)[NQ], const f2 (
         bwd_gaussian<CH, NQ, MIXED>(ra, t, bit, km, mq, pq, px, batch_hi, m_slow, park, park_lane, s_part, s_rec, vsplat, lane);
     }
 #endif
+}
+
+template <int NQ>
+struct BwdWalkState { ParkState park; u64 mq[NQ]; BwdPixel px[NQ]; f2 pq[NQ]; };
+
+template <int CH, int NQ>
+__device__ __attribute__((noinline)) void bwd_walk_mixed(BwdWalkState<NQ>* st, u64 km, int batch_hi, u64 m_slow, float* park_lane,
+                                                         const float* s_part, const float (*s_rec)[kRecFloats], float* vsplat,
+                                                         int lane) {
+    BwdWalkState<NQ> w = *st;
+    // (arguments and loaded values arrive in vector registers: the wave-uniform ones back into scalar registers)
+    w.park.n = __builtin_amdgcn_readfirstlane(w.park.n); w.park.t0 = __builtin_amdgcn_readfirstlane(w.park.t0);
+    w.park.t1 = __builtin_amdgcn_readfirstlane(w.park.t1); w.park.t2 = __builtin_amdgcn_readfirstlane(w.park.t2);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) w.mq[q] = uniform_u64(w.mq[q]);
+    bwd_walk<CH, NQ, true>(uniform_u64(km), w.mq, w.pq, w.px, __builtin_amdgcn_readfirstlane(batch_hi), uniform_u64(m_slow),
+                           w.park, park_lane, s_part, s_rec, vsplat, lane);
+    *st = w;
 }
 
 // vsplat row layout (QED_VSPLAT_FLOATS = 16):
@@ -940,6 +1045,20 @@ __device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_rec)[kRecFl
 #elif QED_K7_FORM == 2
         if (m_slow == 0) bwd_walk<CH, NQ, false>(km, mq, pq, px, batch_hi, m_slow, park, park_lane, s_part, s_rec, vsplat, lane);
         else bwd_walk<CH, NQ, true>(km, mq, pq, px, batch_hi, m_slow, park, park_lane, s_part, s_rec, vsplat, lane);
+#elif QED_K7_FORM == 4
+        if (__builtin_expect(m_slow == 0, 1)) {
+            bwd_walk<CH, NQ, false>(km, mq, pq, px, batch_hi, m_slow, park, park_lane, s_part, s_rec, vsplat, lane);
+        } else {                                         // (out of line on a copy of the state: see fwd_tile)
+            BwdWalkState<NQ> st;
+            st.park = park;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { st.mq[q] = mq[q]; st.px[q] = px[q]; st.pq[q] = pq[q]; }
+            bwd_walk_mixed<CH, NQ>(&st, km, batch_hi, m_slow, park_lane, s_part, s_rec, vsplat, lane);
+            park.n = __builtin_amdgcn_readfirstlane(st.park.n); park.t0 = __builtin_amdgcn_readfirstlane(st.park.t0);
+            park.t1 = __builtin_amdgcn_readfirstlane(st.park.t1); park.t2 = __builtin_amdgcn_readfirstlane(st.park.t2);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) px[q] = st.px[q];
+        }
 #else
         bwd_walk<CH, NQ, true>(km, mq, pq, px, batch_hi, m_slow, park, park_lane, s_part, s_rec, vsplat, lane);
 #endif
@@ -977,6 +1096,9 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
             bwd_tile<CH, 1>(tile_order[b >> 2], (b & 3) | keep_all, s_rec, s_part, C, splats, flatten_ids, offsets,
                             width, height, tile_w, tile_h, backgrounds, render_alpha, t_final, last_ids, v_render, v_alpha, vsplat, post);
         } else {
+            // (Dealing the CHEAPEST tiles -- handed out last -- as quadrant waves too, to fill the ragged end of a launch of
+            // ~2 whole tiles per wave slot, was measured: 261 us without, 268 / 287 / 306 with 10 / 20 / 30 % of the tiles;
+            // a quadrant wave stages and culls the tile's whole list again)
             const int i = b - 3 * n_split;
             if (i >= n_total) return;                    // (the grid is sized for the largest n_split the host allows)
             bwd_tile<CH, 4>(tile_order[i], keep_all, s_rec, s_part, C, splats, flatten_ids, offsets, width, height,

@@ -501,6 +501,16 @@ def write_sh_grads(means: Tensor, viewmat: Tensor, sh_degree: int, v_color: Tens
             L.ptr(v_color), 3, L.ptr(v_rest), v_rest.numel() // max(n, 1), _stream()), "qed_sh_grad_from_views")
 
 
+def _reference_key_order(metrics: Dict) -> Dict:
+    """The metrics dict in the order the reference fills it (model.py:160-194: the four rgb entries, gaussian_count, the
+    seven depth entries when the batch has a depth image, avg_min_scale) -- pinned by tests/golden/reference_kats.npz."""
+    order = ("rgb_mse", "rgb_psnr", "rgb_ssim", "rgb_lpips", "gaussian_count", "depth_abs_rel", "depth_sq_rel", "depth_rmse",
+             "depth_rmse_log", "depth_a1", "depth_a2", "depth_a3", "avg_min_scale")
+    out = {k: metrics[k] for k in order if k in metrics}
+    out.update({k: v for k, v in metrics.items() if k not in out})
+    return out
+
+
 def _counted_step(opt, device) -> None:
     """Tell the device's workspace that ``opt`` has counted a step behind the current frame (see _Workspace.counted_step)."""
     if device.type == "cuda":
@@ -1144,7 +1154,7 @@ class QEDSplatterModel(nn.Module):
                                            self.scales[..., -1], float(self.config.ssim_lambda), float(self.config.depth_lambda))
                 ctx.ssim = shared
                 out["gaussian_count"] = self.num_points
-                return out
+                return _reference_key_order(out)
             out = dict(_image_metrics(pred_rgb.detach(), gt_rgb, outputs["depth"].detach() if has_depth else None, gt_depth,
                                       keep_ssim_maps=keep))
             kept = out.pop("_ssim_shared", None)
@@ -1152,7 +1162,7 @@ class QEDSplatterModel(nn.Module):
                 ctx.ssim = kept
             out["gaussian_count"] = self.num_points
             out["avg_min_scale"] = nanmean_exp(self.scales[..., -1])                  # model.py:192-194
-        return out
+        return _reference_key_order(out)
 
     @property
     def intersection_overflows(self) -> int:

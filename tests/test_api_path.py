@@ -1096,7 +1096,7 @@ def test_reference_get_metrics_dict_kats_keys_values_and_writer_shape(cuda, trai
             assert as_floats[key] == pytest.approx(float(k[f"{tag}_{key}"]), rel=2e-5), (tag, key)
         # PSNR follows from the pinned MSE (data range 1)
         assert as_floats["rgb_psnr"] == pytest.approx(-10.0 * math.log10(float(k[f"{tag}_rgb_mse"])), rel=1e-5)
-        assert 0.0 < as_floats["rgb_ssim"] < 1.0 and math.isnan(as_floats["rgb_lpips"])
+        assert -1.0 <= as_floats["rgb_ssim"] <= 1.0 and math.isnan(as_floats["rgb_lpips"])    # (random images: SSIM ~ 0)
 
 
 @pytest.mark.parametrize("how", ["accumulate", "zero_in_place", "retain_graph"])
