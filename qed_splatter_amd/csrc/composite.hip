@@ -35,17 +35,14 @@
 
 #include "qed_common.h"
 
+// Development switches (A/B builds: python -m qed_splatter_amd.build --variant NAME -DQED_K7_FORM=1):
+//   QED_K6_FORM / QED_K7_FORM  1 = one walk that tests the per-pixel form per Gaussian,
+//                              2 = two copies of the walk, the test per BATCH (the product form)
 #ifndef QED_K6_FORM
 #define QED_K6_FORM 2
 #endif
 #ifndef QED_K7_FORM
 #define QED_K7_FORM 2
-#endif
-#ifndef QED_K7_FETCH
-#define QED_K7_FETCH 2
-#endif
-#ifndef QED_K6_FETCH
-#define QED_K6_FETCH 0
 #endif
 
 namespace qed {
@@ -65,31 +62,18 @@ constexpr float kLog2e = 1.4426950408889634f;
 constexpr int kRecFloats = 12;      // LDS record stride (floats): 10 used + the list id (backward) + 1 pad
 
 // Backward: how the 12 per-Gaussian gradient sums leave the wave.  Cross-lane instructions are the expensive ones
-// (v_permlane*_swap 8.4, DPP 4.3 issue cycles against 2.2-2.5 for a plain op), and a full in-wave reduction of 12 values
-// is 9 swaps + 9 adds + 12 DPP adds = ~150 cycles per (tile, Gaussian).  So only ONE halving level runs in the wave
-// (6 v_permlane16_swap + 6 adds: 32 partial sums per value); the partials of up to four Gaussians are parked in LDS
-// (stores are issued beside the vector pipe, not on it) and the flush -- one lane per (Gaussian, value) -- adds the 32
-// partials with plain adds before its atomic: ~87 cycles per Gaussian.
-#ifndef QED_K7_REDUCE
-#define QED_K7_REDUCE 1
-#endif
-#if QED_K7_REDUCE == 0
-// (round-4 form, kept for the A/B measurement: one halving level in the wave, 32 partials per value, three slots)
-constexpr int kParkSlots = 3;                // Gaussians parked per flush (16 lanes each)
-constexpr int kParkStride = 36;              // floats per (Gaussian, value): 32 partials + 4 pad, and
-constexpr int kParkSlot = 448;               // floats per parked Gaussian (12 values, padded to a multiple of 64): the
-                                             // 16-byte reads of the flush (lane groups {0-3,12-15,20-27}, ...) then hit
-                                             // 16 different 4-bank groups
-#else
-// NO halving level in the wave: every lane parks its own 12 sums (12 ds_write_b32, issued beside the vector pipe: the
-// six v_permlane16_swap + six adds per Gaussian were 18 issue quad-cycles of the pipe this kernel is bound by), and the
-// flush -- two lanes per (Gaussian, value) -- adds the 64 partials in a fixed order.
+// (v_permlane*_swap 8.4, DPP 4.3 issue cycles against 2.2-2.5 for a plain op: scripts/ubench/xlane_cycles.hip), so there
+// is NO reduction level in the wave: every lane parks its own 12 sums in LDS (stores are issued beside the vector pipe,
+// not on it; conflict-free: lane = bank) and the flush -- two lanes per (Gaussian, value) -- adds the 64 partials in a
+// fixed order, one DPP add joins the two halves, one lane issues the atomic.  (Rounds 2-4 ran one halving level in the
+// wave -- six v_permlane16_swap + six adds per Gaussian -- and parked 32 partials of up to three Gaussians; measured
+// against each other under the round-5 visit body the two forms tie (274.5 vs 276 us), this one without the 13 M
+// bank-conflict cycles per launch of the other: profiles/r05_k6_k7_variants.txt.)
 constexpr int kParkSlots = 2;                // Gaussians parked per flush: 24 rows, two lanes each
 constexpr int kParkStride = 68;              // floats per (Gaussian, value) row: 64 partials + 4 pad: the 16-byte reads of the
                                              // flush (row = lane >> 1, half = lane & 1; ds_read_b128 lane groups
                                              // {0-3,12-15,20-27}, ...) hit 16 different 4-bank slots: slot = row + 8 half + j mod 16
 constexpr int kParkSlot = 12 * kParkStride;  // floats per parked Gaussian
-#endif
 
 // Diagnostic build only (-DQED_COMPOSITE_STATS; scripts/composite_stats.py): how much work each stage of the
 // compositing kernels really does.  Wave-uniform counts, added by lane 0.
@@ -275,42 +259,13 @@ __device__ __forceinline__ void fwd_gaussian(const FwdRec& r, int t, u64 bit, u6
     }
 }
 
-// QED_K6_FETCH 0: the record is read when its Gaussian's turn comes (the other resident waves hide the LDS latency).
-// 2: one Gaussian ahead into a second register set, the walk unrolled by two (a prefetched record that a finishing
-// quadrant made unnecessary is simply read over).
+// The record is read when its Gaussian's turn comes: the other resident waves hide the LDS latency.  (Requested one
+// Gaussian ahead into a second register set, the walk unrolled by two, the kernel is SLOWER -- 136-152 us against 123-130
+// in round 5, 154 against 150 in round 3: the scalar bookkeeping of the look-ahead costs more than the latency it hides,
+// and 80 registers per lane at six waves per SIMD leave no room for it.  profiles/r05_k6_k7_variants.txt)
 template <int CH, int NQ, bool MIXED>
 __device__ __forceinline__ void fwd_walk(u64& km, u64 (&mq)[NQ], const f2 (&pq)[NQ], FwdPixel (&px)[NQ], u64 (&done)[NQ],
                                          int batch_start, u64 m_slow, int& n_vis, const float (*s_rec)[kRecFloats]) {
-#if QED_K6_FETCH == 2
-    if (!km) return;
-    FwdRec ra, rb;
-    int tn = __builtin_ctzll(km);
-    fwd_fetch(ra, s_rec, tn);
-    while (true) {
-        {
-            const int t = tn;
-            const u64 bit = 1ull << t;
-            km &= ~bit;
-            int tp = -1;
-            if (km) { tp = __builtin_ctzll(km); fwd_fetch(rb, s_rec, tp); }
-            fwd_gaussian<CH, NQ, MIXED>(ra, t, bit, km, mq, pq, px, done, batch_start, m_slow, n_vis);
-            if (!km) break;
-            tn = __builtin_ctzll(km);
-            if (tn != tp) fwd_fetch(rb, s_rec, tn);
-        }
-        {
-            const int t = tn;
-            const u64 bit = 1ull << t;
-            km &= ~bit;
-            int tp = -1;
-            if (km) { tp = __builtin_ctzll(km); fwd_fetch(ra, s_rec, tp); }
-            fwd_gaussian<CH, NQ, MIXED>(rb, t, bit, km, mq, pq, px, done, batch_start, m_slow, n_vis);
-            if (!km) break;
-            tn = __builtin_ctzll(km);
-            if (tn != tp) fwd_fetch(ra, s_rec, tn);
-        }
-    }
-#else
     while (km) {
         const int t = __builtin_ctzll(km);
         const u64 bit = 1ull << t;
@@ -319,24 +274,6 @@ __device__ __forceinline__ void fwd_walk(u64& km, u64 (&mq)[NQ], const f2 (&pq)[
         fwd_fetch(r, s_rec, t);
         fwd_gaussian<CH, NQ, MIXED>(r, t, bit, km, mq, pq, px, done, batch_start, m_slow, n_vis);
     }
-#endif
-}
-
-template <int NQ>
-struct FwdWalkState { u64 km; int n_vis; u64 mq[NQ], done[NQ]; FwdPixel px[NQ]; f2 pq[NQ]; };
-
-template <int CH, int NQ>
-__device__ __attribute__((noinline)) void fwd_walk_mixed(FwdWalkState<NQ>* st, int batch_start, u64 m_slow,
-                                                         const float (*s_rec)[kRecFloats]) {
-    FwdWalkState<NQ> w = *st;
-    // (arguments and loaded values arrive in vector registers: the wave-uniform ones back into scalar registers)
-    w.km = uniform_u64(w.km);
-    w.n_vis = __builtin_amdgcn_readfirstlane(w.n_vis);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) { w.mq[q] = uniform_u64(w.mq[q]); w.done[q] = uniform_u64(w.done[q]); }
-    fwd_walk<CH, NQ, true>(w.km, w.mq, w.pq, w.px, w.done, __builtin_amdgcn_readfirstlane(batch_start), uniform_u64(m_slow),
-                           w.n_vis, s_rec);
-    *st = w;
 }
 
 // ================================================================================================
@@ -415,11 +352,7 @@ __device__ __forceinline__ void fwd_tile(int tile, int qf, float (*s_rec)[kRecFl
         u64 km = or_masks(mq);
         QED_STAT(0, 1); QED_STAT(1, min(kBatch, end - (start + b * kBatch))); QED_STAT(2, __builtin_popcountll(km));
         // which per-pixel form this Gaussian takes (see fwd_quadrant); the record carries log2(opacity) for the fast one
-#if QED_K6_FORM == 0
-        const bool fast = false;
-#else
         const bool fast = gaussian_is_fast(r0.z, r0.w, r1.x, r1.y);
-#endif
         const u64 m_slow = uniform_u64(__ballot(!fast));
         if (km) {                                       // park this lane's (pre-scaled) Gaussian for the broadcast reads:
             const float bh = kConicScale * r0.w;        // {x, y, k a, k b | k b, k c, r, g | b, depth, opacity or its log2, -}
@@ -435,27 +368,9 @@ __device__ __forceinline__ void fwd_tile(int tile, int qf, float (*s_rec)[kRecFl
         const int batch_start = start + b * kBatch;
         // the walk over the batch's survivors (fwd_walk): two copies -- a batch whose Gaussians all take the fast form
         // (every batch of an ordinary scene) runs without any per-visit test of the form
-#if QED_K6_FORM == 3                        // (experiment: fast form only -- wrong for slow-form Gaussians)
-        fwd_walk<CH, NQ, false>(km, mq, pq, px, done, batch_start, m_slow, n_vis, s_rec);
-#elif QED_K6_FORM == 2
+#if QED_K6_FORM == 2
         if (m_slow == 0) fwd_walk<CH, NQ, false>(km, mq, pq, px, done, batch_start, m_slow, n_vis, s_rec);
         else fwd_walk<CH, NQ, true>(km, mq, pq, px, done, batch_start, m_slow, n_vis, s_rec);
-#elif QED_K6_FORM == 4
-        if (__builtin_expect(m_slow == 0, 1)) {
-            fwd_walk<CH, NQ, false>(km, mq, pq, px, done, batch_start, m_slow, n_vis, s_rec);
-        } else {
-            // a batch with a slow-form Gaussian (rare): the walk that tests the form per Gaussian is an OUT-OF-LINE function
-            // on a COPY of the state -- inlined beside the fast walk it cost the hot path registers (scratch spills), and
-            // handing it the state itself would pin that state in memory for the whole kernel
-            FwdWalkState<NQ> st;
-            st.km = km; st.n_vis = n_vis;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) { st.mq[q] = mq[q]; st.done[q] = done[q]; st.px[q] = px[q]; st.pq[q] = pq[q]; }
-            fwd_walk_mixed<CH, NQ>(&st, batch_start, m_slow, s_rec);
-            km = uniform_u64(st.km); n_vis = __builtin_amdgcn_readfirstlane(st.n_vis);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) { mq[q] = uniform_u64(st.mq[q]); done[q] = uniform_u64(st.done[q]); px[q] = st.px[q]; }
-        }
 #else
         fwd_walk<CH, NQ, true>(km, mq, pq, px, done, batch_start, m_slow, n_vis, s_rec);
 #endif
@@ -580,11 +495,6 @@ composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
 // ================================================================================================
 // backward
 // ================================================================================================
-__device__ __forceinline__ void swap16(float& a, float& b) {
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
-}
-
 // per-Gaussian gradient accumulators of one lane (summed over its four pixels)
 struct GradAcc {
     f2 vxy;        // 0, 1   v_x, v_y
@@ -672,31 +582,6 @@ __device__ __forceinline__ float flush_scale(int k, float v, float lo, bool slow
     return v;
 }
 
-#if QED_K7_REDUCE == 0
-__device__ __forceinline__ void flush_parked(int n_parked, int pt0, int pt1, int pt2, u64 m_slow,
-                                             const float* __restrict__ s_part, const float (*s_rec)[kRecFloats],
-                                             float* __restrict__ vsplat, int lane) {
-    QED_STAT(13, 1);
-    __syncthreads();                                    // single wave: orders the parking stores before these reads
-    const int grp = lane >> 4, k = lane & 15;
-    const int tg = grp == 0 ? pt0 : grp == 1 ? pt1 : pt2;
-    if (grp < n_parked && k < 12) {
-        const float4* src = reinterpret_cast<const float4*>(s_part + grp * kParkSlot + k * kParkStride);
-        const float4 a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3], a4 = src[4], a5 = src[5], a6 = src[6], a7 = src[7];
-        const int id = __float_as_int(s_rec[tg][11]);
-        const float lo = s_rec[tg][10];
-        const float4 b0 = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
-        const float4 b1 = make_float4(a2.x + a3.x, a2.y + a3.y, a2.z + a3.z, a2.w + a3.w);
-        const float4 b2 = make_float4(a4.x + a5.x, a4.y + a5.y, a4.z + a5.z, a4.w + a5.w);
-        const float4 b3 = make_float4(a6.x + a7.x, a6.y + a7.y, a6.z + a7.z, a6.w + a7.w);
-        const float4 c0 = make_float4(b0.x + b1.x, b0.y + b1.y, b0.z + b1.z, b0.w + b1.w);
-        const float4 c1 = make_float4(b2.x + b3.x, b2.y + b3.y, b2.z + b3.z, b2.w + b3.w);
-        float v = ((c0.x + c1.x) + (c0.y + c1.y)) + ((c0.z + c1.z) + (c0.w + c1.w));
-        v = flush_scale(k, v, lo, (m_slow >> tg) & 1);
-        if (v != 0.f) atomicAdd(&vsplat[(size_t)id * QED_VSPLAT_FLOATS + k], v);
-    }
-}
-#else
 __device__ __forceinline__ void flush_parked(int n_parked, int pt0, int pt1, int /*pt2*/, u64 m_slow,
                                              const float* __restrict__ s_part, const float (*s_rec)[kRecFloats],
                                              float* __restrict__ vsplat, int lane) {
@@ -726,7 +611,6 @@ __device__ __forceinline__ void flush_parked(int n_parked, int pt0, int pt1, int
         if (v != 0.f) atomicAdd(&vsplat[(size_t)id * QED_VSPLAT_FLOATS + k], v);
     }
 }
-#endif
 
 // ---- the walk over one staged batch's surviving Gaussians (plain functions, not lambdas: a closure that refers to another
 // closure kept every local they captured in scratch memory) -----------------------------------------------------------
@@ -760,26 +644,13 @@ __device__ __forceinline__ void bwd_gaussian(BwdRec& r, int t, u64 bit, u64 km, 
         QED_STAT(11, 1);
         bwd_quadrant<CH, MIXED>(pq[q], XY, R0, R1, lo, col01, col23, idx, slow, px[q], any_valid, g);
     }
-#if QED_K7_FETCH == 1
-    if (km) bwd_fetch(r, s_rec, __builtin_ctzll(km));
-#endif
     if (any_valid == 0) return;
     QED_STAT(12, 1);
     {
         float gv[12] = {g.vxy.x, g.vxy.y, g.ax, g.ay, g.c01.x, g.c01.y, g.c2, g.s0, g.rg.x, g.rg.y, g.bd.x, g.bd.y};
         float* dst = park_lane + park.n * kParkSlot;
-#if QED_K7_REDUCE == 0
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            // a = [a.r0, b.r0, a.r2, b.r2], b = [a.r1, b.r1, a.r3, b.r3]: a + b holds, per 16-lane row, the sum of a
-            // row pair of value 2 i (rows 0, 2) or 2 i + 1 (rows 1, 3)
-            swap16(gv[2 * i], gv[2 * i + 1]);
-            dst[i * 2 * kParkStride] = gv[2 * i] + gv[2 * i + 1];
-        }
-#else
 #pragma unroll
         for (int i = 0; i < 12; ++i) dst[i * kParkStride] = gv[i];
-#endif
     }
     // (selects, not an if-chain: the compiler turned the chain into an indexed store to the struct -- in scratch memory)
     park.t0 = park.n == 0 ? t : park.t0;
@@ -791,17 +662,17 @@ __device__ __forceinline__ void bwd_gaussian(BwdRec& r, int t, u64 bit, u64 km, 
     }
 }
 
-// QED_K7_FETCH 2: the record of a surviving Gaussian is requested one Gaussian AHEAD, into a second set of registers (the
-// walk is unrolled by two so that the sets alternate without copies): the LDS latency (~130 cycles) runs beside the
-// pixels of the current Gaussian.  1 (the round-4 form): requested behind the current one's pixels into the very
-// registers they were read from -- the latency ran beside the in-wave reduction, which is gone (kParkSlots).  0: on demand.
+// The record of a surviving Gaussian is requested one Gaussian AHEAD, into a second set of registers (the walk is
+// unrolled by two so that the sets alternate without copies): the LDS latency runs beside the pixels of the current
+// Gaussian.  (Rounds 3-4 requested it behind the current one's pixels into the very registers it was read from, where
+// the latency ran beside the in-wave reduction, which is gone.  On demand / behind / ahead measure alike within the
+// spread, 274-277 us: profiles/r05_k6_k7_variants.txt; this form keeps the fetch clear of compiler-inserted copies.)
 template <int CH, int NQ, bool MIXED>
 __device__ __forceinline__ void bwd_walk(u64 km, const u64 (&mq)[NQ], const f2 (&pq)[NQ], BwdPixel (&px)[NQ], int batch_hi,
                                          u64 m_slow, ParkState& park, float* park_lane, const float* __restrict__ s_part,
                                          const float (*s_rec)[kRecFloats], float* __restrict__ vsplat, int lane) {
     BwdRec ra, rb;
     ra.q0 = ra.q1 = ra.q2 = rb.q0 = rb.q1 = rb.q2 = make_float4(0.f, 0.f, 0.f, 0.f);
-#if QED_K7_FETCH == 2
     if (km) bwd_fetch(ra, s_rec, __builtin_ctzll(km));
     while (km) {
         {
@@ -820,38 +691,6 @@ __device__ __forceinline__ void bwd_walk(u64 km, const u64 (&mq)[NQ], const f2 (
             bwd_gaussian<CH, NQ, MIXED>(rb, t, bit, km, mq, pq, px, batch_hi, m_slow, park, park_lane, s_part, s_rec, vsplat, lane);
         }
     }
-#else
-#if QED_K7_FETCH == 1
-    if (km) bwd_fetch(ra, s_rec, __builtin_ctzll(km));
-#endif
-    while (km) {
-        const int t = __builtin_ctzll(km);
-        const u64 bit = 1ull << t;
-        km &= ~bit;
-#if QED_K7_FETCH == 0
-        bwd_fetch(ra, s_rec, t);
-#endif
-        bwd_gaussian<CH, NQ, MIXED>(ra, t, bit, km, mq, pq, px, batch_hi, m_slow, park, park_lane, s_part, s_rec, vsplat, lane);
-    }
-#endif
-}
-
-template <int NQ>
-struct BwdWalkState { ParkState park; u64 mq[NQ]; BwdPixel px[NQ]; f2 pq[NQ]; };
-
-template <int CH, int NQ>
-__device__ __attribute__((noinline)) void bwd_walk_mixed(BwdWalkState<NQ>* st, u64 km, int batch_hi, u64 m_slow, float* park_lane,
-                                                         const float* s_part, const float (*s_rec)[kRecFloats], float* vsplat,
-                                                         int lane) {
-    BwdWalkState<NQ> w = *st;
-    // (arguments and loaded values arrive in vector registers: the wave-uniform ones back into scalar registers)
-    w.park.n = __builtin_amdgcn_readfirstlane(w.park.n); w.park.t0 = __builtin_amdgcn_readfirstlane(w.park.t0);
-    w.park.t1 = __builtin_amdgcn_readfirstlane(w.park.t1); w.park.t2 = __builtin_amdgcn_readfirstlane(w.park.t2);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) w.mq[q] = uniform_u64(w.mq[q]);
-    bwd_walk<CH, NQ, true>(uniform_u64(km), w.mq, w.pq, w.px, __builtin_amdgcn_readfirstlane(batch_hi), uniform_u64(m_slow),
-                           w.park, park_lane, s_part, s_rec, vsplat, lane);
-    *st = w;
 }
 
 // vsplat row layout (QED_VSPLAT_FLOATS = 16):
@@ -1015,11 +854,7 @@ __device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_rec)[kRecFl
         QED_STAT(8, 1); QED_STAT(9, min(kBatch, batch_hi + 1 - start)); QED_STAT(10, __builtin_popcountll(km));
         QED_STAT(NQ == 4 ? 16 : 17, b == 0 ? 1 : 0);
         // the per-pixel form of this lane's Gaussian: the forward kernel's decision, from the same record (fwd_quadrant)
-#if QED_K7_FORM == 0
-        const bool fast = false;
-#else
         const bool fast = gaussian_is_fast(r0.z, r0.w, r1.x, r1.y);
-#endif
         const u64 m_slow = uniform_u64(__ballot(!fast));
         if (km) {                                       // park this lane's Gaussian, laid out as the loop's register pairs:
             const float bh = kConicScale * r0.w;        // {x, y, k a, k b | k b, k c, b, depth | r, g, opacity or its log2, id}
@@ -1032,33 +867,12 @@ __device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_rec)[kRecFl
         const float4 n0 = splats[3 * (size_t)rid_n], n1 = splats[3 * (size_t)rid_n + 1],
                      n2 = splats[3 * (size_t)rid_n + 2];
         const int rid_nn = id_at(batch_hi - 2 * kBatch - lane);
-#if QED_K7_REDUCE == 0
-        // this lane's slot in a parked Gaussian's partials: [value = 2 i + (row & 1)][half = row >> 1][lane & 15]
-        float* const park_lane = s_part + ((lane >> 4) & 1) * kParkStride + (lane >> 5) * 16 + (lane & 15);
-#else
         float* const park_lane = s_part + lane;         // [slot][value][lane]
-#endif
         // two copies of the walk, as in the forward kernel: a batch whose Gaussians all take the fast form carries no test
         ParkState park{0, 0, 0, 0};
-#if QED_K7_FORM == 3                        // (experiment: fast form only -- wrong for slow-form Gaussians)
-        bwd_walk<CH, NQ, false>(km, mq, pq, px, batch_hi, m_slow, park, park_lane, s_part, s_rec, vsplat, lane);
-#elif QED_K7_FORM == 2
+#if QED_K7_FORM == 2
         if (m_slow == 0) bwd_walk<CH, NQ, false>(km, mq, pq, px, batch_hi, m_slow, park, park_lane, s_part, s_rec, vsplat, lane);
         else bwd_walk<CH, NQ, true>(km, mq, pq, px, batch_hi, m_slow, park, park_lane, s_part, s_rec, vsplat, lane);
-#elif QED_K7_FORM == 4
-        if (__builtin_expect(m_slow == 0, 1)) {
-            bwd_walk<CH, NQ, false>(km, mq, pq, px, batch_hi, m_slow, park, park_lane, s_part, s_rec, vsplat, lane);
-        } else {                                         // (out of line on a copy of the state: see fwd_tile)
-            BwdWalkState<NQ> st;
-            st.park = park;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) { st.mq[q] = mq[q]; st.px[q] = px[q]; st.pq[q] = pq[q]; }
-            bwd_walk_mixed<CH, NQ>(&st, km, batch_hi, m_slow, park_lane, s_part, s_rec, vsplat, lane);
-            park.n = __builtin_amdgcn_readfirstlane(st.park.n); park.t0 = __builtin_amdgcn_readfirstlane(st.park.t0);
-            park.t1 = __builtin_amdgcn_readfirstlane(st.park.t1); park.t2 = __builtin_amdgcn_readfirstlane(st.park.t2);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) px[q] = st.px[q];
-        }
 #else
         bwd_walk<CH, NQ, true>(km, mq, pq, px, batch_hi, m_slow, park, park_lane, s_part, s_rec, vsplat, lane);
 #endif
