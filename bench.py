@@ -451,6 +451,9 @@ def main():
 
     dp_compact = not args.dp_plain and not args.plain_adam
     fused_sh = dp_compact
+    # N > 1: row capacity of the sparse colour-gradient message, agreed by all ranks after the first step (None: the dense
+    # message is no larger -- SURVEY 8d's scene is 95 % visible; QED_BENCH_DP_SPARSE=1 forces the sparse form for rehearsals)
+    sparse_cap = [None]
 
     def exchange_and_step(adam_sh, adam_leading, adam_all, in_graph=False):
         """N > 1.  Compact exchange: the all-gather of the colour gradients is issued first and the SH part of the
@@ -459,8 +462,15 @@ def main():
         if dp_compact:
             # in_graph: the message was assembled at the end of the forward+backward graph and the SH graph folds the
             # gathered overflow words itself (four eager launches less per step)
-            ex = exchange_grads_compact_begin(model, world, prepared=in_graph, fold=not in_graph)
-            ex.wait_views()
+            if sparse_cap[0] is not None:
+                # the sparse colour-gradient message (rows of the Gaussians this rank saw): packs and unpacks eagerly
+                ex = exchange_grads_compact_begin(model, world, sparse_cap=sparse_cap[0])
+                ex.wait_views()
+                if in_graph:
+                    P.fold_skip_words(model)        # (the SH graph's own fold then repeats it: idempotent)
+            else:
+                ex = exchange_grads_compact_begin(model, world, prepared=in_graph, fold=not in_graph)
+                ex.wait_views()
             adam_sh()
             ex.wait_geometry()
             adam_leading()
@@ -502,6 +512,12 @@ def main():
     M_ref = M if M_ref is None else M_ref
     n_vis = int((model.info["radii"] > 0).sum())
     log(f"scene ready: N={n} visible={n_vis} M={M}")
+    if multi and dp_compact:
+        sparse_cap[0] = P.sparse_message_capacity(model, world)          # (one MAX all-reduce; None: dense is no larger)
+        if sparse_cap[0] is None and os.environ.get("QED_BENCH_DP_SPARSE") == "1":
+            sparse_cap[0] = (n + 3) // 4 * 4
+        log("colour-gradient message: " + ("dense (3 N floats per rank)" if sparse_cap[0] is None else
+                                           f"sparse, {sparse_cap[0]} rows of {n} per rank"))
     restore()
     for _ in range(args.warmup):
         step(args.sync_m)
@@ -578,7 +594,13 @@ def main():
             adam_only()
             return losses
 
-        one_graph = [args.dp_one_graph or os.environ.get("QED_BENCH_DP_ONE_GRAPH", "0") in ("1", "2")]
+        # N > 1: ONE graph with the collectives captured is the default (0.987 against 1.028 ms in a group of one,
+        # profiles/r04_bench_rccl_self.json); QED_BENCH_DP_ONE_GRAPH=0 keeps the three graphs around eager collectives, =1
+        # issues the all-gather ahead of the projection backward (--dp-one-graph), =2 / unset behind the whole backward.
+        # Whatever is asked for, the three-graph form is what runs unless EVERY rank captured the one-graph form.
+        # (gloo rehearsals stage through the host: nothing to capture there)
+        one_graph_env = os.environ.get("QED_BENCH_DP_ONE_GRAPH", "1" if args.dp_one_graph else ("0" if rehearse else "2"))
+        one_graph = [one_graph_env in ("1", "2")]
 
         def capture_all():
             """(run, dispatch, graphs): every graph of the step captured afresh -- also after an intersection overflow, when
@@ -592,25 +614,36 @@ def main():
                     for p in model.parameters():
                         p.grad = None
                     losses = model.fused_loss(cam, batch, background=bg, sync=False, compact_sh_grad=True, optimizer=opt)
-                    if os.environ.get("QED_BENCH_DP_ONE_GRAPH") == "2":      # (comparison: the gather behind the whole backward)
-                        model.backward_fused(losses)
-                    else:
+                    if one_graph_env == "1":                 # the gather ahead of the projection backward
                         P.backward_with_early_gather(model, losses, world)
+                    else:
+                        model.backward_fused(losses)
                     ex = exchange_grads_compact_begin(model, world)
                     ex.wait_views()
                     adam_sh_part()
                     ex.wait_geometry()
                     adam_leading_part()
                     return losses
+                g1 = None
                 try:
                     g1 = GraphedTrainStep(dp_step, dev, warmup=3, check_every=0)
-                    return g1.replay, ("ONE hipGraph with the collectives inside: all-gather ahead of the projection backward, "
-                                       "SH groups behind it while the geometry all-reduce is on the links, leading groups"), [g1]
                 except Exception as e:
                     log(f"one-graph capture of the data-parallel step failed ({type(e).__name__}: {e}); three graphs instead")
                     torch.cuda.synchronize()
                     opt.drop_tick()
-                    one_graph[0] = False
+                # the ranks must run the SAME form (a rank replaying captured collectives against peers that issue eager
+                # ones in another order would hang): one graph only if every rank has it
+                agreed = torch.tensor([1 if g1 is not None else 0], device=dev, dtype=torch.int32)
+                dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+                if int(agreed):
+                    where = "ahead of the projection backward" if one_graph_env == "1" else "behind the backward pass"
+                    return g1.replay, (f"ONE hipGraph with the collectives inside: all-gather {where}, SH groups behind it "
+                                       "while the geometry all-reduce is on the links, leading groups"), [g1]
+                if g1 is not None:
+                    log("another rank could not capture the one-graph form; three graphs instead")
+                    del g1
+                    opt.drop_tick()
+                one_graph[0] = False
             if split:
                 g_fb = GraphedTrainStep(fwd_bwd_message if multi and dp_compact else fwd_bwd, dev, warmup=3, check_every=0)
                 g_fb.replay()                          # fills the captured (static) .grad buffers before Adam's

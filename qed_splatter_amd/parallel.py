@@ -216,6 +216,83 @@ def backward_with_early_gather(model, losses, world_size: int, group=None) -> No
     torch.autograd.backward([t for t, _ in keep], [gi for _, gi in keep])
 
 
+# ---- sparse colour-gradient message -------------------------------------------------------------------------------------
+# The colour gradient of a Gaussian that a rank's camera does not see (radii == 0) is zero, so a rank need only send the
+# rows it has: (index, 3 floats) per VISIBLE Gaussian = 16 B against 12 B per Gaussian of the dense message.  In SURVEY
+# 8d's synthetic scene 95 % are visible (the dense form is smaller); a camera of a real capture sees a fraction of the
+# scene, and xGMI links, not HBM, bound the exchange.  The message is capacity-bounded like the intersection list: ``cap``
+# rows (agreed by all ranks at set-up: sparse_message_capacity), a rank with more visible rows than that marks the step as
+# overflowed -- the word every rank's optimiser takes as skip_flag -- and the caller re-calibrates.  Row layout (floats):
+#   [0:16] view matrix | [16] overflow word (int32 bits) | [17] visible rows (int32 bits) | [18:20] pad |
+#   [20 : 20 + cap] indices (int32 bits) | [20 + cap : 20 + 4 cap] colour gradients
+# The receiver scatters the R lists into the dense [R, 3 N + 20] rows the optimiser pass reads (sh_views), header behind the
+# colours as in the dense message, so nothing downstream changes.  Plain torch ops without a host read: the same code runs
+# on CPU tensors in the gloo tests and on the GPU inside a captured graph.
+SPARSE_HEADER = 20
+
+
+def sparse_row_floats(cap: int) -> int:
+    return SPARSE_HEADER + 4 * int(cap)
+
+
+def sparse_message_capacity(model, world_size: int, group=None, headroom: float = 1.5, visible=None):
+    """Set-up time (one host read, one MAX all-reduce): the row capacity every rank will use, or None when the dense
+    message is no larger (capacity >= 3/4 N: 16 B per visible row against 12 B per Gaussian)."""
+    vis = _visible_rows(model, visible)
+    n = vis.numel()
+    count = vis.sum().to(torch.int64).reshape(1)
+    if not _single(world_size):
+        dist.all_reduce(count, op=dist.ReduceOp.MAX, group=group)
+    cap = min(n, max(4, (int(int(count) * headroom) + 3) // 4 * 4))          # (a multiple of 4: the row's parts stay 16-byte aligned)
+    return None if 4 * cap >= 3 * n else cap
+
+
+def _visible_rows(model, visible=None) -> torch.Tensor:
+    if visible is not None:
+        return visible.reshape(-1)
+    return (model.info["radii"][0] > 0).reshape(-1)
+
+
+def pack_sparse_message(v_color: torch.Tensor, visible: torch.Tensor, viewmat: torch.Tensor, overflow_word: torch.Tensor,
+                        cap: int, out: torch.Tensor) -> None:
+    """This rank's sparse row (layout above) into ``out`` [20 + 4 cap].  ``v_color`` [N,3] or [3 N]; ``visible`` [N] bool.
+    A rank with more than ``cap`` visible rows sends the first ``cap`` and raises its overflow word to the count it needed."""
+    n = visible.numel()
+    vis = visible.reshape(-1)
+    pos = torch.cumsum(vis.to(torch.int32), 0, dtype=torch.int32) - 1          # position of a visible row in the list
+    count = pos[-1:] + 1 if n > 0 else torch.zeros(1, dtype=torch.int32, device=out.device)
+    keep = vis & (pos < cap)
+    dst = torch.where(keep, pos, torch.full_like(pos, cap)).to(torch.int64)     # (slot `cap` takes what is not sent)
+    idx_buf = torch.zeros(cap + 1, dtype=torch.int32, device=out.device)
+    rgb_buf = torch.zeros(cap + 1, 3, dtype=torch.float32, device=out.device)
+    idx_buf.scatter_(0, dst, torch.arange(n, dtype=torch.int32, device=out.device))
+    rgb_buf.index_copy_(0, dst, v_color.reshape(n, 3).to(torch.float32)) if n > 0 else None
+    out[:16] = viewmat.reshape(-1).to(torch.float32)
+    over = torch.where(count > cap, count, torch.zeros_like(count))
+    out[16:17].view(torch.int32).copy_(torch.maximum(overflow_word.reshape(1).to(torch.int32), over))
+    out[17:18].view(torch.int32).copy_(count)
+    out[18:20] = 0.0
+    out[SPARSE_HEADER:SPARSE_HEADER + cap].view(torch.int32).copy_(idx_buf[:cap])
+    out[SPARSE_HEADER + cap:].copy_(rgb_buf[:cap].reshape(-1))
+
+
+def unpack_sparse_messages(rows: torch.Tensor, n: int, cap: int, dense: torch.Tensor) -> None:
+    """The gathered sparse rows [R, 20 + 4 cap] -> dense [R, 3 n + 20]: colour gradients scattered to their Gaussians (zero
+    elsewhere), then the 20 header floats (view matrix, overflow word, count) as in the dense message."""
+    R = rows.shape[0]
+    nv = 3 * n
+    dense[:, :nv] = 0.0
+    counts = rows[:, 17:18].view(torch.int32).clamp(max=cap)                                     # [R,1]
+    idx = rows[:, SPARSE_HEADER:SPARSE_HEADER + cap].view(torch.int32).to(torch.int64)           # [R,cap]
+    rgb = rows[:, SPARSE_HEADER + cap:].reshape(R, cap, 3)
+    live = torch.arange(cap, device=rows.device).reshape(1, cap) < counts                       # rows beyond the count: unset
+    body = torch.zeros(R, n + 1, 3, dtype=torch.float32, device=rows.device)                     # (slot n takes the dead rows)
+    dst = torch.where(live, idx, torch.full_like(idx, n))
+    body.scatter_(1, dst.unsqueeze(-1).expand(R, cap, 3), rgb)
+    dense[:, :nv] = body[:, :n].reshape(R, nv)
+    dense[:, nv:nv + SPARSE_HEADER] = rows[:, :SPARSE_HEADER]
+
+
 def _message_buffers(model, row: int, n_rows: int, device):
     bufs = getattr(model, "_dp_buffers", None)
     if bufs is None or bufs[0].numel() != row or bufs[1].shape != (n_rows, row) or bufs[0].device != device:
@@ -242,7 +319,7 @@ def fold_skip_words(model) -> None:
 
 
 def exchange_grads_compact_begin(model, world_size: int, group=None, prepared: bool = False,
-                                 fold: bool = True) -> CompactExchange:
+                                 fold: bool = True, sparse_cap=None, visible=None) -> CompactExchange:
     """``exchange_grads_compact(..., rebuild=False)`` with both collectives left in flight, the all-gather of the
     colour gradients FIRST: the SH part of the optimiser (88 us at 500 k Gaussians, two thirds of the Adam pass) needs
     only that message and runs while the geometry all-reduce is still on the links:
@@ -256,7 +333,14 @@ def exchange_grads_compact_begin(model, world_size: int, group=None, prepared: b
 
     ``prepared``: the message is in the send buffer already (prepare_compact_message, e.g. captured behind the backward
     pass).  ``fold=False``: the caller folds the gathered overflow words itself (fold_skip_words) after wait_views() and
-    before the optimiser launches -- in a captured optimiser graph that is a graph node instead of an eager launch."""
+    before the optimiser launches -- in a captured optimiser graph that is a graph node instead of an eager launch.
+
+    ``sparse_cap`` (from sparse_message_capacity, the same on every rank): the all-gather carries only the rows of the
+    Gaussians this rank's camera saw (index + colour gradient, at most ``sparse_cap`` of them); ``wait_views()`` scatters
+    the gathered lists into the dense rows the optimiser reads.  Same ``model.sh_views``, same update as the dense message
+    (a Gaussian a rank did not see has a zero colour gradient there either way)."""
+    if sparse_cap is not None:
+        return _exchange_sparse_begin(model, world_size, group, int(sparse_cap), visible, fold)
     g = model.flat_grad()
     if g is None:
         raise RuntimeError("no gradients to exchange: call backward() first")
@@ -285,6 +369,48 @@ def exchange_grads_compact_begin(model, world_size: int, group=None, prepared: b
     _dp_skip_word(model, g.device)              # (exists before anything captures an optimiser launch that reads it)
     return CompactExchange(w_gather, w_reduce, geo, 1.0 if nccl else 1.0 / n_views,
                            fold=(lambda: _fold_skip_words(model, recv, nv)) if fold else None)
+
+
+def _exchange_sparse_begin(model, world_size: int, group, cap: int, visible, fold: bool) -> CompactExchange:
+    g = model.flat_grad()
+    if g is None:
+        raise RuntimeError("no gradients to exchange: call backward() first")
+    if not getattr(model, "last_compact", False):
+        raise RuntimeError("exchange_grads_compact_begin needs gradients from fused_loss(..., compact_sh_grad=True)")
+    names, begin, N = model.group_names, model.group_begin, model.num_points
+    i_dc = names.index("features_dc")
+    geo, v_local = g[:begin[i_dc]], g[begin[i_dc]:begin[i_dc + 1]]
+    nv, row, srow = 3 * N, 3 * N + SPARSE_HEADER, sparse_row_floats(cap)
+    n_rows = max(world_size, 1)
+    _, dense = _message_buffers(model, row, n_rows, g.device)                 # what sh_views / fold_skip_words read
+    sb = getattr(model, "_dp_sparse_buffers", None)
+    if sb is None or sb[0].numel() != srow or sb[1].shape != (n_rows, srow) or sb[0].device != g.device:
+        sb = model._dp_sparse_buffers = (torch.zeros(srow, dtype=torch.float32, device=g.device),
+                                         torch.zeros(n_rows, srow, dtype=torch.float32, device=g.device))
+    send, recv = sb
+    pack_sparse_message(v_local, _visible_rows(model, visible), model.last_viewmat, _local_overflow_word(g.device), cap, send)
+    n_views = n_rows
+    model.sh_views = (n_views, dense[:, nv:], row, dense, row, 1.0 / n_views)
+    _dp_skip_word(model, g.device)
+    if _single(world_size):
+        recv[0].copy_(send)
+        unpack_sparse_messages(recv, N, cap, dense)
+        if fold:
+            _fold_skip_words(model, dense, nv)
+        return CompactExchange(None, None, geo, 1.0)
+    nccl = dist.get_backend(group) == "nccl"
+    if nccl:
+        w_gather = dist.all_gather_into_tensor(recv.view(-1), send, group=group, async_op=True)
+        w_reduce = dist.all_reduce(geo, op=dist.ReduceOp.AVG, group=group, async_op=True)
+    else:
+        w_gather = dist.all_gather(list(recv.unbind(0)), send, group=group, async_op=True)
+        w_reduce = dist.all_reduce(geo, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+    def after_gather():
+        unpack_sparse_messages(recv, N, cap, dense)
+        if fold:
+            _fold_skip_words(model, dense, nv)
+    return CompactExchange(w_gather, w_reduce, geo, 1.0 if nccl else 1.0 / n_views, fold=after_gather)
 
 
 def _fold_skip_words(model, recv: torch.Tensor, nv: int) -> None:

@@ -18,7 +18,7 @@ import torch.distributed as dist  # noqa: E402
 from qed_splatter_amd import _lib as L  # noqa: E402
 from qed_splatter_amd.model import FlatAdam, PinholeCameras, QEDSplatterModel, QEDSplatterModelConfig  # noqa: E402
 from qed_splatter_amd.parallel import (allreduce_and_step, allreduce_flat_grad, backward_with_early_gather,  # noqa: E402
-                                       exchange_grads_compact, exchange_grads_compact_begin)
+                                       exchange_grads_compact, exchange_grads_compact_begin, sparse_message_capacity)
 from qed_splatter_amd.scene import synthetic_scene  # noqa: E402
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -32,7 +32,7 @@ names = ("means", "scales", "quats", "opacities", "features_dc", "features_rest"
 K = sc["Ks"][0]
 cam = PinholeCameras(sc["camera_to_worlds"][rank:rank + 1].to(dev), float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), w, h)
 batch = {"image": sc["gt_rgb"].to(dev), "depth_image": sc["gt_depth"].to(dev)}
-models = [QEDSplatterModel(QEDSplatterModelConfig.synthetic(sh_degree_interval=1), **{k: sc[k].to(dev) for k in names}) for _ in range(6)]
+models = [QEDSplatterModel(QEDSplatterModelConfig.synthetic(sh_degree_interval=1), **{k: sc[k].to(dev) for k in names}) for _ in range(7)]
 opts = [FlatAdam(m, means_schedule=FlatAdam.MEANS_SCHEDULE) for m in models]
 for m in models:
     m.step = 30000
@@ -57,7 +57,11 @@ for step in range(4):
             exchange_grads_compact(m, world, rebuild=False)
             o.step(fused_sh=True)
         else:                                   # both collectives in flight, optimiser in two parts behind them
-            ex = exchange_grads_compact_begin(m, world)
+            # i == 6: the SPARSE colour-gradient message (only the rows this rank's camera saw; capacity agreed at set-up;
+            # forced below the dense break-even here: the synthetic scene is 95 % visible)
+            if i == 6 and step == 0:
+                sparse_cap = sparse_message_capacity(m, world) or (m.num_points + 3) // 4 * 4
+            ex = exchange_grads_compact_begin(m, world, sparse_cap=sparse_cap if i == 6 else None)
             ex.wait_views()
             o.step(fused_sh=True, part=1)
             ex.wait_geometry()
@@ -87,8 +91,14 @@ gathered6 = [torch.empty_like(models[5].flat_params) for _ in range(world)]
 dist.all_gather(gathered6, models[5].flat_params.detach())
 replicas5 = all(torch.equal(gathered6[0], t) for t in gathered6)
 print(f"rank {rank}: all-gather issued ahead of the projection backward == plain: {same5}; replicas identical: {replicas5}", flush=True)
-same = same and same2 and same3 and same4 and same5
-replicas = replicas and replicas4 and replicas5
+same6 = bool(((models[0].flat_params - models[6].flat_params).abs() <= 1e-5 + 1e-4 * models[0].flat_params.abs()).all())
+gathered7 = [torch.empty_like(models[6].flat_params) for _ in range(world)]
+dist.all_gather(gathered7, models[6].flat_params.detach())
+replicas6 = all(torch.equal(gathered7[0], t) for t in gathered7)
+print(f"rank {rank}: sparse colour-gradient message (capacity {sparse_cap} rows of {n}) == plain: {same6}; replicas identical: "
+      f"{replicas6}", flush=True)
+same = same and same2 and same3 and same4 and same5 and same6
+replicas = replicas and replicas4 and replicas5 and replicas6
 
 # ---- one rank's frame overflows its intersection buffer: EVERY rank must skip that step ----------------
 # Per-rank cameras make the list length rank dependent, so an overflow need not hit all ranks in the same step; the rank

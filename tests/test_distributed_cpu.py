@@ -112,6 +112,41 @@ def _worker(rank, world, port, q):
                 ok = ok and int(recv[r, nv + 16:nv + 17].view(torch.int32)) == (77 if r == world - 1 else 0)
         for other in results[1:]:
             ok = ok and torch.equal(results[0][0][:b[4]], other[0][:b[4]]) and torch.equal(results[0][1], other[1])
+        # the SPARSE colour-gradient message (only the rows of the Gaussians a rank's camera saw: index + 3 floats) leaves the
+        # optimiser exactly what the dense message leaves it -- also when a rank saw NOTHING (rank 0 here), and the capacity
+        # all ranks agree on covers the rank that saw the most
+        P._CPU_OVERFLOW_WORD[0] = 0
+        n_pts = m.num_points
+        gsel = torch.Generator().manual_seed(100 + rank)
+        visible = torch.zeros(n_pts, dtype=torch.bool) if rank == 0 else torch.rand(n_pts, generator=gsel) < 0.4
+        views = {}
+        for form in ("dense", "sparse", "sparse-overflow"):
+            m3 = QEDSplatterModel(None, **{k: sc[k] for k in PARAM_NAMES})
+            flat3 = (torch.arange(total, dtype=torch.float32) + 1.0) * (rank + 1)
+            flat3[b[4]:b[5]] = flat3[b[4]:b[5]] * visible.repeat_interleave(3)          # unseen Gaussians: zero colour gradient
+            off = 0
+            for name in m3.group_names:
+                p = m3.gauss_params[name]
+                p.grad = flat3[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+            m3.last_compact = True
+            m3.last_viewmat = torch.eye(4).reshape(1, 4, 4) * (rank + 2)
+            if form == "dense":
+                ex = exchange_grads_compact_begin(m3, world)
+            else:
+                cap = P.sparse_message_capacity(m3, world, visible=visible, headroom=1.25)
+                ok = ok and cap == 28                                  # 20 rows on rank 1, none on rank 0: 1.25 x 20 -> 28
+                if form == "sparse-overflow":
+                    cap = 4                                            # fewer rows than the other rank has: it must say so
+                ex = exchange_grads_compact_begin(m3, world, sparse_cap=cap, visible=visible)
+            ex.wait_views()
+            ex.wait_geometry()
+            views[form] = (m3.sh_views[3].clone(), m3.flat_grad().clone(), int(m3._dp_skip))
+        d, sp, so = views["dense"], views["sparse"], views["sparse-overflow"]
+        ok = ok and torch.equal(d[0][:, :nv + 17], sp[0][:, :nv + 17]) and torch.equal(d[1][:b[4]], sp[1][:b[4]])
+        ok = ok and d[2] == 0 and sp[2] == 0
+        ok = ok and float(sp[0][0, :nv].abs().max()) == 0.0 and float(sp[0][1, :nv].abs().max()) > 0.0   # rank 0 saw nothing
+        ok = ok and so[2] > 4                                           # the overflowing rank's count: every rank skips the step
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

@@ -67,7 +67,7 @@ def test_bench_exchange_path_through_rccl_in_a_group_of_one(cuda):
 
 @pytest.mark.gpu
 def test_two_rank_exchanges_agree_and_an_overflow_on_one_rank_skips_the_step_on_all(cuda):
-    """scripts/dp_rehearsal.py on two gloo ranks that share cuda:0: the four exchange forms leave the parameters the plain
+    """scripts/dp_rehearsal.py on two gloo ranks that share cuda:0: the exchange forms (chunked, compact, views into the optimiser, overlapped, early gather, sparse message) leave the parameters the plain
     all-reduce + step leaves, replicas stay bit-identical -- also through a step in which ONE rank's frame overflows its
     intersection buffer: that rank renders an empty frame and every rank skips the update (the overflow word travels with
     the exchange; parallel.py), then all train on."""
@@ -84,6 +84,8 @@ def test_two_rank_exchanges_agree_and_an_overflow_on_one_rank_skips_the_step_on_
     p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-3000:])
     assert p.stdout.count("step skipped on this rank: True") == 4, p.stdout[-3000:]       # two ranks x two exchange forms
+    # the sparse colour-gradient message (rows of the Gaussians a rank saw) trains like the dense one, on both ranks
+    assert p.stdout.count("sparse colour-gradient message") == 2 and "== plain: False" not in p.stdout, p.stdout[-3000:]
 
 
 def test_launcher_enforces_its_wall_limit_and_reaps_its_children(tmp_path):
