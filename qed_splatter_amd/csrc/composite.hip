@@ -456,8 +456,11 @@ __device__ __forceinline__ void small_wave(int r, int n_small, int& t, int& q) {
 // every later tile by FOUR waves, one per quadrant.  Workgroups are dispatched in index order, so the
 // quarter-size work items arrive last and fill the end of the launch, where whole-tile waves would leave most
 // wave slots idle (measured: 2.7 of 5 resident waves per SIMD on average with whole tiles only).
+// (six waves per SIMD leave the forward kernel 80 registers per lane: with two copies of the walk it spilled 92 bytes per
+// lane per batch -- +38 MB written and +40 MB fetched per launch, profiles/r05_hbm_traffic_pmc.json; five waves = 96
+// registers, no scratch, and the same time within the spread: 127.9 vs 130.4 us, profiles/r05_k6_k7_variants.txt)
 #ifndef QED_K6_WAVES
-#define QED_K6_WAVES 6
+#define QED_K6_WAVES 5
 #endif
 #ifndef QED_K7_WAVES
 #define QED_K7_WAVES 4
@@ -1136,6 +1139,28 @@ extern "C" int qed_composite_fwd(int32_t C, int32_t N, const float* splats, cons
     return check_launch("qed_composite_fwd");
 }
 
+// at most an eighth of the tiles are split (the grid must be fixed before the count is known)
+static int max_split_tiles(long long grid) { return (int)(grid / 8); }
+
+static void launch_tile_order(const int32_t* tile_cost, long long grid, int32_t* order_ws, hipStream_t st) {
+    int dev = 0, n_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+        n_cu = 256;
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, tile_cost, (int)grid, order_ws, 1.0f,
+                       n_cu * 4 * QED_K7_WAVES, max_split_tiles(grid));
+}
+
+// The costliest-first order of qed_composite_bwd as a launch of its own: one workgroup, ~10 us, that depends on nothing but
+// qed_composite_fwd's tile_cost -- a caller with a second stream runs it beside the loss passes that sit between the two
+// compositing kernels and hands qed_composite_bwd the result (launch_flags | QED_CL_ORDER_READY).
+extern "C" int qed_tile_order(const int32_t* tile_cost, int64_t n_tiles, int32_t* order_ws, void* stream) {
+    QED_REQUIRE(tile_cost && order_ws && n_tiles > 0 && n_tiles < (1ll << 29), "bad arguments");
+    QED_REQUIRE(((uintptr_t)tile_cost & 15) == 0, "tile_cost must be 16-byte aligned");
+    launch_tile_order(tile_cost, n_tiles, order_ws, (hipStream_t)stream);
+    return check_launch("qed_tile_order");
+}
+
 extern "C" int qed_composite_bwd(int32_t C, int32_t N, const float* splats, const int32_t* flatten_ids,
                                  const int32_t* offsets, int32_t width, int32_t height, int32_t tile_w,
                                  int32_t tile_h, int32_t channels, const float* backgrounds,
@@ -1166,16 +1191,10 @@ extern "C" int qed_composite_bwd(int32_t C, int32_t N, const float* splats, cons
     const int* tile_order = nullptr;
     // a forced launch shape (test hook) keeps the plain tile order
     if (tile_cost != nullptr && (launch_flags & 3) == 0) {
-        int dev = 0, n_cu = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-            n_cu = 256;
-        // at most an eighth of the tiles are split (the grid must be fixed before the count is known)
-        const int max_split = (int)(grid / 8);
-        hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, tile_cost, (int)grid, order_ws, 1.0f,
-                           n_cu * 4 * QED_K7_WAVES, max_split);
+        // (QED_CL_ORDER_READY: the caller ran qed_tile_order itself -- on another stream, beside the loss passes)
+        if (!(launch_flags & QED_CL_ORDER_READY)) launch_tile_order(tile_cost, grid, order_ws, st);
         tile_order = order_ws;
-        blocks = (unsigned)(grid + 3ll * max_split);
+        blocks = (unsigned)(grid + 3ll * max_split_tiles(grid));
     }
     if (channels == 4)
         hipLaunchKernelGGL(composite_bwd_kernel<4>, dim3(blocks), dim3(64), 0, st, C, (const float4*)splats,

@@ -96,6 +96,10 @@ class QEDSplatterModelConfig:
     # place (_LazySHGradParameter); after QedAdam has consumed the compact form it is None (as after zero_grad()).  False:
     # always write the full gradients
     lazy_sh_grad: bool = True
+    # fused_loss(): the costliest-first tile order of the compositing backward (one workgroup, ~10 us, needs only the forward
+    # kernel's per-tile counts) is launched on a second stream, beside the loss / SSIM passes that sit between the two
+    # compositing kernels, instead of in front of the backward kernel.  Same order, same gradients
+    order_tiles_on_side_stream: bool = True
 
     @classmethod
     def synthetic(cls, **kw) -> "QEDSplatterModelConfig":
@@ -1256,13 +1260,19 @@ class QEDSplatterModel(nn.Module):
         tick = None
         if optimizer is not None and torch.is_grad_enabled() and cfg.ssim_lambda > 0.0:
             tick = optimizer.take_tick()
+        from . import rasterization as _R
         try:
-            render, alpha, self.info = rasterization(
-                means=self.means, quats=self.quats, scales=self.scales, opacities=self.opacities, colors=colors,
-                viewmats=viewmat, Ks=K, width=W, height=H, tile_size=16, packed=False, near_plane=0.01, far_plane=1e10,
-                render_mode="RGB+D", sh_degree=deg, sparse_grad=False, absgrad=True,
-                rasterize_mode=cfg.rasterize_mode, _flags=flags, _sh_rest=sh_rest, _sync=sync, _vsplat_holder=holder,
-                _c2w=cam_c2w)
+            # (the backward pass's tile order is launched beside the loss passes, on a second stream: rasterization.py)
+            side_before, _R.ORDER_ON_SIDE_STREAM = _R.ORDER_ON_SIDE_STREAM, cfg.order_tiles_on_side_stream
+            try:
+                render, alpha, self.info = rasterization(
+                    means=self.means, quats=self.quats, scales=self.scales, opacities=self.opacities, colors=colors,
+                    viewmats=viewmat, Ks=K, width=W, height=H, tile_size=16, packed=False, near_plane=0.01, far_plane=1e10,
+                    render_mode="RGB+D", sh_degree=deg, sparse_grad=False, absgrad=True,
+                    rasterize_mode=cfg.rasterize_mode, _flags=flags, _sh_rest=sh_rest, _sync=sync, _vsplat_holder=holder,
+                    _c2w=cam_c2w)
+            finally:
+                _R.ORDER_ON_SIDE_STREAM = side_before
             self.xys = self.info["means2d"]
             self.radii = self.info["radii"][0]
             self.last_viewmat, self.last_sh_degree = viewmat, deg
