@@ -259,7 +259,6 @@ typedef struct {
 #define QED_CL_QUADRANT_WAVES 2
 #define QED_CL_HALF_AND_HALF 3
 #define QED_CL_NO_CULL 4
-#define QED_CL_ORDER_READY 8   /* qed_composite_bwd: order_ws already holds qed_tile_order's result for this tile_cost */
 int qed_composite_fwd(int32_t C, int32_t N, const float* splats, const int32_t* flatten_ids,
                       const int32_t* offsets, int32_t width, int32_t height, int32_t tile_w,
                       int32_t tile_h, int32_t channels, const float* backgrounds, float* render,
@@ -277,12 +276,6 @@ int qed_composite_fwd(int32_t C, int32_t N, const float* splats, const int32_t* 
  * tiles are then handed out costliest first (greedy longest-processing-time scheduling of the launch; tiles heavier than
  * the average wave slot's whole share are dealt as four quadrant waves), ordered by one extra one-workgroup launch into
  * order_ws (C*tiles + 1 ints of scratch).  Same gradients up to the order of the float atomics. */
-/* The ordering launch of qed_composite_bwd on its own (one workgroup): order_ws [n_tiles + 1] from tile_cost [n_tiles][4].
- * It depends on qed_composite_fwd only, so a caller can run it on a second stream beside whatever sits between the two
- * compositing kernels (the loss passes) and pass QED_CL_ORDER_READY to qed_composite_bwd.  (Nothing in the reference: the
- * launch order is an implementation matter behind model.py:267-288's backward.) */
-int qed_tile_order(const int32_t* tile_cost, int64_t n_tiles, int32_t* order_ws, void* stream);
-
 int qed_composite_bwd(int32_t C, int32_t N, const float* splats, const int32_t* flatten_ids,
                       const int32_t* offsets, int32_t width, int32_t height, int32_t tile_w,
                       int32_t tile_h, int32_t channels, const float* backgrounds,

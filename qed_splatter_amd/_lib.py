@@ -39,7 +39,6 @@ SIGNATURES = {
     "qed_bin_tiles": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P]),
     "qed_composite_fwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "qed_composite_bwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
-    "qed_tile_order": (C.c_int, [_P, _L, _P, _P]),
     "qed_loss_reduce": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qed_loss_grad": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _I, _F, _F, _P]),
     "qed_sh_grad_from_views": (C.c_int, [_I, _I, _P, _P, _L, _P, _L, _I, _F, _P, _I, _P, _I, _P]),
@@ -106,7 +105,7 @@ VSPLAT_FLOATS = 16
 SH_JAC_FLOATS = 10            # QED_SH_JAC_FLOATS
 STATUS_WORDS = 4
 TILE = 16
-CL_TILE_WAVES, CL_QUADRANT_WAVES, CL_HALF_AND_HALF, CL_NO_CULL, CL_ORDER_READY = 1, 2, 3, 4, 8
+CL_TILE_WAVES, CL_QUADRANT_WAVES, CL_HALF_AND_HALF, CL_NO_CULL = 1, 2, 3, 4
 BIN_AUTO, BIN_TWO_STAGE, BIN_TILE_SORT = 0, 1, 2
 
 

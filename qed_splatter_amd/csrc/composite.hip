@@ -1151,16 +1151,6 @@ static void launch_tile_order(const int32_t* tile_cost, long long grid, int32_t*
                        n_cu * 4 * QED_K7_WAVES, max_split_tiles(grid));
 }
 
-// The costliest-first order of qed_composite_bwd as a launch of its own: one workgroup, ~10 us, that depends on nothing but
-// qed_composite_fwd's tile_cost -- a caller with a second stream runs it beside the loss passes that sit between the two
-// compositing kernels and hands qed_composite_bwd the result (launch_flags | QED_CL_ORDER_READY).
-extern "C" int qed_tile_order(const int32_t* tile_cost, int64_t n_tiles, int32_t* order_ws, void* stream) {
-    QED_REQUIRE(tile_cost && order_ws && n_tiles > 0 && n_tiles < (1ll << 29), "bad arguments");
-    QED_REQUIRE(((uintptr_t)tile_cost & 15) == 0, "tile_cost must be 16-byte aligned");
-    launch_tile_order(tile_cost, n_tiles, order_ws, (hipStream_t)stream);
-    return check_launch("qed_tile_order");
-}
-
 extern "C" int qed_composite_bwd(int32_t C, int32_t N, const float* splats, const int32_t* flatten_ids,
                                  const int32_t* offsets, int32_t width, int32_t height, int32_t tile_w,
                                  int32_t tile_h, int32_t channels, const float* backgrounds,
@@ -1191,8 +1181,10 @@ extern "C" int qed_composite_bwd(int32_t C, int32_t N, const float* splats, cons
     const int* tile_order = nullptr;
     // a forced launch shape (test hook) keeps the plain tile order
     if (tile_cost != nullptr && (launch_flags & 3) == 0) {
-        // (QED_CL_ORDER_READY: the caller ran qed_tile_order itself -- on another stream, beside the loss passes)
-        if (!(launch_flags & QED_CL_ORDER_READY)) launch_tile_order(tile_cost, grid, order_ws, st);
+        // (Launched by the caller on a SECOND stream, beside the loss passes that sit between the two compositing kernels, the
+        // ordering is off the critical path on paper; replayed from a hipGraph the fork / join cost more than its 10 us:
+        // 1.002 against 0.992 ms per step, profiles/r05_negative_results.txt)
+        launch_tile_order(tile_cost, grid, order_ws, st);
         tile_order = order_ws;
         blocks = (unsigned)(grid + 3ll * max_split_tiles(grid));
     }

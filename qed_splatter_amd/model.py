@@ -96,10 +96,6 @@ class QEDSplatterModelConfig:
     # place (_LazySHGradParameter); after QedAdam has consumed the compact form it is None (as after zero_grad()).  False:
     # always write the full gradients
     lazy_sh_grad: bool = True
-    # fused_loss(): the costliest-first tile order of the compositing backward (one workgroup, ~10 us, needs only the forward
-    # kernel's per-tile counts) is launched on a second stream, beside the loss / SSIM passes that sit between the two
-    # compositing kernels, instead of in front of the backward kernel.  Same order, same gradients
-    order_tiles_on_side_stream: bool = True
 
     @classmethod
     def synthetic(cls, **kw) -> "QEDSplatterModelConfig":
@@ -457,14 +453,14 @@ class _FusedImageLoss(torch.autograd.Function):
             # main = (1 - l) L1 + l (1 - SSIM): ONE launch forms the SSIM gradient w.r.t. the clamped colour and pushes
             # it, with the L1 part and the depth term, through the clamp / background composite (qed_loss_grad_ssim)
             n_out = 3.0 * (H - 10) * (W - 10)
-            maps = torch.empty(lib.qed_ssim_maps_floats(H, W), dtype=torch.float32, device=dev)
-            ssum = torch.empty(lib.qed_ssim_sum_floats(H, W), dtype=torch.float32, device=dev)
-            L.check(lib.qed_ssim_fwd(H, W, CH, L.ptr(render), L.ptr(alpha), L.ptr(background), L.ptr(gt_rgb),
-                                     L.ptr(mask), L.ptr(maps), L.ptr(ssum), st), "qed_ssim_fwd")
             # the same launch zeroes the accumulator the compositing backward will add into (no fill launch there)
             vsplat = None
             if vsplat_holder is not None and vsplat_rows > 0:
                 vsplat = torch.empty(vsplat_rows, L.VSPLAT_FLOATS, dtype=torch.float32, device=dev)
+            maps = torch.empty(lib.qed_ssim_maps_floats(H, W), dtype=torch.float32, device=dev)
+            ssum = torch.empty(lib.qed_ssim_sum_floats(H, W), dtype=torch.float32, device=dev)
+            L.check(lib.qed_ssim_fwd(H, W, CH, L.ptr(render), L.ptr(alpha), L.ptr(background), L.ptr(gt_rgb),
+                                     L.ptr(mask), L.ptr(maps), L.ptr(ssum), st), "qed_ssim_fwd")
             L.check(lib.qed_loss_grad_ssim(H, W, CH, L.ptr(render), L.ptr(alpha), L.ptr(background), L.ptr(gt_rgb),
                                            L.ptr(gt_depth), L.ptr(mask), L.ptr(maps), L.ptr(sums), 1.0 - ssim_lambda,
                                            depth_lambda, -ssim_lambda / n_out, L.ptr(v_render), L.ptr(v_alpha),
@@ -1260,19 +1256,13 @@ class QEDSplatterModel(nn.Module):
         tick = None
         if optimizer is not None and torch.is_grad_enabled() and cfg.ssim_lambda > 0.0:
             tick = optimizer.take_tick()
-        from . import rasterization as _R
         try:
-            # (the backward pass's tile order is launched beside the loss passes, on a second stream: rasterization.py)
-            side_before, _R.ORDER_ON_SIDE_STREAM = _R.ORDER_ON_SIDE_STREAM, cfg.order_tiles_on_side_stream
-            try:
-                render, alpha, self.info = rasterization(
-                    means=self.means, quats=self.quats, scales=self.scales, opacities=self.opacities, colors=colors,
-                    viewmats=viewmat, Ks=K, width=W, height=H, tile_size=16, packed=False, near_plane=0.01, far_plane=1e10,
-                    render_mode="RGB+D", sh_degree=deg, sparse_grad=False, absgrad=True,
-                    rasterize_mode=cfg.rasterize_mode, _flags=flags, _sh_rest=sh_rest, _sync=sync, _vsplat_holder=holder,
-                    _c2w=cam_c2w)
-            finally:
-                _R.ORDER_ON_SIDE_STREAM = side_before
+            render, alpha, self.info = rasterization(
+                means=self.means, quats=self.quats, scales=self.scales, opacities=self.opacities, colors=colors,
+                viewmats=viewmat, Ks=K, width=W, height=H, tile_size=16, packed=False, near_plane=0.01, far_plane=1e10,
+                render_mode="RGB+D", sh_degree=deg, sparse_grad=False, absgrad=True,
+                rasterize_mode=cfg.rasterize_mode, _flags=flags, _sh_rest=sh_rest, _sync=sync, _vsplat_holder=holder,
+                _c2w=cam_c2w)
             self.xys = self.info["means2d"]
             self.radii = self.info["radii"][0]
             self.last_viewmat, self.last_sh_degree = viewmat, deg

@@ -214,22 +214,6 @@ SH_HANDOVER = True
 # under the same parity checks; see tests/test_gpu_parity.py::test_dense_scene_gradients_against_the_fp32_band)
 KEEP_T_FINAL = True
 
-# The costliest-first tile order of the compositing backward needs nothing but the forward kernel's per-tile counts: with this
-# switch on (model.fused_loss sets it around its call), _Composite.forward launches it right behind qed_composite_fwd on a
-# SECOND stream, where the one-workgroup launch (~10 us) runs beside the loss / SSIM passes instead of in front of
-# qed_composite_bwd; the backward pass joins that stream.  Under a hipGraph capture fork and join become graph edges.
-ORDER_ON_SIDE_STREAM = False
-_SIDE_STREAMS: "Dict[int, torch.cuda.Stream]" = {}
-
-
-def _side_stream(dev) -> "torch.cuda.Stream":
-    idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    st = _SIDE_STREAMS.get(idx)
-    if st is None:
-        st = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=dev)
-    return st
-
-
 # Called by _ProjectSH.backward right before qed_project_bwd is launched, with (packed gradient rows [C*N,16], sh_jac planes,
 # C * N), when the backward pass writes compact SH gradients: the data-parallel exchange packs the colour-gradient message
 # from them and puts its all-gather on the links while the projection backward runs (parallel.early_gather)
@@ -588,16 +572,6 @@ class _Composite(torch.autograd.Function):
                                       L.ptr(last_ids), L.ptr(tile_cost), C_byref(post), L.composite_launch_flags(), _stream()),
                 "qed_composite_fwd")
         ctx.tile_cost = tile_cost
-        ctx.order_ready = None
-        if tile_cost is not None and ORDER_ON_SIDE_STREAM and L.composite_launch_flags() & 3 == 0:
-            order_ws = torch.empty(C * tile_w * tile_h + 1, dtype=torch.int32, device=dev)
-            cur, side = torch.cuda.current_stream(dev), _side_stream(dev)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                L.check(lib.qed_tile_order(L.ptr(tile_cost), C * tile_w * tile_h, L.ptr(order_ws), _stream()), "qed_tile_order")
-            tile_cost.record_stream(side)
-            order_ws.record_stream(side)
-            ctx.order_ready = (order_ws, side)
         ctx.save_for_backward(splats, flatten_ids, offsets, alpha, last_ids, bg, render if post is not None else None, pbg,
                               t_final)
         ctx.meta = (C, N, width, height, tile_w, tile_h, channels, absgrad)
@@ -647,16 +621,7 @@ class _Composite(torch.autograd.Function):
             vsplat = torch.zeros(C * N, R, dtype=torch.float32, device=dev)
         tile_cost = ctx.tile_cost
         flags = L.composite_launch_flags()
-        ready = getattr(ctx, "order_ready", None)
-        if ready is not None:
-            # the order was computed beside the loss passes (ORDER_ON_SIDE_STREAM): join that stream.  (Taken once: a second
-            # backward pass through a retained graph orders again, inline.)
-            order_ws, side = ready
-            ctx.order_ready = None
-            torch.cuda.current_stream(dev).wait_stream(side)
-            flags |= L.CL_ORDER_READY
-        else:
-            order_ws = torch.empty(C * tile_w * tile_h + 1, dtype=torch.int32, device=dev) if tile_cost is not None else None
+        order_ws = torch.empty(C * tile_w * tile_h + 1, dtype=torch.int32, device=dev) if tile_cost is not None else None
         L.check(lib.qed_composite_bwd(C, N, L.ptr(splats), L.ptr(flatten_ids), L.ptr(offsets), width, height, tile_w,
                                       tile_h, channels, L.ptr(bg), L.ptr(alpha), L.ptr(t_final), L.ptr(last_ids),
                                       L.ptr(v_render) if post is None else None, L.ptr(v_alpha) if post is None else None,

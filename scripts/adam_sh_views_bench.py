@@ -40,6 +40,7 @@ for n, sizes in ((500_000, (1, 2, 4, 8)), (2_000_000, (1, 4))):
             vm = torch.tensor([[math.cos(a), 0, -math.sin(a), 0], [0, -1, 0, 0], [math.sin(a), 0, -math.cos(a), 0], [0, 0, 0, 1.0]])
             recv[r, nv:nv + 16] = vm.reshape(-1).to(dev)
         model.last_compact = True
+        model.last_sh_degree = 3
         model.sh_views = (n_views, recv[:, nv:], row, recv, row, 1.0 / n_views)
         for p_, off in zip(model.parameters(), b):
             p_.grad = g[off:off + p_.numel()].view(p_.shape)

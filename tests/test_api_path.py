@@ -1063,41 +1063,6 @@ def test_graphed_get_outputs_follows_shape_changes_and_other_losses(cuda):
         assert_close(grads[True][k], grads[False][k].double().cpu(), 2e-5, f"grad {k} (custom loss through the segment)")
 
 
-@pytest.mark.parametrize("graphed", [False, True])
-def test_tile_order_on_a_second_stream_changes_nothing(cuda, graphed):
-    """config.order_tiles_on_side_stream: the fused step launches the compositing backward's tile order right behind the
-    forward kernel on a second stream (beside the loss / SSIM passes) and the backward pass joins it -- eager, and as fork /
-    join edges of a captured hipGraph.  Same losses and gradients as the inline ordering."""
-    from qed_splatter_amd.graph import GraphedTrainStep
-    w, h, n = 200, 136, 6000
-    sc = scene(n, w, h, seed=37)
-    got = {}
-    for side in (False, True):
-        # (an explicit stream from the start, as bench.py does: autograd pins a leaf's gradient accumulation to the stream
-        # it first ran on, and nothing may touch the legacy default stream while a step is being captured)
-        with torch.cuda.stream(torch.cuda.Stream(device=cuda)):
-            m, cam, batch = _model(sc, cuda, order_tiles_on_side_stream=side)
-            m.train()
-
-            def fwd_bwd():
-                for p in m.parameters():
-                    p.grad = None
-                losses = m.fused_loss(cam, batch, sync=False)
-                m.backward_fused(losses)
-                return losses
-            m.backward_fused(m.fused_loss(cam, batch, sync=True))    # calibrates the intersection capacity
-            if graphed:
-                g = GraphedTrainStep(fwd_bwd, cuda, warmup=2, check_every=0)
-                losses = g.replay()
-            else:
-                losses = fwd_bwd()
-            torch.cuda.synchronize()
-            got[side] = (float(losses["loss"]), {k: m.gauss_params[k].grad.detach().clone() for k in PARAM_NAMES})
-    assert got[True][0] == pytest.approx(got[False][0], rel=1e-6)
-    for k in PARAM_NAMES:
-        assert_close(got[True][1][k], got[False][1][k].double().cpu(), 2e-5, f"grad {k} (tile order on a second stream)")
-
-
 @pytest.mark.parametrize("training", [False, True])
 def test_reference_get_metrics_dict_kats_keys_values_and_writer_shape(cuda, training):
     """get_metrics_dict against the reference's own (model.py:120-197, d = 1 branch, executed by

@@ -1451,18 +1451,6 @@ def test_backward_tile_order_is_costliest_first_and_changes_no_gradient(cuda, li
     assert n_split == want_split, (n_split, want_split, per_slot)
     scale = float(outs[0].abs().max())
     assert scale > 0 and float((outs[0] - outs[1]).abs().max()) <= 2e-5 * scale
-    # the ordering as a launch of its own (what a caller with a second stream runs beside the loss passes): the same order,
-    # and qed_composite_bwd told that it is ready launches nothing but the backward kernel
-    order2 = torch.full((T + 1,), -1, dtype=torch.int32, device=cuda)
-    L.check(lib.qed_tile_order(L.ptr(cost), T, L.ptr(order2), st), "qed_tile_order")
-    torch.cuda.synchronize()
-    assert int(order2[T]) == n_split and sorted(order2[:T].cpu().tolist()) == list(range(T))
-    assert torch.equal(c.clamp(max=4095)[order2[:T].cpu().long()], key)     # (ties inside a cost bucket may be dealt differently)
-    vs3 = torch.zeros(n, L.VSPLAT_FLOATS, device=cuda)
-    L.check(lib.qed_composite_bwd(1, n, L.ptr(splats), L.ptr(fid), L.ptr(offs), w, h, tw, th, 4, None, L.ptr(alpha),
-                                  None, L.ptr(last), L.ptr(v_r), L.ptr(v_a), L.ptr(vs3), L.ptr(cost), L.ptr(order2), None,
-                                  L.CL_ORDER_READY, st), "bwd")
-    assert float((outs[0] - vs3).abs().max()) <= 2e-5 * scale
     with pytest.raises(L.QedSplatError):                               # the two buffers go together
         L.check(lib.qed_composite_bwd(1, n, L.ptr(splats), L.ptr(fid), L.ptr(offs), w, h, tw, th, 4, None, L.ptr(alpha),
                                       None, L.ptr(last), L.ptr(v_r), L.ptr(v_a), L.ptr(outs[0]), L.ptr(cost), None, None, 0, st), "bwd")

@@ -45,17 +45,22 @@ def test_bench_exchange_path_through_rccl_in_a_group_of_one(cuda):
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
             "--no-cpu-baseline", "--no-api-path", "--gaussians", "100000", "--width", "960", "--height", "540"]
     outs = []
-    one_graph = dict(env, QED_BENCH_DP_ONE_GRAPH="1")    # ... and the whole step, collectives included, as ONE captured graph
-    for e in (env, {k: v for k, v in env.items() if k != "QED_BENCH_RCCL_SELF"}, one_graph):
+    # default: the whole step, collectives included, as ONE captured graph (gather behind the backward pass); =1: the gather
+    # ahead of the projection backward; =0: three graphs around eager collectives (the fallback when a capture fails)
+    early = dict(env, QED_BENCH_DP_ONE_GRAPH="1")
+    three = dict(env, QED_BENCH_DP_ONE_GRAPH="0")
+    for e in (three, {k: v for k, v in env.items() if k != "QED_BENCH_RCCL_SELF"}, early, env):
         p = subprocess.run(base, env=e, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-4000:]
         lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
         assert len(lines) == 1, p.stdout[-2000:]
         outs.append((json.loads(lines[0]), p.stderr))
-    (o_self, err_self), (o_single, _), (o_one, err_one) = outs
-    assert "ONE hipGraph" in o_one["config"]["dispatch"], err_one[-2000:]
-    c = o_one["config"]["intersections_after_timed_steps"]
-    assert abs(c - o_single["config"]["intersections_after_timed_steps"]) <= 2e-3 * c
+    (o_self, err_self), (o_single, _), (o_one, err_one), (o_def, err_def) = outs
+    assert "ONE hipGraph" in o_one["config"]["dispatch"] and "ahead of the projection" in o_one["config"]["dispatch"], err_one[-2000:]
+    assert "ONE hipGraph" in o_def["config"]["dispatch"] and "behind the backward" in o_def["config"]["dispatch"], err_def[-2000:]
+    for o in (o_one, o_def):
+        c = o["config"]["intersections_after_timed_steps"]
+        assert abs(c - o_single["config"]["intersections_after_timed_steps"]) <= 2e-3 * c
     assert "three hipGraphs" in o_self["config"]["dispatch"], err_self[-2000:]      # the N > 1 dispatch, captured
     assert "RCCL" in o_self["config"]["parallelism"] and o_single["config"]["parallelism"] == "single"
     assert o_self["n_gpus"] == 1 and o_self["value"] > 0
