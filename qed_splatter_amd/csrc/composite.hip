@@ -37,9 +37,11 @@
 
 // Development switches (A/B builds: python -m qed_splatter_amd.build --variant NAME -DQED_K7_FORM=1):
 //   QED_K6_FORM / QED_K7_FORM  1 = one walk that tests the per-pixel form per Gaussian,
-//                              2 = two copies of the walk, the test per BATCH (the product form)
+//                              2 = two copies of the walk inline, the test per BATCH (K7's product form),
+//                              4 = (K6) the fast walk inline, the mixed walk OUT OF LINE on a copy of the state (K6's product
+//                                  form: the hot loop keeps its scalar registers; 124-126 us against 128, r05_k6_k7_variants.txt)
 #ifndef QED_K6_FORM
-#define QED_K6_FORM 2
+#define QED_K6_FORM 4
 #endif
 #ifndef QED_K7_FORM
 #define QED_K7_FORM 2
@@ -276,6 +278,23 @@ __device__ __forceinline__ void fwd_walk(u64& km, u64 (&mq)[NQ], const f2 (&pq)[
     }
 }
 
+template <int NQ>
+struct FwdWalkState { u64 km; int n_vis; u64 mq[NQ], done[NQ]; FwdPixel px[NQ]; f2 pq[NQ]; };
+
+template <int CH, int NQ>
+__device__ __attribute__((noinline)) void fwd_walk_mixed(FwdWalkState<NQ>* st, int batch_start, u64 m_slow,
+                                                         const float (*s_rec)[kRecFloats]) {
+    FwdWalkState<NQ> w = *st;
+    // (arguments and loaded values arrive in vector registers: the wave-uniform ones back into scalar registers)
+    w.km = uniform_u64(w.km);
+    w.n_vis = __builtin_amdgcn_readfirstlane(w.n_vis);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { w.mq[q] = uniform_u64(w.mq[q]); w.done[q] = uniform_u64(w.done[q]); }
+    fwd_walk<CH, NQ, true>(w.km, w.mq, w.pq, w.px, w.done, __builtin_amdgcn_readfirstlane(batch_start), uniform_u64(m_slow),
+                           w.n_vis, s_rec);
+    *st = w;
+}
+
 // ================================================================================================
 // forward
 // ================================================================================================
@@ -371,6 +390,22 @@ __device__ __forceinline__ void fwd_tile(int tile, int qf, float (*s_rec)[kRecFl
 #if QED_K6_FORM == 2
         if (m_slow == 0) fwd_walk<CH, NQ, false>(km, mq, pq, px, done, batch_start, m_slow, n_vis, s_rec);
         else fwd_walk<CH, NQ, true>(km, mq, pq, px, done, batch_start, m_slow, n_vis, s_rec);
+#elif QED_K6_FORM == 4
+        if (__builtin_expect(m_slow == 0, 1)) {
+            fwd_walk<CH, NQ, false>(km, mq, pq, px, done, batch_start, m_slow, n_vis, s_rec);
+        } else {
+            // a batch with a slow-form Gaussian (rare): the walk that tests the form per Gaussian is an OUT-OF-LINE function
+            // on a COPY of the state -- inlined beside the fast walk it costs the hot loop its scalar registers, and handing
+            // it the state itself would pin that state in memory for the whole kernel
+            FwdWalkState<NQ> st;
+            st.km = km; st.n_vis = n_vis;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { st.mq[q] = mq[q]; st.done[q] = done[q]; st.px[q] = px[q]; st.pq[q] = pq[q]; }
+            fwd_walk_mixed<CH, NQ>(&st, batch_start, m_slow, s_rec);
+            km = uniform_u64(st.km); n_vis = __builtin_amdgcn_readfirstlane(st.n_vis);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { mq[q] = uniform_u64(st.mq[q]); done[q] = uniform_u64(st.done[q]); px[q] = st.px[q]; }
+        }
 #else
         fwd_walk<CH, NQ, true>(km, mq, pq, px, done, batch_start, m_slow, n_vis, s_rec);
 #endif

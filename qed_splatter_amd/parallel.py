@@ -139,7 +139,7 @@ class CompactExchange:
 class early_gather:
     """Context manager: while it is active, the backward pass of ``model.fused_loss(..., compact_sh_grad=True)`` issues the
     all-gather of the colour-gradient message ITSELF, between the compositing backward and the projection backward
-    (rasterization.PRE_PROJECT_BWD): the message is K7's colour gradient under the forward pass's clamp mask
+    (a hook registered for THIS model in rasterization.PRE_PROJECT_BWD): the message is K7's colour gradient under the forward pass's clamp mask
     (qed_pack_color_grad) -- exactly what the projection backward would write -- so the 6 MB per rank are on the links
     while the projection backward (~30 us at 500 k Gaussians) runs.  ``exchange_grads_compact_begin`` then finds the
     gather in flight and only adds the geometry all-reduce.
@@ -176,13 +176,18 @@ class early_gather:
 
     def __enter__(self):
         from . import rasterization as R
-        self._prev, R.PRE_PROJECT_BWD = R.PRE_PROJECT_BWD, self._hook
+        self._key = self.model.means.untyped_storage().data_ptr()       # this model's hook only (rasterization.PRE_PROJECT_BWD)
+        self._prev = R.PRE_PROJECT_BWD.get(self._key)
+        R.PRE_PROJECT_BWD[self._key] = self._hook
         self.model._early_gather = None
         return self
 
     def __exit__(self, *exc):
         from . import rasterization as R
-        R.PRE_PROJECT_BWD = self._prev
+        if self._prev is None:
+            R.PRE_PROJECT_BWD.pop(self._key, None)
+        else:
+            R.PRE_PROJECT_BWD[self._key] = self._prev
         return False
 
 

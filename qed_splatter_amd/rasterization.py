@@ -216,8 +216,10 @@ KEEP_T_FINAL = True
 
 # Called by _ProjectSH.backward right before qed_project_bwd is launched, with (packed gradient rows [C*N,16], sh_jac planes,
 # C * N), when the backward pass writes compact SH gradients: the data-parallel exchange packs the colour-gradient message
-# from them and puts its all-gather on the links while the projection backward runs (parallel.early_gather)
-PRE_PROJECT_BWD = None
+# from them and puts its all-gather on the links while the projection backward runs (parallel.early_gather).  Keyed by the
+# storage of the model's `means` (the flat parameter buffer): a hook belongs to ONE model, and two models (or threads) running
+# their backward passes at once never see each other's.
+PRE_PROJECT_BWD: "Dict[int, object]" = {}
 
 
 def _workspace(device) -> _Workspace:
@@ -410,8 +412,10 @@ class _ProjectSH(torch.autograd.Function):
         lazy = getattr(ctx, "lazy_sh", None)
         if (flags & L.F_SH_GRAD_COMPACT) and lazy is not None and not lazy(v_sh0, v_shN, viewmats, sh_degree):
             flags &= ~L.F_SH_GRAD_COMPACT
-        if PRE_PROJECT_BWD is not None and sh_jac is not None and (flags & L.F_SH_GRAD_COMPACT):
-            PRE_PROJECT_BWD(vsplat, sh_jac, C * N)
+        if PRE_PROJECT_BWD and sh_jac is not None and (flags & L.F_SH_GRAD_COMPACT):
+            hook = PRE_PROJECT_BWD.get(means.untyped_storage().data_ptr())
+            if hook is not None:
+                hook(vsplat, sh_jac, C * N)
         L.check(lib.qed_project_bwd(
             N, C, L.ptr(means), L.ptr(quats), L.ptr(scales), L.ptr(opacities), L.ptr(sh0), sh0_stride, shN_ptr,
             shN_stride, sh_degree, L.ptr(viewmats), L.ptr(Ks), width, height, eps2d, flags, L.ptr(radii),
