@@ -152,12 +152,19 @@ __device__ __forceinline__ void project_one(const Cam& cam, const float* mean, c
     p.mx = cam.fx * p.x * rz + cam.cx;
     p.my = cam.fy * p.y * rz + cam.cy;
 
-    const float det_orig = a0 * c0 - b0 * b0;
+    // det(T T^T) as the sum of the squared 2x2 minors of T (Cauchy-Binet), and det(T T^T + eps I) = det(T T^T) +
+    // eps tr(T T^T) + eps^2: sums of non-negative terms.  a0 c0 - b0^2 is the difference of two numbers 1e4 .. 1e8 times its
+    // size for an elongated Gaussian (the conic of a 2 500 : 1 needle came out 4e-3 off, and with it every gradient that
+    // passes through it: DESIGN.md section 2)
+    const float m01 = p.Tm[0] * p.Tm[4] - p.Tm[1] * p.Tm[3];
+    const float m02 = p.Tm[0] * p.Tm[5] - p.Tm[2] * p.Tm[3];
+    const float m12 = p.Tm[1] * p.Tm[5] - p.Tm[2] * p.Tm[4];
+    const float det_orig = m01 * m01 + m02 * m02 + m12 * m12;
     p.A = a0 + eps2d;
     p.B = b0;
     p.Cc = c0 + eps2d;
-    p.det = p.A * p.Cc - p.B * p.B;
-    if (p.det <= 0.f) return;
+    p.det = det_orig + eps2d * (a0 + c0) + eps2d * eps2d;
+    if (!(p.det > 0.f)) return;
     p.comp = sqrtf(fmaxf(0.f, det_orig / p.det));
     const float rdet = 1.f / p.det;
     p.ca = p.Cc * rdet;
@@ -165,7 +172,8 @@ __device__ __forceinline__ void project_one(const Cam& cam, const float* mean, c
     p.cc = p.A * rdet;
 
     const float bh = 0.5f * (p.A + p.Cc);
-    const float v1 = bh + sqrtf(fmaxf(0.01f, bh * bh - p.det));
+    const float hd = 0.5f * (p.A - p.Cc);
+    const float v1 = bh + sqrtf(fmaxf(0.01f, hd * hd + p.B * p.B));     // bh^2 - det = ((A - C) / 2)^2 + B^2
     p.radius = ceilf(3.f * sqrtf(v1));
     if (p.radius <= radius_clip) return;
     if (p.mx + p.radius <= 0.f || p.mx - p.radius >= (float)width || p.my + p.radius <= 0.f ||
@@ -717,28 +725,44 @@ project_bwd_kernel(int N, int C, const float* __restrict__ means, const float* _
             } else {
                 vo += v_op;
             }
-            // ---- conic -> blurred covariance:  H = -X G X,  X = conic, G = [[v_ca, v_cb/2],[v_cb/2, v_cc]] ----
+            // ---- conic -> blurred covariance -> T:  H = -X G X,  X = conic, G = [[v_ca, v_cb/2],[v_cb/2, v_cc]], v_T = 2 H T,
+            // evaluated in the EIGENBASIS of the covariance: X = U diag(1 / l+, 1 / l-) U^T, so H = -U (G' / (l_a l_b)) U^T
+            // with G' = U^T G U.  Formed entry by entry in the pixel basis, the share of H along an elongated Gaussian's
+            // long axis (~ 1 / l+^2) is what is left of entries 1e8 times larger: `scales` gradients 6e-2 off on
+            // 2 500 : 1 needles.  l+ = bh + r and l- = det / l+ with the cancellation-free det.
             const float g01 = 0.5f * v_cb;
-            const float xg00 = p.ca * v_ca + p.cb * g01, xg01 = p.ca * g01 + p.cb * v_cc;
-            const float xg10 = p.cb * v_ca + p.cc * g01, xg11 = p.cb * g01 + p.cc * v_cc;
-            float h00 = -(xg00 * p.ca + xg01 * p.cb);
-            float h01 = -(xg00 * p.cb + xg01 * p.cc);
-            float h11 = -(xg10 * p.cb + xg11 * p.cc);
+            const float bh = 0.5f * (p.A + p.Cc), hd = 0.5f * (p.A - p.Cc);
+            const float rr = sqrtf(hd * hd + p.B * p.B);
+            const float lp = bh + rr, lm = p.det / lp;
+            // unit eigenvector of l+: (B, l+ - A) or (l+ - C, B), whichever is formed without a cancelling subtraction
+            float ux, uy;
+            if (hd >= 0.f) { ux = hd + rr; uy = p.B; }          // l+ - C = (A - C) / 2 + r
+            else { ux = p.B; uy = rr - hd; }                    // l+ - A = (C - A) / 2 + r
+            const float un = ux * ux + uy * uy;
+            if (un > 0.f) { const float ir = rsqrtf(un); ux *= ir; uy *= ir; } else { ux = 1.f; uy = 0.f; }
+            const float wx = -uy, wy = ux;                      // eigenvector of l-
+            const float gux = v_ca * ux + g01 * uy, guy = g01 * ux + v_cc * uy;       // G u
+            const float gwx = v_ca * wx + g01 * wy, gwy = g01 * wx + v_cc * wy;       // G w
+            const float ilp = 1.f / lp, ilm = 1.f / lm;
+            float hpp = -(ux * gux + uy * guy) * ilp * ilp;     // H' in the eigenbasis
+            float hpm = -(ux * gwx + uy * gwy) * ilp * ilm;
+            float hmm = -(wx * gwx + wy * gwy) * ilm * ilm;
             if (flags & QED_F_ANTIALIASED) {
-                // compensation = sqrt(max(0, det_orig / det_blur))  (gsplat add_blur_vjp)
-                const float det_conic = p.ca * p.cc - p.cb * p.cb;
+                // compensation = sqrt(max(0, det_orig / det_blur))  (gsplat add_blur_vjp): + v_sqr (om X - eps det(X) I)
+                const float det_conic = 1.f / p.det;
                 const float v_sqr = v_comp * 0.5f / (p.comp + 1e-6f);
                 const float om = 1.f - p.comp * p.comp;
-                h00 += v_sqr * (om * p.ca - eps2d * det_conic);
-                h01 += v_sqr * (om * p.cb);
-                h11 += v_sqr * (om * p.cc - eps2d * det_conic);
+                hpp += v_sqr * (om * ilp - eps2d * det_conic);
+                hmm += v_sqr * (om * ilm - eps2d * det_conic);
             }
-            // ---- cov2d = T T^T + eps I  ->  v_T = 2 H T ----
+            // ---- cov2d = T T^T + eps I  ->  v_T = 2 H T = 2 U H' (U^T T) ----
             float vT[6];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                vT[j] = 2.f * (h00 * p.Tm[j] + h01 * p.Tm[3 + j]);
-                vT[3 + j] = 2.f * (h01 * p.Tm[j] + h11 * p.Tm[3 + j]);
+                const float pu = ux * p.Tm[j] + uy * p.Tm[3 + j], pw = wx * p.Tm[j] + wy * p.Tm[3 + j];
+                const float qu = hpp * pu + hpm * pw, qw = hpm * pu + hmm * pw;
+                vT[j] = 2.f * (ux * qu + wx * qw);
+                vT[3 + j] = 2.f * (uy * qu + wy * qw);
             }
             // ---- T = J W ----
             const float rz = p.rz, rz2 = rz * rz, rz3 = rz2 * rz;
