@@ -732,18 +732,17 @@ project_bwd_kernel(int N, int C, const float* __restrict__ means, const float* _
             // 2 500 : 1 needles.  l+ = bh + r and l- = det / l+ with the cancellation-free det.
             const float g01 = 0.5f * v_cb;
             const float bh = 0.5f * (p.A + p.Cc), hd = 0.5f * (p.A - p.Cc);
-            const float rr = sqrtf(hd * hd + p.B * p.B);
-            const float lp = bh + rr, lm = p.det / lp;
+            const float rr = __builtin_amdgcn_sqrtf(hd * hd + p.B * p.B);              // (1 ulp forms: the bound is 1e-4)
+            const float lp = bh + rr, ilp = __builtin_amdgcn_rcpf(lp), lm = p.det * ilp, ilm = __builtin_amdgcn_rcpf(lm);
             // unit eigenvector of l+: (B, l+ - A) or (l+ - C, B), whichever is formed without a cancelling subtraction
             float ux, uy;
             if (hd >= 0.f) { ux = hd + rr; uy = p.B; }          // l+ - C = (A - C) / 2 + r
             else { ux = p.B; uy = rr - hd; }                    // l+ - A = (C - A) / 2 + r
             const float un = ux * ux + uy * uy;
-            if (un > 0.f) { const float ir = rsqrtf(un); ux *= ir; uy *= ir; } else { ux = 1.f; uy = 0.f; }
+            if (un > 0.f) { const float ir = __builtin_amdgcn_rsqf(un); ux *= ir; uy *= ir; } else { ux = 1.f; uy = 0.f; }
             const float wx = -uy, wy = ux;                      // eigenvector of l-
             const float gux = v_ca * ux + g01 * uy, guy = g01 * ux + v_cc * uy;       // G u
             const float gwx = v_ca * wx + g01 * wy, gwy = g01 * wx + v_cc * wy;       // G w
-            const float ilp = 1.f / lp, ilm = 1.f / lm;
             float hpp = -(ux * gux + uy * guy) * ilp * ilp;     // H' in the eigenbasis
             float hpm = -(ux * gwx + uy * gwy) * ilp * ilm;
             float hmm = -(wx * gwx + wy * gwy) * ilm * ilm;
