@@ -33,9 +33,10 @@ __device__ __constant__ float c_win[kWin] = {
     1.028380357e-03f, 7.598758209e-03f, 3.600077331e-02f, 1.093606874e-01f, 2.130055279e-01f, 2.660117149e-01f,
     2.130055279e-01f, 1.093606874e-01f, 3.600077331e-02f, 7.598758209e-03f, 1.028380357e-03f};
 
-template <int TW_, int TH_>
+template <int TW_, int TH_, int NT_ = 256>
 struct SsimTile {
-    static constexpr int TW = TW_, TH = TH_;
+    static constexpr int TW = TW_, TH = TH_, NT = NT_;          // NT threads per workgroup
+    static constexpr int NW = NT / 64;
     static constexpr int PW = TW + kHalo, PH = TH + kHalo;
     static constexpr int SP = TW + 12;                 // patch row stride: 16-float reads stay in the row; odd multiple of 4
     static constexpr int SH = TW + 4;                  // row-pass output stride (odd multiple of 4 floats)
@@ -51,11 +52,11 @@ struct SsimTile {
         if constexpr (WAVE_COLUMNS) { gx = i >> 6; py = i & 63; return py < PH; }
         else { gx = i / PH; py = i - gx * PH; return true; }
     }
-    static constexpr int COL_GROUPS = 256 / TW;
+    static constexpr int COL_GROUPS = NT / TW;
     static constexpr int CB = TH / COL_GROUPS;         // column pass: CB outputs per thread
-    static constexpr int RPP = 256 / PW;               // staging: patch rows per pass (thread -> one patch column)
+    static constexpr int RPP = NT / PW;                // staging: patch rows per pass (thread -> one patch column)
     static constexpr int LOADS = (PH + RPP - 1) / RPP; // patch pixels per staging thread
-    static_assert(TW % 4 == 0 && 256 % TW == 0 && TH % COL_GROUPS == 0, "tile shape");
+    static_assert(TW % 4 == 0 && NT % TW == 0 && NT % 64 == 0 && TH % COL_GROUPS == 0, "tile shape");
 };
 
 // predicted colour channel k of pixel (iy, ix): either a plain [H,W,3] image or composited on the fly
@@ -100,7 +101,7 @@ template <bool COMPOSITE, bool MASKED, class T>
 #ifndef QED_SSIM_FWD_PLAIN_WAVES
 #define QED_SSIM_FWD_PLAIN_WAVES 3   // the plain-image form spills 16-18 registers at four waves per SIMD: 60 -> 53 us at three
 #endif
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(T::NT)
 __attribute__((amdgpu_waves_per_eu(COMPOSITE ? QED_SSIM_FWD_WAVES : QED_SSIM_FWD_PLAIN_WAVES,
                                    COMPOSITE ? QED_SSIM_FWD_WAVES : QED_SSIM_FWD_PLAIN_WAVES)))
 ssim_fwd_kernel(int H, int W, int channels, const float* __restrict__ pred, const float* __restrict__ alpha,
@@ -109,7 +110,7 @@ ssim_fwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
     constexpr int TW = T::TW, PW = T::PW, PH = T::PH, SP = T::SP, SH = T::SH, CB = T::CB;
     __shared__ __attribute__((aligned(16))) float s_x[PH * SP], s_y[PH * SP];
     __shared__ __attribute__((aligned(16))) float s_h[4][PH * SH];
-    __shared__ float s_red[4];
+    __shared__ float s_red[T::NW];
     const int Ho = H - kHalo, Wo = W - kHalo;
     // neighbouring blocks share 10-pixel halos: keep them on one XCD's L2 (workgroups are dealt round-robin
     // over the 8 XCDs, so a linear grid is remapped to give each XCD a contiguous run of blocks)
@@ -191,7 +192,7 @@ ssim_fwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
         }
         __syncthreads();
         // rows: window sums of x, y, x^2 + y^2, x y; consecutive lanes take consecutive rows
-        for (int i = tid; i < T::ROW_SLOTS; i += 256) {
+        for (int i = tid; i < T::ROW_SLOTS; i += T::NT) {
             int gx, py;
             if (!T::row_item(i, gx, py)) continue;
             float x[16], y[16], p[16];
@@ -257,7 +258,12 @@ ssim_fwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
     __syncthreads();
     // one partial per workgroup (folded by the consumer): no zeroing launch in front of the kernel and no 2 040
     // same-address atomics behind it
-    if (tid == 0) ssim_sum[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    if (tid == 0) {
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < T::NW; ++q) tot += s_red[q];
+        ssim_sum[blockIdx.x] = tot;
+    }
 }
 
 // v_pred[H,W,3] = scale * (scale_dev ? scale_dev[0] : 1) * d(sum of the SSIM map)/d pred, pred = the colour BEFORE the
@@ -294,7 +300,7 @@ template <bool COMPOSITE, bool MASKED, class T, int FUSE = 0>
 #ifndef QED_SSIM_FUSED_WAVES
 #define QED_SSIM_FUSED_WAVES 3      // FUSE 3/4 holds the depth inputs and the alpha gradients of its four pixels as well
 #endif
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(T::NT)
 __attribute__((amdgpu_waves_per_eu(FUSE >= 3 ? QED_SSIM_FUSED_WAVES : QED_SSIM_BWD_WAVES,
                                    FUSE >= 3 ? QED_SSIM_FUSED_WAVES : QED_SSIM_BWD_WAVES)))
 ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, const float* __restrict__ alpha,
@@ -305,7 +311,7 @@ ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
     constexpr int TW = T::TW, PW = T::PW, PH = T::PH, SP = T::SP, SH = T::SH, CB = T::CB;
     __shared__ __attribute__((aligned(16))) float s_m[3][PH * SP];
     __shared__ __attribute__((aligned(16))) float s_h[3][PH * SH];
-    __shared__ float s_red[2][4];
+    __shared__ float s_red[2][T::NW];
     const int Ho = H - kHalo, Wo = W - kHalo;
     const int nbx = (W + TW - 1) / TW;
     const int blk = xcd_remap(blockIdx.x, gridDim.x);                   // halo sharing: see ssim_fwd_kernel
@@ -336,10 +342,10 @@ ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
         const bool want_depth = FUSE == 4 || (FUSE == 1 && lf.v_depth != nullptr);
         float ep_nv[4] = {0.f, 0.f, 0.f, 0.f}, ep_dm[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
         if constexpr (FUSE == 4) {
-            static_assert(kLossMaxGrid <= 4 * 256, "four partials per thread cover pass 1's grid");
+            static_assert(kLossMaxGrid <= 4 * T::NT, "four partials per thread cover pass 1's grid");
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int b = tid + 256 * j;
+                const int b = tid + T::NT * j;
                 const int bc = b < lf.n_loss_blocks ? b : 0;
                 const float nv = loss_part(lf.sums, 0)[bc], dm = loss_part(lf.sums, 1)[bc];
                 ep_nv[j] = b < lf.n_loss_blocks ? nv : 0.f;
@@ -362,8 +368,10 @@ ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
             dm = wave_max(dm);
             if ((tid & 63) == 0) { s_red[0][tid >> 6] = nv; s_red[1][tid >> 6] = dm; }
             __syncthreads();
-            const float nvalid = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
-            dmax = fmaxf(fmaxf(s_red[1][0], s_red[1][1]), fmaxf(s_red[1][2], s_red[1][3]));
+            float nvalid = 0.f;
+            dmax = -3.0e38f;
+#pragma unroll
+            for (int q = 0; q < T::NW; ++q) { nvalid += s_red[0][q]; dmax = fmaxf(dmax, s_red[1][q]); }
             w_d = nvalid > 0.f ? lf.depth_lambda / nvalid : 0.f;
             // (s_red is written again only after the channel passes, each of which starts with a barrier)
         } else if constexpr (FUSE == 1) {
@@ -376,7 +384,7 @@ ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
         if (lf.zero_buf != nullptr) {
             const long long per = (lf.zero_vec + gridDim.x - 1) / gridDim.x;
             const long long lo = (long long)blockIdx.x * per, hi = lo + per < lf.zero_vec ? lo + per : lf.zero_vec;
-            for (long long i = lo + tid; i < hi; i += 256) lf.zero_buf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (long long i = lo + tid; i < hi; i += T::NT) lf.zero_buf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     float r0[CB], r1[CB];            // channels 0 and 1 wait for channel 2: one 12-byte store per pixel
@@ -423,7 +431,7 @@ ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
                 }
         }
         __syncthreads();
-        for (int i = tid; i < T::ROW_SLOTS; i += 256) {
+        for (int i = tid; i < T::ROW_SLOTS; i += T::NT) {
             int gx, py;
             if (!T::row_item(i, gx, py)) continue;
             const int o = py * SH + 4 * gx;
@@ -508,8 +516,11 @@ ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
         __syncthreads();
         if (tid == 0) {
             const int slot = (int)(blockIdx.x % (unsigned)lf.n_loss_blocks);
-            atomicAdd(&loss_part(lf.sums, 2)[slot], s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3]);
-            atomicAdd(&loss_part(lf.sums, 3)[slot], s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3]);
+            float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+            for (int q = 0; q < T::NW; ++q) { t0 += s_red[0][q]; t1 += s_red[1][q]; }
+            atomicAdd(&loss_part(lf.sums, 2)[slot], t0);
+            atomicAdd(&loss_part(lf.sums, 3)[slot], t1);
         }
     }
 }
@@ -518,12 +529,18 @@ ssim_bwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
 #define QED_SSIM_FWD_TW 32
 #define QED_SSIM_FWD_TH 32
 #endif
+#ifndef QED_SSIM_FWD_NT
+#define QED_SSIM_FWD_NT 256
+#endif
+#ifndef QED_SSIM_BWD_NT
+#define QED_SSIM_BWD_NT 256
+#endif
 #ifndef QED_SSIM_BWD_TW
 #define QED_SSIM_BWD_TW 32
 #define QED_SSIM_BWD_TH 32
 #endif
-using Tile = SsimTile<QED_SSIM_FWD_TW, QED_SSIM_FWD_TH>;
-using TileB = SsimTile<QED_SSIM_BWD_TW, QED_SSIM_BWD_TH>;
+using Tile = SsimTile<QED_SSIM_FWD_TW, QED_SSIM_FWD_TH, QED_SSIM_FWD_NT>;
+using TileB = SsimTile<QED_SSIM_BWD_TW, QED_SSIM_BWD_TH, QED_SSIM_BWD_NT>;
 
 }  // namespace qed
 
@@ -549,7 +566,7 @@ extern "C" int qed_ssim_fwd(int32_t height, int32_t width, int32_t channels, con
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(((width - kHalo + Tile::TW - 1) / Tile::TW) * ((height - kHalo + Tile::TH - 1) / Tile::TH));
 #define QED_SSIM_FWD(COMP, MASK, CHN)                                                                               \
-    hipLaunchKernelGGL((ssim_fwd_kernel<COMP, MASK, Tile>), grid, dim3(256), 0, st, height, width, CHN, pred, alpha,   \
+    hipLaunchKernelGGL((ssim_fwd_kernel<COMP, MASK, Tile>), grid, dim3(Tile::NT), 0, st, height, width, CHN, pred, alpha,   \
                        background, gt_rgb, mask, maps, ssim_sum)
     if (alpha != nullptr) { if (mask) QED_SSIM_FWD(true, true, channels); else QED_SSIM_FWD(true, false, channels); }
     else { if (mask) QED_SSIM_FWD(false, true, 3); else QED_SSIM_FWD(false, false, 3); }
@@ -566,7 +583,7 @@ extern "C" int qed_ssim_bwd(int32_t height, int32_t width, int32_t channels, con
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(((width + TileB::TW - 1) / TileB::TW) * ((height + TileB::TH - 1) / TileB::TH));
 #define QED_SSIM_BWD(COMP, MASK, CHN)                                                                               \
-    hipLaunchKernelGGL((ssim_bwd_kernel<COMP, MASK, TileB>), grid, dim3(256), 0, st, height, width, CHN, pred, alpha,   \
+    hipLaunchKernelGGL((ssim_bwd_kernel<COMP, MASK, TileB>), grid, dim3(TileB::NT), 0, st, height, width, CHN, pred, alpha,   \
                        background, gt_rgb, mask, maps, scale, scale_dev, v_pred, LossFuse{})
     if (alpha != nullptr) { if (mask) QED_SSIM_BWD(true, true, channels); else QED_SSIM_BWD(true, false, channels); }
     else { if (mask) QED_SSIM_BWD(false, true, 3); else QED_SSIM_BWD(false, false, 3); }
@@ -595,7 +612,7 @@ extern "C" int qed_loss_grad_ssim(int32_t height, int32_t width, int32_t channel
                       v_render, v_alpha, nullptr, zero_floats > 0 ? (float4*)zero_buf : nullptr, zero_floats / 4};
     const dim3 grid(((width + TileB::TW - 1) / TileB::TW) * ((height + TileB::TH - 1) / TileB::TH));
 #define QED_SSIM_BWD_FUSED(MASK, CHN)                                                                                \
-    hipLaunchKernelGGL((ssim_bwd_kernel<true, MASK, TileB, CHN>), grid, dim3(256), 0, st, height, width, CHN, render, \
+    hipLaunchKernelGGL((ssim_bwd_kernel<true, MASK, TileB, CHN>), grid, dim3(TileB::NT), 0, st, height, width, CHN, render, \
                        alpha, background, gt_rgb, mask, maps, ssim_scale, (const float*)nullptr, (float*)nullptr, lf)
     if (channels == 4) { if (mask) QED_SSIM_BWD_FUSED(true, 4); else QED_SSIM_BWD_FUSED(false, 4); }
     else { if (mask) QED_SSIM_BWD_FUSED(true, 3); else QED_SSIM_BWD_FUSED(false, 3); }
@@ -633,10 +650,10 @@ extern "C" int qed_image_losses_ssim_bwd(int32_t height, int32_t width, const fl
                       zero_buf ? (long long)(zero_floats / 4) : 0};
     const dim3 grid(((width + TileB::TW - 1) / TileB::TW) * ((height + TileB::TH - 1) / TileB::TH));
     if (mask)
-        hipLaunchKernelGGL((ssim_bwd_kernel<false, true, TileB, 1>), grid, dim3(256), 0, st, height, width, 3, rgb,
+        hipLaunchKernelGGL((ssim_bwd_kernel<false, true, TileB, 1>), grid, dim3(TileB::NT), 0, st, height, width, 3, rgb,
                            (const float*)nullptr, (const float*)nullptr, gt_rgb, mask, maps, ssim_scale, g_main, v_rgb, lf);
     else
-        hipLaunchKernelGGL((ssim_bwd_kernel<false, false, TileB, 1>), grid, dim3(256), 0, st, height, width, 3, rgb,
+        hipLaunchKernelGGL((ssim_bwd_kernel<false, false, TileB, 1>), grid, dim3(TileB::NT), 0, st, height, width, 3, rgb,
                            (const float*)nullptr, (const float*)nullptr, gt_rgb, mask, maps, ssim_scale, g_main, v_rgb, lf);
     return check_launch("qed_image_losses_ssim_bwd");
 }
