@@ -152,7 +152,42 @@ __device__ __forceinline__ u64 uniform_u64(u64 v) {
 // the flush).
 constexpr float kConicScale = -0.5f * kLog2e;
 __device__ __forceinline__ f2 conic_times_d(f2 R0, f2 R1, f2 d) {
-    return R0 * (f2){d.x, d.x} + R1 * (f2){d.y, d.y};  // (k (a dx + b dy), k (b dx + c dy))
+    // (k (a dx + b dy), k (b dx + c dy)) as fma(R0, dx, R1 dy) -- spelled out: left to the compiler's contraction of
+    // `R0 dx + R1 dy` the product that is rounded first is whichever operand it has at hand, which differed between the
+    // quadrants of ONE kernel (and could between the two kernels): alphas an ulp apart for the same (pixel, Gaussian)
+    return __builtin_elementwise_fma(R0, (f2){d.x, d.x}, R1 * (f2){d.y, d.y});
+}
+
+// the third 16 bytes of a splat record without its last word (the packed tile rectangle, which only the binning reads):
+// a 12-byte load.  As a 16-byte load the word's register is dead on arrival, the allocator hands it out at once, and the
+// write-after-write hazard makes the wave wait for the load right behind its issue.
+typedef float f3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ f3 load_rec_tail(const float4* __restrict__ splats, size_t g) {
+    return *reinterpret_cast<const f3*>(&splats[3 * g + 2]);
+}
+
+// The pixel centres of a lane: ONE pair (its pixel in quadrant 0) instead of one pair per quadrant.  d = mean - centre is
+// formed once per Gaussian against that pixel and a quadrant takes 8 off the component(s) it is displaced in -- six
+// registers fewer per lane in both kernels: the forward kernel at 96 registers was moving a colour accumulator through
+// scratch around every batch's cull, and the reload behind the next batch's gather made the walk wait for the gather
+// (the hot loop is spill-free now; the kernel's time did not change: 123-125 us either way, r05_k6_k7_variants.txt).
+// The forward and the backward kernel and both launch shapes form d with the SAME operations (a one-quadrant wave
+// subtracts its offset pair, 0 or 8 per component: x - 0 is exact), so every alpha is bit-identical in all of them.
+template <int NQ>
+struct PixGrid {
+    f2 p0;       // centre of the lane's pixel in quadrant 0 of the tile
+    f2 off;      // NQ == 1: (8 or 0, 8 or 0) of the wave's quadrant
+};
+template <int NQ>
+__device__ __forceinline__ f2 quadrant_delta(const PixGrid<NQ>& pg, f2 d0, int q) {
+    if constexpr (NQ == 4) {
+        f2 d = d0;
+        if (q & 1) d.x -= 8.f;
+        if (q >> 1) d.y -= 8.f;
+        return d;
+    } else {
+        return d0 - pg.off;
+    }
 }
 
 // get_outputs' post-processing folded into the compositing kernels (model.py:295-297, 304-306; the reference-shaped route):
@@ -192,9 +227,8 @@ __device__ __forceinline__ bool gaussian_is_fast(float ca, float cb, float cc, f
 }
 // MIXED = false: every Gaussian of the batch takes the fast form (no test at all); true: `slow` (wave-uniform) decides.
 template <int CH, bool MIXED>
-__device__ __forceinline__ void fwd_quadrant(f2 pq, f2 XY, f2 R0, f2 R1, float lo, f2 col01, f2 col23, int idx_v,
+__device__ __forceinline__ void fwd_quadrant(f2 d, f2 R0, f2 R1, float lo, f2 col01, f2 col23, int idx_v,
                                              unsigned slow, u64& done, FwdPixel& s) {
-    const f2 d = XY - pq;
     const f2 md = conic_times_d(R0, R1, d);
     float a;
     u64 m_ok;
@@ -237,9 +271,10 @@ __device__ __forceinline__ void fwd_fetch(FwdRec& r, const float (*s_rec)[kRecFl
 // composite Gaussian t (record r): the quadrants whose mask holds it, in turn.  A quadrant that finishes is dropped from
 // the masks, which can take later Gaussians out of km.
 template <int CH, int NQ, bool MIXED>
-__device__ __forceinline__ void fwd_gaussian(const FwdRec& r, int t, u64 bit, u64& km, u64 (&mq)[NQ], const f2 (&pq)[NQ],
+__device__ __forceinline__ void fwd_gaussian(const FwdRec& r, int t, u64 bit, u64& km, u64 (&mq)[NQ], const PixGrid<NQ>& pg,
                                              FwdPixel (&px)[NQ], u64 (&done)[NQ], int batch_start, u64 m_slow, int& n_vis) {
     const f2 XY = {r.q0.x, r.q0.y}, R0 = {r.q0.z, r.q0.w}, R1 = {r.q1.x, r.q1.y}, col01 = {r.q1.z, r.q1.w};
+    const f2 d0 = XY - pg.p0;
     const f2 col23 = {r.q2.x, CH == 4 ? r.q2.y : 0.f};
     QED_STAT(4, 1);
     int idx_v;                                          // one VGPR copy per Gaussian, not per quadrant
@@ -250,7 +285,7 @@ __device__ __forceinline__ void fwd_gaussian(const FwdRec& r, int t, u64 bit, u6
         if (!(mq[q] & bit)) continue;                   // wave-uniform: this quadrant cannot see Gaussian t
         QED_STAT(3, 1);
         asm volatile("s_add_u32 %0, %0, 1" : "+s"(n_vis));              // (a scalar counter: as `++n_vis` it took a VGPR and spilled)
-        fwd_quadrant<CH, MIXED>(pq[q], XY, R0, R1, r.q2.z, col01, col23, idx_v, slow, done[q], px[q]);
+        fwd_quadrant<CH, MIXED>(quadrant_delta<NQ>(pg, d0, q), R0, R1, r.q2.z, col01, col23, idx_v, slow, done[q], px[q]);
         if (done[q] == ~0ull) {                         // quadrant finished: drop it from the masks
             mq[q] = 0;
             u64 m = 0;
@@ -266,7 +301,7 @@ __device__ __forceinline__ void fwd_gaussian(const FwdRec& r, int t, u64 bit, u6
 // in round 5, 154 against 150 in round 3: the scalar bookkeeping of the look-ahead costs more than the latency it hides,
 // and 80 registers per lane at six waves per SIMD leave no room for it.  profiles/r05_k6_k7_variants.txt)
 template <int CH, int NQ, bool MIXED>
-__device__ __forceinline__ void fwd_walk(u64& km, u64 (&mq)[NQ], const f2 (&pq)[NQ], FwdPixel (&px)[NQ], u64 (&done)[NQ],
+__device__ __forceinline__ void fwd_walk(u64& km, u64 (&mq)[NQ], const PixGrid<NQ>& pg, FwdPixel (&px)[NQ], u64 (&done)[NQ],
                                          int batch_start, u64 m_slow, int& n_vis, const float (*s_rec)[kRecFloats]) {
     while (km) {
         const int t = __builtin_ctzll(km);
@@ -274,12 +309,12 @@ __device__ __forceinline__ void fwd_walk(u64& km, u64 (&mq)[NQ], const f2 (&pq)[
         km &= ~bit;
         FwdRec r;
         fwd_fetch(r, s_rec, t);
-        fwd_gaussian<CH, NQ, MIXED>(r, t, bit, km, mq, pq, px, done, batch_start, m_slow, n_vis);
+        fwd_gaussian<CH, NQ, MIXED>(r, t, bit, km, mq, pg, px, done, batch_start, m_slow, n_vis);
     }
 }
 
 template <int NQ>
-struct FwdWalkState { u64 km; int n_vis; u64 mq[NQ], done[NQ]; FwdPixel px[NQ]; f2 pq[NQ]; };
+struct FwdWalkState { u64 km; int n_vis; u64 mq[NQ], done[NQ]; FwdPixel px[NQ]; PixGrid<NQ> pg; };
 
 template <int CH, int NQ>
 __device__ __attribute__((noinline)) void fwd_walk_mixed(FwdWalkState<NQ>* st, int batch_start, u64 m_slow,
@@ -290,7 +325,7 @@ __device__ __attribute__((noinline)) void fwd_walk_mixed(FwdWalkState<NQ>* st, i
     w.n_vis = __builtin_amdgcn_readfirstlane(w.n_vis);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { w.mq[q] = uniform_u64(w.mq[q]); w.done[q] = uniform_u64(w.done[q]); }
-    fwd_walk<CH, NQ, true>(w.km, w.mq, w.pq, w.px, w.done, __builtin_amdgcn_readfirstlane(batch_start), uniform_u64(m_slow),
+    fwd_walk<CH, NQ, true>(w.km, w.mq, w.pg, w.px, w.done, __builtin_amdgcn_readfirstlane(batch_start), uniform_u64(m_slow),
                            w.n_vis, s_rec);
     *st = w;
 }
@@ -323,7 +358,9 @@ __device__ __forceinline__ void fwd_tile(int tile, int qf, float (*s_rec)[kRecFl
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
 #endif
 
-    f2 pq[NQ];                                          // pixel centres of this lane's NQ pixels
+    PixGrid<NQ> pg;                                     // pixel centres of this lane's NQ pixels
+    pg.p0 = (f2){(float)(tx * QED_TILE + lx) + 0.5f, (float)(ty * QED_TILE + ly) + 0.5f};
+    pg.off = (f2){(float)((q0 & 1) << 3), (float)((q0 >> 1) << 3)};
     FwdPixel px[NQ];
     u64 done[NQ];                                       // wave-uniform masks
     bool inside[NQ];
@@ -331,7 +368,6 @@ __device__ __forceinline__ void fwd_tile(int tile, int qf, float (*s_rec)[kRecFl
     for (int q = 0; q < NQ; ++q) {
         const int qq = NQ == 4 ? q : q0;
         const int ix = tx * QED_TILE + ((qq & 1) << 3) + lx, iy = ty * QED_TILE + ((qq >> 1) << 3) + ly;
-        pq[q] = (f2){(float)ix + 0.5f, (float)iy + 0.5f};
         inside[q] = ix < width && iy < height;
         done[q] = __ballot(!inside[q]);
         px[q].T = 1.f;
@@ -347,10 +383,11 @@ __device__ __forceinline__ void fwd_tile(int tile, int qf, float (*s_rec)[kRecFl
     // condition is merged with the old value right behind it, which makes the wave wait for it on the spot.
     auto id_at = [&](int idx) { return flatten_ids[idx < end ? idx : end - 1]; };
     int rid_n = id_at(start + kBatch + lane);
-    float4 r0, r1, r2;
+    float4 r0, r1;
+    f3 r2;
     {
         const size_t g = (size_t)id_at(start + lane);
-        r0 = splats[3 * g]; r1 = splats[3 * g + 1]; r2 = splats[3 * g + 2];
+        r0 = splats[3 * g]; r1 = splats[3 * g + 1]; r2 = load_rec_tail(splats, g);
     }
     bool present = start + lane < end;
     auto and_done = [&]() { u64 m = ~0ull;
@@ -382,32 +419,38 @@ __device__ __forceinline__ void fwd_tile(int tile, int qf, float (*s_rec)[kRecFl
         __syncthreads();                                // single wave: orders the stores before the reads below
         // issue the gather of the next batch (its ids arrived a batch ago) and the id load of the one after
         const size_t g_n = (size_t)rid_n;
-        const float4 n0 = splats[3 * g_n], n1 = splats[3 * g_n + 1], n2 = splats[3 * g_n + 2];
+        const float4 n0 = splats[3 * g_n], n1 = splats[3 * g_n + 1];
+        const f3 n2 = load_rec_tail(splats, g_n);
         const int rid_nn = id_at(start + (b + 2) * kBatch + lane);
         const int batch_start = start + b * kBatch;
         // the walk over the batch's survivors (fwd_walk): two copies -- a batch whose Gaussians all take the fast form
         // (every batch of an ordinary scene) runs without any per-visit test of the form
 #if QED_K6_FORM == 2
-        if (m_slow == 0) fwd_walk<CH, NQ, false>(km, mq, pq, px, done, batch_start, m_slow, n_vis, s_rec);
-        else fwd_walk<CH, NQ, true>(km, mq, pq, px, done, batch_start, m_slow, n_vis, s_rec);
+        if (m_slow == 0) fwd_walk<CH, NQ, false>(km, mq, pg, px, done, batch_start, m_slow, n_vis, s_rec);
+        else fwd_walk<CH, NQ, true>(km, mq, pg, px, done, batch_start, m_slow, n_vis, s_rec);
 #elif QED_K6_FORM == 4
         if (__builtin_expect(m_slow == 0, 1)) {
-            fwd_walk<CH, NQ, false>(km, mq, pq, px, done, batch_start, m_slow, n_vis, s_rec);
+            fwd_walk<CH, NQ, false>(km, mq, pg, px, done, batch_start, m_slow, n_vis, s_rec);
         } else {
             // a batch with a slow-form Gaussian (rare): the walk that tests the form per Gaussian is an OUT-OF-LINE function
             // on a COPY of the state -- inlined beside the fast walk it costs the hot loop its scalar registers, and handing
             // it the state itself would pin that state in memory for the whole kernel
             FwdWalkState<NQ> st;
             st.km = km; st.n_vis = n_vis;
+            st.pg = pg;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) { st.mq[q] = mq[q]; st.done[q] = done[q]; st.px[q] = px[q]; st.pq[q] = pq[q]; }
+            for (int q = 0; q < NQ; ++q) { st.mq[q] = mq[q]; st.done[q] = done[q]; st.px[q] = px[q]; }
             fwd_walk_mixed<CH, NQ>(&st, batch_start, m_slow, s_rec);
             km = uniform_u64(st.km); n_vis = __builtin_amdgcn_readfirstlane(st.n_vis);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) { mq[q] = uniform_u64(st.mq[q]); done[q] = uniform_u64(st.done[q]); px[q] = st.px[q]; }
+            // the loads of this copy-back retire HERE: left pending at the join, the fast path inherits "a register of the
+            // walk may still be the target of a load" and its first Gaussian waits for vmcnt(1) -- the counter retires in
+            // order, so that is the next batch's gather (s_waitcnt vmcnt(0), expcnt / lgkmcnt untouched)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
         }
 #else
-        fwd_walk<CH, NQ, true>(km, mq, pq, px, done, batch_start, m_slow, n_vis, s_rec);
+        fwd_walk<CH, NQ, true>(km, mq, pg, px, done, batch_start, m_slow, n_vis, s_rec);
 #endif
         all_done = and_done() == ~0ull;                 // (a finished quadrant empties its mask, so km ran out by itself)
         r0 = n0; r1 = n1; r2 = n2;                      // rotate the pipeline (the wave waits HERE, not above)
@@ -551,9 +594,8 @@ struct BwdPixel {
 
 // MIXED / slow / lo: as fwd_quadrant.
 template <int CH, bool MIXED>
-__device__ __forceinline__ void bwd_quadrant(f2 pq, f2 XY, f2 R0, f2 R1, float lo, f2 col01, f2 col23, int idx,
+__device__ __forceinline__ void bwd_quadrant(f2 d, f2 R0, f2 R1, float lo, f2 col01, f2 col23, int idx,
                                              unsigned slow, BwdPixel& s, u64& any_valid, GradAcc& g) {
-    const f2 d = XY - pq;
     const f2 w = conic_times_d(R0, R1, d);
     float opv, a;
     u64 m_valid, m_vs;
@@ -663,13 +705,14 @@ __device__ __forceinline__ void bwd_fetch(BwdRec& r, const float (*s_rec)[kRecFl
 
 // the pixels of Gaussian t (record r), then its twelve sums parked for the flush
 template <int CH, int NQ, bool MIXED>
-__device__ __forceinline__ void bwd_gaussian(BwdRec& r, int t, u64 bit, u64 km, const u64 (&mq)[NQ], const f2 (&pq)[NQ],
+__device__ __forceinline__ void bwd_gaussian(BwdRec& r, int t, u64 bit, u64 km, const u64 (&mq)[NQ], const PixGrid<NQ>& pg,
                                              BwdPixel (&px)[NQ], int batch_hi, u64 m_slow, ParkState& park,
                                              float* park_lane, const float* __restrict__ s_part,
                                              const float (*s_rec)[kRecFloats], float* __restrict__ vsplat, int lane) {
     const f2 XY = {r.q0.x, r.q0.y}, R0 = {r.q0.z, r.q0.w}, R1 = {r.q1.x, r.q1.y};
     const f2 col23 = {r.q1.z, CH == 4 ? r.q1.w : 0.f}, col01 = {r.q2.x, r.q2.y};
     const float lo = r.q2.z;
+    const f2 d0 = XY - pg.p0;
     const int idx = batch_hi - t;
     const unsigned slow = MIXED ? __builtin_amdgcn_readfirstlane((unsigned)(m_slow >> t) & 1u) : 0u;
     GradAcc g;
@@ -680,7 +723,7 @@ __device__ __forceinline__ void bwd_gaussian(BwdRec& r, int t, u64 bit, u64 km, 
     for (int q = 0; q < NQ; ++q) {
         if (!(mq[q] & bit)) continue;                   // wave-uniform: this quadrant cannot see Gaussian t
         QED_STAT(11, 1);
-        bwd_quadrant<CH, MIXED>(pq[q], XY, R0, R1, lo, col01, col23, idx, slow, px[q], any_valid, g);
+        bwd_quadrant<CH, MIXED>(quadrant_delta<NQ>(pg, d0, q), R0, R1, lo, col01, col23, idx, slow, px[q], any_valid, g);
     }
     if (any_valid == 0) return;
     QED_STAT(12, 1);
@@ -706,7 +749,7 @@ __device__ __forceinline__ void bwd_gaussian(BwdRec& r, int t, u64 bit, u64 km, 
 // the latency ran beside the in-wave reduction, which is gone.  On demand / behind / ahead measure alike within the
 // spread, 274-277 us: profiles/r05_k6_k7_variants.txt; this form keeps the fetch clear of compiler-inserted copies.)
 template <int CH, int NQ, bool MIXED>
-__device__ __forceinline__ void bwd_walk(u64 km, const u64 (&mq)[NQ], const f2 (&pq)[NQ], BwdPixel (&px)[NQ], int batch_hi,
+__device__ __forceinline__ void bwd_walk(u64 km, const u64 (&mq)[NQ], const PixGrid<NQ>& pg, BwdPixel (&px)[NQ], int batch_hi,
                                          u64 m_slow, ParkState& park, float* park_lane, const float* __restrict__ s_part,
                                          const float (*s_rec)[kRecFloats], float* __restrict__ vsplat, int lane) {
     BwdRec ra, rb;
@@ -718,7 +761,7 @@ __device__ __forceinline__ void bwd_walk(u64 km, const u64 (&mq)[NQ], const f2 (
             const u64 bit = 1ull << t;
             km &= ~bit;
             if (km) bwd_fetch(rb, s_rec, __builtin_ctzll(km));
-            bwd_gaussian<CH, NQ, MIXED>(ra, t, bit, km, mq, pq, px, batch_hi, m_slow, park, park_lane, s_part, s_rec, vsplat, lane);
+            bwd_gaussian<CH, NQ, MIXED>(ra, t, bit, km, mq, pg, px, batch_hi, m_slow, park, park_lane, s_part, s_rec, vsplat, lane);
         }
         if (!km) break;
         {
@@ -726,7 +769,7 @@ __device__ __forceinline__ void bwd_walk(u64 km, const u64 (&mq)[NQ], const f2 (
             const u64 bit = 1ull << t;
             km &= ~bit;
             if (km) bwd_fetch(ra, s_rec, __builtin_ctzll(km));
-            bwd_gaussian<CH, NQ, MIXED>(rb, t, bit, km, mq, pq, px, batch_hi, m_slow, park, park_lane, s_part, s_rec, vsplat, lane);
+            bwd_gaussian<CH, NQ, MIXED>(rb, t, bit, km, mq, pg, px, batch_hi, m_slow, park, park_lane, s_part, s_rec, vsplat, lane);
         }
     }
 }
@@ -757,7 +800,9 @@ __device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_rec)[kRecFl
     const int start = offsets[tile], end = offsets[tile + 1];
     if (end <= start) return;
 
-    f2 pq[NQ];
+    PixGrid<NQ> pg;
+    pg.p0 = (f2){(float)(tx * QED_TILE + lx) + 0.5f, (float)(ty * QED_TILE + ly) + 0.5f};
+    pg.off = (f2){(float)((q0 & 1) << 3), (float)((q0 >> 1) << 3)};
     BwdPixel px[NQ];
     int quad_last[NQ];
     int tile_last = -1;
@@ -774,7 +819,6 @@ __device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_rec)[kRecFl
     for (int q = 0; q < NQ; ++q) {
         const int qq = NQ == 4 ? q : q0;
         const int ix = tx * QED_TILE + ((qq & 1) << 3) + lx, iy = ty * QED_TILE + ((qq >> 1) << 3) + ly;
-        pq[q] = (f2){(float)ix + 0.5f, (float)iy + 0.5f};
         inside[q] = ix < width && iy < height;
         const size_t pix = ((size_t)cam * height + min(iy, height - 1)) * width + min(ix, width - 1);
         pix_in[q] = pix;
@@ -868,7 +912,8 @@ __device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_rec)[kRecFl
     auto id_at = [&](int idx) { return flatten_ids[idx > start ? idx : start]; };
     int rid = id_at(eff_end - 1 - lane);
     int rid_n = id_at(eff_end - 1 - kBatch - lane);
-    float4 r0 = splats[3 * (size_t)rid], r1 = splats[3 * (size_t)rid + 1], r2 = splats[3 * (size_t)rid + 2];
+    float4 r0 = splats[3 * (size_t)rid], r1 = splats[3 * (size_t)rid + 1];
+    f3 r2 = load_rec_tail(splats, (size_t)rid);
     bool present = eff_end - 1 - lane >= start;
     // everything fetched so far (pixel state, first records, second ids) has landed before the loop: inside it the
     // only loads in flight are the prefetches, and the per-Gaussian body never waits on memory (without this the
@@ -902,17 +947,17 @@ __device__ __forceinline__ void bwd_tile(int tile, int qf, float (*s_rec)[kRecFl
                                                                        __int_as_float(rid));
         }
         __syncthreads();
-        const float4 n0 = splats[3 * (size_t)rid_n], n1 = splats[3 * (size_t)rid_n + 1],
-                     n2 = splats[3 * (size_t)rid_n + 2];
+        const float4 n0 = splats[3 * (size_t)rid_n], n1 = splats[3 * (size_t)rid_n + 1];
+        const f3 n2 = load_rec_tail(splats, (size_t)rid_n);
         const int rid_nn = id_at(batch_hi - 2 * kBatch - lane);
         float* const park_lane = s_part + lane;         // [slot][value][lane]
         // two copies of the walk, as in the forward kernel: a batch whose Gaussians all take the fast form carries no test
         ParkState park{0, 0, 0, 0};
 #if QED_K7_FORM == 2
-        if (m_slow == 0) bwd_walk<CH, NQ, false>(km, mq, pq, px, batch_hi, m_slow, park, park_lane, s_part, s_rec, vsplat, lane);
-        else bwd_walk<CH, NQ, true>(km, mq, pq, px, batch_hi, m_slow, park, park_lane, s_part, s_rec, vsplat, lane);
+        if (m_slow == 0) bwd_walk<CH, NQ, false>(km, mq, pg, px, batch_hi, m_slow, park, park_lane, s_part, s_rec, vsplat, lane);
+        else bwd_walk<CH, NQ, true>(km, mq, pg, px, batch_hi, m_slow, park, park_lane, s_part, s_rec, vsplat, lane);
 #else
-        bwd_walk<CH, NQ, true>(km, mq, pq, px, batch_hi, m_slow, park, park_lane, s_part, s_rec, vsplat, lane);
+        bwd_walk<CH, NQ, true>(km, mq, pg, px, batch_hi, m_slow, park, park_lane, s_part, s_rec, vsplat, lane);
 #endif
         const int n_parked = park.n, pt0 = park.t0, pt1 = park.t1, pt2 = park.t2;
         if (n_parked)                                   // before the next batch overwrites s_rec (ids, opacities)
