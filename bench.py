@@ -809,6 +809,10 @@ def main():
                 "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": prof_note,
                 "algorithmic_bytes_per_launch": alg_bytes, "list_entries_per_launch": M_proc,
                 "list_entries_reference": M_ref, "kernel_ms": dom_ms,
+                "kernel_ms_covers": "HIP events on the launch stream around the qed_composite_bwd ENTRY POINT, eager: the "
+                                    "one-workgroup ordering launch (tile_order_kernel, ~10 us) + composite_bwd_kernel + the two "
+                                    "event records; the rocprofv3 kernel trace of the same command lists the two kernels "
+                                    "separately (profiles/r05_bench_kernel_stats_v3.txt: 9.8 + 276.1 us on that box)",
                 # the same launch priced on the list the REFERENCE operator would have walked for this image (SURVEY 8d's
                 # unit is gsplat's intersection): a shorter list for the same image lowers `frac` while the kernel gets
                 # faster, so both are given; `achieved` / `frac` stay on what the launch really processed
