@@ -259,6 +259,8 @@ typedef struct {
 #define QED_CL_QUADRANT_WAVES 2
 #define QED_CL_HALF_AND_HALF 3
 #define QED_CL_NO_CULL 4
+#define QED_CL_ORDER_READY 8    /* qed_composite_bwd: order_ws already holds the launch order of this tile_cost
+                                   (qed_ssim_fwd_step wrote it): no ordering launch in front of the kernel */
 int qed_composite_fwd(int32_t C, int32_t N, const float* splats, const int32_t* flatten_ids,
                       const int32_t* offsets, int32_t width, int32_t height, int32_t tile_w,
                       int32_t tile_h, int32_t channels, const float* backgrounds, float* render,
@@ -327,6 +329,18 @@ int qed_ssim_fwd(int32_t height, int32_t width, int32_t channels, const float* p
 int qed_ssim_bwd(int32_t height, int32_t width, int32_t channels, const float* pred, const float* alpha,
                  const float* background, const float* gt_rgb, const float* mask, const float* maps,
                  float scale, const float* scale_dev, float* v_pred, void* stream);
+/* qed_ssim_fwd of the fused training step, with two optional PASSENGERS riding in the same launch instead of in launches of
+ * their own on the step's critical chain:
+ *  - tile_cost != NULL: one extra workgroup sorts the tiles of the compositing backward that follows by the cost
+ *    qed_composite_fwd counted (tile_cost[n_tiles][4], n_tiles = C * tile_w * tile_h) and leaves the launch order in
+ *    order_ws[n_tiles + 1] -- pass that order_ws to qed_composite_bwd with QED_CL_ORDER_READY;
+ *  - sums != NULL: pass 1 of the image loss, exactly qed_loss_reduce(height * width, channels, render, ..., gt_depth, mask,
+ *    sums), as extra workgroups (no separate qed_loss_reduce call then).
+ * render / alpha / background as in qed_ssim_fwd's composite mode (alpha must be given). */
+int qed_ssim_fwd_step(int32_t height, int32_t width, int32_t channels, const float* render, const float* alpha,
+                      const float* background, const float* gt_rgb, const float* mask, float* maps,
+                      float* ssim_sum, const int32_t* tile_cost, int64_t n_tiles, int32_t* order_ws,
+                      const float* gt_depth, float* sums, void* stream);
 
 /* qed_ssim_bwd and qed_loss_grad in ONE launch (the fused training step), after qed_ssim_fwd and qed_loss_reduce on
  * the same buffers: every thread of the SSIM backward pass finishes its pixels on the spot -- SSIM gradient (scale

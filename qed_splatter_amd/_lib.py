@@ -58,6 +58,7 @@ SIGNATURES = {
     "qed_ssim_maps_floats": (C.c_int64, [_I, _I]),
     "qed_ssim_sum_floats": (C.c_int64, [_I, _I]),
     "qed_ssim_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "qed_ssim_fwd_step": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P]),
     "qed_ssim_bwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P]),
     "qed_post_process_fwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "qed_post_process_bwd": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -105,7 +106,7 @@ VSPLAT_FLOATS = 16
 SH_JAC_FLOATS = 10            # QED_SH_JAC_FLOATS
 STATUS_WORDS = 4
 TILE = 16
-CL_TILE_WAVES, CL_QUADRANT_WAVES, CL_HALF_AND_HALF, CL_NO_CULL = 1, 2, 3, 4
+CL_TILE_WAVES, CL_QUADRANT_WAVES, CL_HALF_AND_HALF, CL_NO_CULL, CL_ORDER_READY = 1, 2, 3, 4, 8
 BIN_AUTO, BIN_TWO_STAGE, BIN_TILE_SORT = 0, 1, 2
 
 

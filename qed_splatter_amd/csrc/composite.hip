@@ -540,9 +540,6 @@ __device__ __forceinline__ void small_wave(int r, int n_small, int& t, int& q) {
 #ifndef QED_K6_WAVES
 #define QED_K6_WAVES 5
 #endif
-#ifndef QED_K7_WAVES
-#define QED_K7_WAVES 4
-#endif
 // quadrant waves at the end of a launch, in units of the device's wave slots for the kernel (see big_tiles())
 #ifndef QED_K6_SMALL
 #define QED_K6_SMALL 2.5
@@ -984,7 +981,7 @@ composite_bwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
     const int keep_all = (n_big_flags >> 30) << 2;
     const int n_big = n_big_flags & 0x3fffffff;
     if (tile_order != nullptr) {
-        // Costliest-first order (qed_tile_order from the forward pass's per-tile visit counts): workgroups are dispatched
+        // Costliest-first order (tile_order_body, from the forward pass's per-tile visit counts): workgroups are dispatched
         // in index order as wave slots free up, i.e. greedy longest-processing-time-first scheduling.  The first n_split
         // tiles of the order -- too heavy for one wave not to set the length of the launch -- are dealt as four quadrant
         // waves each, ahead of everything else.
@@ -1061,77 +1058,11 @@ depth_fixup_kernel(int n_pix, const float* __restrict__ alpha, float* __restrict
     }
 }
 
-// ---- costliest-first tile order for the backward launch ---------------------------------------------------------
-// Workgroups are dispatched in index order as wave slots free up, so handing the tiles out in order of decreasing cost is
-// greedy longest-processing-time-first scheduling: the end of the launch is filled with the cheapest tiles instead of with
-// whatever the image's corner holds.  The cost is the forward pass's own count of (Gaussian, quadrant) visits on the tile
-// (qed_composite_fwd's tile_cost), which the backward pass repeats within a per cent; the sorted list's length per tile
-// is NOT a usable predictor (culling and early termination decide).  Measured at config B: 336 -> 293 us.
-// One workgroup: counting sort on min(cost, 4095), descending (order inside a bucket is arbitrary: it only permutes the
-// order of the float atomics, which is arbitrary anyway).  order[n_tiles] receives n_split = the number of leading tiles
-// whose cost exceeds `split_factor` x (total cost / wave slots): a single wave on such a tile would set the length of the
-// launch by itself, so the kernel deals them as four quadrant waves each.
-constexpr int kCostBuckets = 4096;
-constexpr int kOrderRegs = 8;                             // tiles per thread held in registers (8 192 tiles: 1080p has 8 160)
+// ---- costliest-first tile order for the backward launch: tile_order_body (qed_common.h) as a launch of its own --------
 __global__ void __launch_bounds__(1024)
-tile_order_kernel(const int* __restrict__ cost4, int n_tiles, int* __restrict__ order, float split_factor, int slots,
-                  int max_split) {
-    __shared__ int hist[kCostBuckets];
-    __shared__ int wave_tot[16];
-    __shared__ long long total_s;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    auto cost_of = [&](int i) { const int4 c4 = reinterpret_cast<const int4*>(cost4)[i]; return c4.x + c4.y + c4.z + c4.w; };
-    auto bucket_of = [](int c) { return kCostBuckets - 1 - min(c, kCostBuckets - 1); };          // bucket 0 = the costliest
-    // the first kOrderRegs x 1024 tiles stay in registers between the two passes (all of them at 1080p): their loads are
-    // requested together, one memory round trip for the whole kernel; larger grids re-read the rest from L2
-    int creg[kOrderRegs];
-#pragma unroll
-    for (int j = 0; j < kOrderRegs; ++j) {
-        const int i = tid + 1024 * j;
-        creg[j] = cost_of(i < n_tiles ? i : 0);
-    }
-    for (int i = tid; i < kCostBuckets; i += 1024) hist[i] = 0;
-    if (tid == 0) total_s = 0;
-    __syncthreads();
-    long long mine = 0;
-#pragma unroll
-    for (int j = 0; j < kOrderRegs; ++j)
-        if (tid + 1024 * j < n_tiles) { mine += creg[j]; atomicAdd(&hist[bucket_of(creg[j])], 1); }
-    for (int i = tid + 1024 * kOrderRegs; i < n_tiles; i += 1024) {
-        const int c = cost_of(i);
-        mine += c;
-        atomicAdd(&hist[bucket_of(c)], 1);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
-    if (lane == 0) atomicAdd((unsigned long long*)&total_s, (unsigned long long)mine);
-    __syncthreads();
-    // exclusive scan of the 4096 counts: four per thread, wave scan, wave totals
-    int c[4], sum = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { c[j] = hist[4 * tid + j]; sum += c[j]; }
-    int x = sum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-    if (lane == 63) wave_tot[wid] = x;
-    __syncthreads();
-    int base = x - sum;
-    for (int w = 0; w < wid; ++w) base += wave_tot[w];
-    // n_split: tiles in the buckets above the threshold (threshold in cost units -> bucket index)
-    const float per_slot = (float)total_s / (float)max(slots, 1);
-    const int thr = (int)fminf(split_factor * per_slot, (float)(kCostBuckets - 1));
-    const int first_light = kCostBuckets - 1 - thr;       // buckets [0, first_light) hold cost > thr
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (4 * tid + j == first_light) order[n_tiles] = min(base, max_split);
-        hist[4 * tid + j] = base;
-        base += c[j];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < kOrderRegs; ++j)
-        if (tid + 1024 * j < n_tiles) order[atomicAdd(&hist[bucket_of(creg[j])], 1)] = tid + 1024 * j;
-    for (int i = tid + 1024 * kOrderRegs; i < n_tiles; i += 1024) order[atomicAdd(&hist[bucket_of(cost_of(i))], 1)] = i;
+tile_order_kernel(TileOrderJob job) {
+    __shared__ __attribute__((aligned(8))) int lds[kOrderLdsInts];
+    tile_order_body<1024>(job, lds);
 }
 
 }  // namespace qed
@@ -1219,16 +1150,8 @@ extern "C" int qed_composite_fwd(int32_t C, int32_t N, const float* splats, cons
     return check_launch("qed_composite_fwd");
 }
 
-// at most an eighth of the tiles are split (the grid must be fixed before the count is known)
-static int max_split_tiles(long long grid) { return (int)(grid / 8); }
-
 static void launch_tile_order(const int32_t* tile_cost, long long grid, int32_t* order_ws, hipStream_t st) {
-    int dev = 0, n_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-        n_cu = 256;
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, tile_cost, (int)grid, order_ws, 1.0f,
-                       n_cu * 4 * QED_K7_WAVES, max_split_tiles(grid));
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, tile_order_job(tile_cost, grid, order_ws));
 }
 
 extern "C" int qed_composite_bwd(int32_t C, int32_t N, const float* splats, const int32_t* flatten_ids,
@@ -1260,7 +1183,11 @@ extern "C" int qed_composite_bwd(int32_t C, int32_t N, const float* splats, cons
     unsigned blocks = (unsigned)(n_big + 4 * (grid - n_big));
     const int* tile_order = nullptr;
     // a forced launch shape (test hook) keeps the plain tile order
-    if (tile_cost != nullptr && (launch_flags & 3) == 0) {
+    if (tile_cost != nullptr && (launch_flags & 3) == 0 && (launch_flags & QED_CL_ORDER_READY)) {
+        // order_ws already holds the order of THIS tile_cost: qed_ssim_fwd_step computed it as a passenger of its launch
+        tile_order = order_ws;
+        blocks = (unsigned)(grid + 3ll * max_split_tiles(grid));
+    } else if (tile_cost != nullptr && (launch_flags & 3) == 0) {
         // (Launched by the caller on a SECOND stream, beside the loss passes that sit between the two compositing kernels, the
         // ordering is off the critical path on paper; replayed from a hipGraph the fork / join cost more than its 10 us:
         // 1.002 against 0.992 ms per step, profiles/r05_negative_results.txt)

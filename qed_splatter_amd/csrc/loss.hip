@@ -75,32 +75,8 @@ __global__ void __launch_bounds__(256)
 loss_reduce_kernel(int n_pix, const float* __restrict__ render, const float* __restrict__ alpha,
                    const float* __restrict__ bg, const float* __restrict__ gt_rgb, const float* __restrict__ gt_depth,
                    const float* __restrict__ mask, float* __restrict__ sums) {
-    // rows 2 and 3 (the loss sums of pass 2): zeroed here for the fused SSIM-backward + gradient pass (ssim.hip), whose
-    // workgroups -- more than kLossMaxGrid at 1080p -- ADD their partials to slot (index mod this grid); the plain pass 2
-    // overwrites its slots
-    if (threadIdx.x == 0) { loss_part(sums, 2)[blockIdx.x] = 0.f; loss_part(sums, 3)[blockIdx.x] = 0.f; }
-    if constexpr (CH != 4) return;
-    float nv = 0.f;
-    float dmax = -3.0e38f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)n_pix; i += (size_t)gridDim.x * 256) {
-        const float d = render[4 * i + 3];
-        dmax = fmaxf(dmax, d);
-        const float m = mask ? mask[i] : 1.f;
-        const float dg = gt_depth[i] * m;
-        // the predicted depth is finite whenever the render is; NaN renders fail isfinite below
-        const float dp = d * m;
-        if (isfinite(dp) && isfinite(dg) && dg > 0.f) nv += 1.f;
-    }
-    nv = wave_sum(nv);
-    dmax = wave_max(dmax);
     __shared__ float s[2][4];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if (lane == 0) { s[0][wid] = nv; s[1][wid] = dmax; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        loss_part(sums, 0)[blockIdx.x] = s[0][0] + s[0][1] + s[0][2] + s[0][3];
-        loss_part(sums, 1)[blockIdx.x] = fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3]));
-    }
+    loss_reduce_body<CH, 256>((int)blockIdx.x, (int)gridDim.x, n_pix, render, gt_depth, mask, sums, s);
 }
 
 // Pass 2: gradients and the per-workgroup partials of the two loss sums.

@@ -244,6 +244,148 @@ __global__ void loss_finalize_kernel(int n_pix, int n_blocks, int has_depth, flo
                                      float depth_lambda, float* __restrict__ losses, const float* __restrict__ extra_sum,
                                      int extra_n, float extra_scale, float extra_offset, AdamTick tick);
 
+// ---- costliest-first tile order of the compositing backward (composite.hip's tile_order_kernel; ssim.hip carries it as
+// a passenger workgroup of the SSIM forward launch in the fused training step) -----------------------------------------
+// Workgroups are dispatched in index order as wave slots free up, so handing the tiles out in order of decreasing cost is
+// greedy longest-processing-time-first scheduling: the end of the launch is filled with the cheapest tiles instead of with
+// whatever the image's corner holds.  The cost is the forward pass's own count of (Gaussian, quadrant) visits on the tile
+// (qed_composite_fwd's tile_cost), which the backward pass repeats within a per cent; the sorted list's length per tile
+// is NOT a usable predictor (culling and early termination decide).  Measured at config B: 336 -> 293 us.
+// One workgroup of NT threads: counting sort on min(cost, 4095), descending (order inside a bucket is arbitrary: it only
+// permutes the order of the float atomics, which is arbitrary anyway).  order[n_tiles] receives n_split = the number of
+// leading tiles whose cost exceeds `split_factor` x (total cost / wave slots): a single wave on such a tile would set the
+// length of the launch by itself, so the kernel deals them as four quadrant waves each.
+#ifndef QED_K7_WAVES
+#define QED_K7_WAVES 4                                    // waves per SIMD the compositing backward is built for
+#endif
+constexpr int kCostBuckets = 4096;
+constexpr int kOrderLdsInts = kCostBuckets + 16 + 2;      // LDS a caller provides: histogram, wave totals, the 64-bit total
+struct TileOrderJob {
+    const int* cost4;       // [n_tiles][4] (NULL: no job)
+    int n_tiles;
+    int* order;             // [n_tiles + 1]
+    float split_factor;
+    int slots;              // wave slots of the backward launch
+    int max_split;
+};
+// at most an eighth of the tiles are split (the grid must be fixed before the count is known)
+inline int max_split_tiles(long long grid) { return (int)(grid / 8); }
+
+template <int NT>
+__device__ __forceinline__ void tile_order_body(const TileOrderJob& job, int* __restrict__ lds) {
+    static_assert(NT % 64 == 0 && NT <= 1024 && kCostBuckets % NT == 0, "workgroup size");
+    constexpr int kRegs = 8;                              // tiles per thread held in registers between the passes: all of 1080p's
+                                                          // 8 160 for the 1 024-thread launch, the first 2 048 for a 256-thread passenger
+    constexpr int kPer = kCostBuckets / NT;               // histogram counts per thread in the scan
+    int* hist = lds;
+    int* wave_tot = lds + kCostBuckets;
+    long long* total_s = reinterpret_cast<long long*>(lds + kCostBuckets + 16);
+    const int* __restrict__ cost4 = job.cost4;
+    int* __restrict__ order = job.order;
+    const int n_tiles = job.n_tiles;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    auto cost_of = [&](int i) { const int4 c4 = reinterpret_cast<const int4*>(cost4)[i]; return c4.x + c4.y + c4.z + c4.w; };
+    auto bucket_of = [](int c) { return kCostBuckets - 1 - min(c, kCostBuckets - 1); };          // bucket 0 = the costliest
+    // the first 8 NT tiles stay in registers between the two passes: their loads are requested together, one memory round
+    // trip; the rest are re-read from L2 in the second pass
+    int creg[kRegs];
+#pragma unroll
+    for (int j = 0; j < kRegs; ++j) {
+        const int i = tid + NT * j;
+        creg[j] = cost_of(i < n_tiles ? i : 0);
+    }
+    for (int i = tid; i < kCostBuckets; i += NT) hist[i] = 0;
+    if (tid == 0) total_s[0] = 0;
+    __syncthreads();
+    long long mine = 0;
+#pragma unroll
+    for (int j = 0; j < kRegs; ++j)
+        if (tid + NT * j < n_tiles) { mine += creg[j]; atomicAdd(&hist[bucket_of(creg[j])], 1); }
+    for (int i = tid + NT * kRegs; i < n_tiles; i += NT) {
+        const int c = cost_of(i);
+        mine += c;
+        atomicAdd(&hist[bucket_of(c)], 1);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if (lane == 0) atomicAdd((unsigned long long*)total_s, (unsigned long long)mine);
+    __syncthreads();
+    // exclusive scan of the 4096 counts: kPer per thread, wave scan, wave totals
+    int c[kPer], sum = 0;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) { c[j] = hist[kPer * tid + j]; sum += c[j]; }
+    int x = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    if (lane == 63) wave_tot[wid] = x;
+    __syncthreads();
+    int base = x - sum;
+    for (int w = 0; w < wid; ++w) base += wave_tot[w];
+    // n_split: tiles in the buckets above the threshold (threshold in cost units -> bucket index)
+    const float per_slot = (float)total_s[0] / (float)max(job.slots, 1);
+    const int thr = (int)fminf(job.split_factor * per_slot, (float)(kCostBuckets - 1));
+    const int first_light = kCostBuckets - 1 - thr;       // buckets [0, first_light) hold cost > thr
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        if (kPer * tid + j == first_light) order[n_tiles] = min(base, job.max_split);
+        hist[kPer * tid + j] = base;
+        base += c[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kRegs; ++j)
+        if (tid + NT * j < n_tiles) order[atomicAdd(&hist[bucket_of(creg[j])], 1)] = tid + NT * j;
+    for (int i = tid + NT * kRegs; i < n_tiles; i += NT) order[atomicAdd(&hist[bucket_of(cost_of(i))], 1)] = i;
+}
+
+// ---- pass 1 of the fused image loss (loss.hip's loss_reduce_kernel; ssim.hip carries it as passenger workgroups of the
+// SSIM forward launch in the fused training step): workgroup `block` of `n_blocks` -------------------------------------
+// Only what must be known BEFORE a gradient can be written: the number of valid depth pixels (its reciprocal scales every
+// depth gradient) and the largest rendered depth (the value alpha == 0 pixels take, model.py:306).  It reads the depth
+// channel, the ground-truth depth and the mask -- not the colours.  s: [2][NT / 64] floats of LDS.
+template <int CH, int NT>
+__device__ __forceinline__ void loss_reduce_body(int block, int n_blocks, int n_pix, const float* __restrict__ render,
+                                                 const float* __restrict__ gt_depth, const float* __restrict__ mask,
+                                                 float* __restrict__ sums, float (*s)[NT / 64]) {
+    // rows 2 and 3 (the loss sums of pass 2): zeroed here for the fused SSIM-backward + gradient pass (ssim.hip), whose
+    // workgroups -- more than kLossMaxGrid at 1080p -- ADD their partials to slot (index mod this grid); the plain pass 2
+    // overwrites its slots
+    if (threadIdx.x == 0) { loss_part(sums, 2)[block] = 0.f; loss_part(sums, 3)[block] = 0.f; }
+    if constexpr (CH != 4) return;
+    float nv = 0.f;
+    float dmax = -3.0e38f;
+    for (size_t i = (size_t)block * NT + threadIdx.x; i < (size_t)n_pix; i += (size_t)n_blocks * NT) {
+        const float d = render[4 * i + 3];
+        dmax = fmaxf(dmax, d);
+        const float m = mask ? mask[i] : 1.f;
+        const float dg = gt_depth[i] * m;
+        // the predicted depth is finite whenever the render is; NaN renders fail isfinite below
+        const float dp = d * m;
+        if (isfinite(dp) && isfinite(dg) && dg > 0.f) nv += 1.f;
+    }
+    nv = wave_sum(nv);
+    dmax = wave_max(dmax);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { s[0][wid] = nv; s[1][wid] = dmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tn = 0.f, tm = -3.0e38f;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) { tn += s[0][w]; tm = fmaxf(tm, s[1][w]); }
+        loss_part(sums, 0)[block] = tn;
+        loss_part(sums, 1)[block] = tm;
+    }
+}
+
+// the job of one backward launch over `grid` tiles on this device (host side; asked of the runtime at every call)
+inline TileOrderJob tile_order_job(const int* tile_cost, long long grid, int* order_ws) {
+    int dev = 0, n_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+        n_cu = 256;
+    return TileOrderJob{tile_cost, (int)grid, order_ws, 1.0f, n_cu * 4 * QED_K7_WAVES, max_split_tiles(grid)};
+}
+
 // grid of the two streaming loss passes (pass 2 reads pass 1's per-workgroup partials by index)
 inline unsigned loss_reduce_grid(long long n_pix) {
     long long g = (n_pix + 255) / 256;

@@ -74,6 +74,13 @@ __device__ __forceinline__ float pred_at(const float* __restrict__ pred, const f
 
 struct __attribute__((packed, aligned(4))) Float3 { float a, b, c; };
 
+// pass 1 of the image loss as passenger workgroups of the SSIM forward launch (see ssim_fwd_kernel)
+struct LossReduceJob {
+    const float* gt_depth;
+    float* sums;
+    int n_pix, channels, n_blocks;      // n_blocks == 0: no job
+};
+
 // 4 adjacent window sums of a row: out[o] = sum_d w[d] v[o + d], o = 0..3, from 14 consecutive inputs
 __device__ __forceinline__ float4 window4(const float (&v)[16], const float (&w)[kWin]) {
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -106,16 +113,40 @@ __attribute__((amdgpu_waves_per_eu(COMPOSITE ? QED_SSIM_FWD_WAVES : QED_SSIM_FWD
                                    COMPOSITE ? QED_SSIM_FWD_WAVES : QED_SSIM_FWD_PLAIN_WAVES)))
 ssim_fwd_kernel(int H, int W, int channels, const float* __restrict__ pred, const float* __restrict__ alpha,
                 const float* __restrict__ bg, const float* __restrict__ gt, const float* __restrict__ mask,
-                float* __restrict__ maps, float* __restrict__ ssim_sum) {
+                float* __restrict__ maps, float* __restrict__ ssim_sum, TileOrderJob order_job, LossReduceJob reduce_job) {
     constexpr int TW = T::TW, PW = T::PW, PH = T::PH, SP = T::SP, SH = T::SH, CB = T::CB;
     __shared__ __attribute__((aligned(16))) float s_x[PH * SP], s_y[PH * SP];
     __shared__ __attribute__((aligned(16))) float s_h[4][PH * SH];
     __shared__ float s_red[T::NW];
+    // PASSENGERS (the fused training step, qed_ssim_fwd_step): launches of their own on the critical chain otherwise.
+    //  * workgroup 0 sorts the compositing backward's tiles by the cost the forward pass counted (a one-workgroup job,
+    //    ~10 us in front of that kernel);
+    //  * the LAST reduce_job.n_blocks workgroups are pass 1 of the image loss (valid-depth count and largest depth of the
+    //    render this launch reads anyway; ~9 us): streaming work that runs while the SSIM workgroups of the second
+    //    generation are in their compute phases.
+    // The SSIM workgroups are the indices in between.
+    const int has_job = order_job.cost4 != nullptr ? 1 : 0;
+    if (has_job && blockIdx.x == 0) {
+        static_assert(sizeof(s_h) >= kOrderLdsInts * sizeof(int), "the ordering job's LDS fits the row-pass planes");
+        tile_order_body<T::NT>(order_job, reinterpret_cast<int*>(&s_h[0][0]));
+        return;
+    }
+    const int block_id = (int)blockIdx.x - has_job, n_blocks = (int)gridDim.x - has_job - reduce_job.n_blocks;
+    if (block_id >= n_blocks) {
+        float (*s2)[T::NW] = reinterpret_cast<float (*)[T::NW]>(&s_h[0][0]);
+        if (reduce_job.channels == 4)
+            loss_reduce_body<4, T::NT>(block_id - n_blocks, reduce_job.n_blocks, reduce_job.n_pix, pred, reduce_job.gt_depth, mask,
+                                       reduce_job.sums, s2);
+        else
+            loss_reduce_body<3, T::NT>(block_id - n_blocks, reduce_job.n_blocks, reduce_job.n_pix, pred, reduce_job.gt_depth, mask,
+                                       reduce_job.sums, s2);
+        return;
+    }
     const int Ho = H - kHalo, Wo = W - kHalo;
     // neighbouring blocks share 10-pixel halos: keep them on one XCD's L2 (workgroups are dealt round-robin
     // over the 8 XCDs, so a linear grid is remapped to give each XCD a contiguous run of blocks)
     const int nbx = (Wo + TW - 1) / TW;
-    const int blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int blk = xcd_remap(block_id, n_blocks);
     const int by = blk / nbx, bx = blk - by * nbx;
     const int ox = bx * TW, oy = by * T::TH;                            // origin in the SSIM map
     const int tid = threadIdx.x;
@@ -262,7 +293,7 @@ ssim_fwd_kernel(int H, int W, int channels, const float* __restrict__ pred, cons
         float tot = 0.f;
 #pragma unroll
         for (int q = 0; q < T::NW; ++q) tot += s_red[q];
-        ssim_sum[blockIdx.x] = tot;
+        ssim_sum[block_id] = tot;
     }
 }
 
@@ -557,21 +588,51 @@ extern "C" int64_t qed_ssim_maps_floats(int32_t height, int32_t width) {
     return 9ll * (height - kHalo) * (width - kHalo);
 }
 
-extern "C" int qed_ssim_fwd(int32_t height, int32_t width, int32_t channels, const float* pred, const float* alpha,
-                            const float* background, const float* gt_rgb, const float* mask, float* maps,
-                            float* ssim_sum, void* stream) {
+static int ssim_fwd_launch(int32_t height, int32_t width, int32_t channels, const float* pred, const float* alpha,
+                           const float* background, const float* gt_rgb, const float* mask, float* maps,
+                           float* ssim_sum, const TileOrderJob& job, const LossReduceJob& rjob, void* stream,
+                           const char* who) {
     QED_REQUIRE(height > kHalo && width > kHalo, "image smaller than the 11 x 11 SSIM window");
     QED_REQUIRE(pred && gt_rgb && ssim_sum, "null buffers");
     QED_REQUIRE(alpha == nullptr || (background && (channels == 3 || channels == 4)), "composite mode needs a background");
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(((width - kHalo + Tile::TW - 1) / Tile::TW) * ((height - kHalo + Tile::TH - 1) / Tile::TH));
+    const dim3 grid(((width - kHalo + Tile::TW - 1) / Tile::TW) * ((height - kHalo + Tile::TH - 1) / Tile::TH) +
+                    (job.cost4 != nullptr ? 1 : 0) + rjob.n_blocks);
 #define QED_SSIM_FWD(COMP, MASK, CHN)                                                                               \
     hipLaunchKernelGGL((ssim_fwd_kernel<COMP, MASK, Tile>), grid, dim3(Tile::NT), 0, st, height, width, CHN, pred, alpha,   \
-                       background, gt_rgb, mask, maps, ssim_sum)
+                       background, gt_rgb, mask, maps, ssim_sum, job, rjob)
     if (alpha != nullptr) { if (mask) QED_SSIM_FWD(true, true, channels); else QED_SSIM_FWD(true, false, channels); }
     else { if (mask) QED_SSIM_FWD(false, true, 3); else QED_SSIM_FWD(false, false, 3); }
 #undef QED_SSIM_FWD
-    return check_launch("qed_ssim_fwd");
+    return check_launch(who);
+}
+
+extern "C" int qed_ssim_fwd(int32_t height, int32_t width, int32_t channels, const float* pred, const float* alpha,
+                            const float* background, const float* gt_rgb, const float* mask, float* maps,
+                            float* ssim_sum, void* stream) {
+    return ssim_fwd_launch(height, width, channels, pred, alpha, background, gt_rgb, mask, maps, ssim_sum,
+                           TileOrderJob{nullptr, 0, nullptr, 0.f, 0, 0}, LossReduceJob{nullptr, nullptr, 0, 0, 0}, stream,
+                           "qed_ssim_fwd");
+}
+
+// qed_ssim_fwd of the fused training step, with its passengers (see ssim_fwd_kernel): the costliest-first tile order of the
+// compositing backward that follows (tile_cost != NULL) and pass 1 of the image loss = qed_loss_reduce (sums != NULL)
+extern "C" int qed_ssim_fwd_step(int32_t height, int32_t width, int32_t channels, const float* render, const float* alpha,
+                                 const float* background, const float* gt_rgb, const float* mask, float* maps,
+                                 float* ssim_sum, const int32_t* tile_cost, int64_t n_tiles, int32_t* order_ws,
+                                 const float* gt_depth, float* sums, void* stream) {
+    QED_REQUIRE(alpha != nullptr, "the training step's render (composite mode)");
+    QED_REQUIRE((tile_cost == nullptr) == (order_ws == nullptr), "tile_cost and order_ws go together");
+    QED_REQUIRE(tile_cost == nullptr || (n_tiles >= 1 && n_tiles < (1ll << 29)), "the tile count");
+    QED_REQUIRE(((uintptr_t)tile_cost & 15) == 0, "tile_cost must be 16-byte aligned");
+    QED_REQUIRE(sums == nullptr || channels == 3 || gt_depth, "gt_depth required with a depth channel");
+    const int n_pix = height * width;
+    const TileOrderJob job = tile_cost != nullptr ? tile_order_job(tile_cost, n_tiles, order_ws)
+                                                  : TileOrderJob{nullptr, 0, nullptr, 0.f, 0, 0};
+    const LossReduceJob rjob = sums != nullptr ? LossReduceJob{gt_depth, sums, n_pix, channels, (int)loss_reduce_grid(n_pix)}
+                                               : LossReduceJob{nullptr, nullptr, 0, 0, 0};
+    return ssim_fwd_launch(height, width, channels, render, alpha, background, gt_rgb, mask, maps, ssim_sum, job, rjob, stream,
+                           "qed_ssim_fwd_step");
 }
 
 extern "C" int qed_ssim_bwd(int32_t height, int32_t width, int32_t channels, const float* pred, const float* alpha,

@@ -24,6 +24,7 @@ Two ways to run a training step:
 from __future__ import annotations
 
 import math
+import os
 import weakref
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Union
@@ -434,7 +435,7 @@ class _FusedImageLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, render, alpha, background, gt_rgb, gt_depth, mask, ssim_lambda, depth_lambda, vsplat_holder=None,
-                vsplat_rows=0, tick=None):
+                vsplat_rows=0, tick=None, tile_cost=None):
         import ctypes
         lib = L.load()
         ctx.set_materialize_grads(False)
@@ -448,7 +449,6 @@ class _FusedImageLoss(torch.autograd.Function):
         v_alpha = torch.empty_like(alpha)
         st = _stream()
         args = (n_pix, CH, L.ptr(render), L.ptr(alpha), L.ptr(background), L.ptr(gt_rgb), L.ptr(gt_depth), L.ptr(mask))
-        L.check(lib.qed_loss_reduce(*args, L.ptr(sums), st), "qed_loss_reduce")
         if ssim_lambda > 0.0:
             # main = (1 - l) L1 + l (1 - SSIM): ONE launch forms the SSIM gradient w.r.t. the clamped colour and pushes
             # it, with the L1 part and the depth term, through the clamp / background composite (qed_loss_grad_ssim)
@@ -459,18 +459,33 @@ class _FusedImageLoss(torch.autograd.Function):
                 vsplat = torch.empty(vsplat_rows, L.VSPLAT_FLOATS, dtype=torch.float32, device=dev)
             maps = torch.empty(lib.qed_ssim_maps_floats(H, W), dtype=torch.float32, device=dev)
             ssum = torch.empty(lib.qed_ssim_sum_floats(H, W), dtype=torch.float32, device=dev)
-            L.check(lib.qed_ssim_fwd(H, W, CH, L.ptr(render), L.ptr(alpha), L.ptr(background), L.ptr(gt_rgb),
-                                     L.ptr(mask), L.ptr(maps), L.ptr(ssum), st), "qed_ssim_fwd")
+            # The SSIM forward launch carries two passengers that would otherwise be launches of their own on the step's
+            # critical chain: pass 1 of the image loss (qed_loss_reduce: ~9 us) and -- the forward pass's per-tile costs
+            # are known by now -- the compositing backward's launch order (~10 us in front of that kernel).
+            order_ws = None
+            if vsplat_holder is not None and tile_cost is not None:
+                order_ws = torch.empty(tile_cost.shape[0] + 1, dtype=torch.int32, device=dev)
+            if os.environ.get("QED_STEP_PASSENGERS", "1") == "0":          # measurement hook: every job a launch of its own
+                L.check(lib.qed_loss_reduce(*args, L.ptr(sums), st), "qed_loss_reduce")
+                L.check(lib.qed_ssim_fwd(H, W, CH, L.ptr(render), L.ptr(alpha), L.ptr(background), L.ptr(gt_rgb),
+                                         L.ptr(mask), L.ptr(maps), L.ptr(ssum), st), "qed_ssim_fwd")
+                order_ws = None
+            else:
+                L.check(lib.qed_ssim_fwd_step(H, W, CH, L.ptr(render), L.ptr(alpha), L.ptr(background), L.ptr(gt_rgb),
+                                            L.ptr(mask), L.ptr(maps), L.ptr(ssum), L.ptr(tile_cost) if order_ws is not None else None,
+                                            tile_cost.shape[0] if order_ws is not None else 0, L.ptr(order_ws),
+                                            L.ptr(gt_depth), L.ptr(sums), st), "qed_ssim_fwd_step")
             L.check(lib.qed_loss_grad_ssim(H, W, CH, L.ptr(render), L.ptr(alpha), L.ptr(background), L.ptr(gt_rgb),
                                            L.ptr(gt_depth), L.ptr(mask), L.ptr(maps), L.ptr(sums), 1.0 - ssim_lambda,
                                            depth_lambda, -ssim_lambda / n_out, L.ptr(v_render), L.ptr(v_alpha),
                                            L.ptr(losses), L.ptr(ssum), ssum.numel(), ssim_lambda, L.ptr(vsplat),
                                            vsplat.numel() if vsplat is not None else 0,
                                            ctypes.addressof(tick) if tick is not None else None, st), "qed_loss_grad_ssim")
-            if vsplat is not None:
+            if vsplat is not None or order_ws is not None:
                 del vsplat_holder[:]
-                vsplat_holder.append(vsplat)
+                vsplat_holder.append({"vsplat": vsplat, "order_ws": order_ws})
         else:
+            L.check(lib.qed_loss_reduce(*args, L.ptr(sums), st), "qed_loss_reduce")
             L.check(lib.qed_loss_grad(*args, L.ptr(sums), 1.0, depth_lambda, L.ptr(v_render), L.ptr(v_alpha),
                                       L.ptr(losses), None, None, 0, 0.0, 0.0, st), "qed_loss_grad")
         ctx.save_for_backward(v_render, v_alpha)
@@ -482,13 +497,13 @@ class _FusedImageLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_total, _v_parts):
         if v_total is None:
-            return (None,) * 11
+            return (None,) * 12
         v_render, v_alpha = ctx.saved_tensors
         # the kernel wrote d(total)/d(render, alpha).  The usual upstream gradient is the cached unit tensor of
         # backward_fused() and needs no scaling pass; anything else (a weighted loss, a GradScaler) is applied
         if v_total.data_ptr() != _unit_grad(v_total.device).data_ptr():
             v_render, v_alpha = v_render * v_total, v_alpha * v_total
-        return v_render, v_alpha, None, None, None, None, None, None, None, None, None
+        return v_render, v_alpha, None, None, None, None, None, None, None, None, None, None
 
 
 def write_sh_grads(means: Tensor, viewmat: Tensor, sh_degree: int, v_color: Tensor, v_rest: Tensor) -> None:
@@ -1266,9 +1281,12 @@ class QEDSplatterModel(nn.Module):
             self.xys = self.info["means2d"]
             self.radii = self.info["radii"][0]
             self.last_viewmat, self.last_sh_degree = viewmat, deg
+            # (the compositing node keeps the forward pass's per-tile costs: the loss launch sorts them for its backward)
+            tile_cost = getattr(render.grad_fn, "tile_cost", None) if torch.is_grad_enabled() else None
             total, parts = _FusedImageLoss.apply(render, alpha, bg.contiguous(), gt_rgb, gt_depth, mask,
                                                  float(cfg.ssim_lambda), cfg.depth_lambda,
-                                                 holder if torch.is_grad_enabled() else None, self.num_points, tick)
+                                                 holder if torch.is_grad_enabled() else None, self.num_points, tick,
+                                                 tile_cost)
         except BaseException:
             # the launch that would have advanced the optimiser's device step state did not happen: the optimiser
             # must tick for itself on the next step (otherwise its counter would be off by one from here on)

@@ -620,12 +620,18 @@ class _Composite(torch.autograd.Function):
         # the fused loss launch may already have zeroed an accumulator for this backward pass (model.fused_loss hands it
         # over through the holder; taken once -- a second backward through a retained graph makes its own)
         holder = ctx.vsplat_holder
-        vsplat = holder.pop() if holder else None
+        handed = holder.pop() if holder else None
+        # (the fused loss launch hands over the zeroed accumulator and, when its SSIM pass carried the ordering job, the
+        # launch order of THIS forward pass's tile costs: a dict; older callers hand over the accumulator alone)
+        vsplat, order_ws = (handed.get("vsplat"), handed.get("order_ws")) if isinstance(handed, dict) else (handed, None)
         if vsplat is None or vsplat.shape != (C * N, R) or vsplat.device != dev or vsplat.dtype != torch.float32:
             vsplat = torch.zeros(C * N, R, dtype=torch.float32, device=dev)
         tile_cost = ctx.tile_cost
         flags = L.composite_launch_flags()
-        order_ws = torch.empty(C * tile_w * tile_h + 1, dtype=torch.int32, device=dev) if tile_cost is not None else None
+        if order_ws is not None and tile_cost is not None and order_ws.numel() == C * tile_w * tile_h + 1 and (flags & 3) == 0:
+            flags |= L.CL_ORDER_READY
+        else:
+            order_ws = torch.empty(C * tile_w * tile_h + 1, dtype=torch.int32, device=dev) if tile_cost is not None else None
         L.check(lib.qed_composite_bwd(C, N, L.ptr(splats), L.ptr(flatten_ids), L.ptr(offsets), width, height, tile_w,
                                       tile_h, channels, L.ptr(bg), L.ptr(alpha), L.ptr(t_final), L.ptr(last_ids),
                                       L.ptr(v_render) if post is None else None, L.ptr(v_alpha) if post is None else None,

@@ -1578,9 +1578,74 @@ def test_backward_tile_order_is_costliest_first_and_changes_no_gradient(cuda, li
     assert n_split == want_split, (n_split, want_split, per_slot)
     scale = float(outs[0].abs().max())
     assert scale > 0 and float((outs[0] - outs[1]).abs().max()) <= 2e-5 * scale
+    # the same order as a PASSENGER of the SSIM forward launch (the fused training step: qed_ssim_fwd_step), handed to the
+    # backward kernel with QED_CL_ORDER_READY: same keys along the order, same split count, same gradients -- and the SSIM
+    # outputs of that launch equal the plain launch's bit for bit
+    gt = torch.rand(h, w, 3, generator=g).to(cuda)
+    bgc = torch.zeros(3, device=cuda)
+    def ssim(order_out):
+        maps = torch.empty(int(lib.qed_ssim_maps_floats(h, w)), device=cuda)
+        ssum = torch.empty(int(lib.qed_ssim_sum_floats(h, w)), device=cuda)
+        common = (h, w, 4, L.ptr(render), L.ptr(alpha), L.ptr(bgc), L.ptr(gt), None, L.ptr(maps), L.ptr(ssum))
+        if order_out is None:
+            L.check(lib.qed_ssim_fwd(*common, st), "ssim")
+        else:
+            # (with both passengers: the ordering job and pass 1 of the image loss)
+            L.check(lib.qed_ssim_fwd_step(*common, L.ptr(cost), T, L.ptr(order_out), L.ptr(gt_d), L.ptr(sums1), st), "ssim step")
+        return maps, ssum
+    order2 = torch.full((T + 1,), -1, dtype=torch.int32, device=cuda)
+    gt_d = (torch.rand(h, w, generator=g) * 10).to(cuda)
+    gt_d[::7, ::5] = 0.0                                                # invalid ground-truth depths
+    sums0 = torch.full((L.LOSS_SUMS_FLOATS,), 7.0, device=cuda)
+    sums1 = torch.full((L.LOSS_SUMS_FLOATS,), 7.0, device=cuda)
+    L.check(lib.qed_loss_reduce(h * w, 4, L.ptr(render), L.ptr(alpha), L.ptr(bgc), L.ptr(gt), L.ptr(gt_d), None, L.ptr(sums0),
+                                st), "loss_reduce")
+    m0, s0 = ssim(None)
+    m1, s1 = ssim(order2)
+    assert torch.equal(m0, m1) and torch.equal(s0, s1)
+    assert torch.equal(sums0, sums1)                                   # the passenger IS qed_loss_reduce, slot for slot
+    o2 = order2[:T].cpu().long()
+    assert sorted(o2.tolist()) == list(range(T)) and int(order2[T]) == n_split
+    assert torch.equal(c.clamp(max=4095)[o2], key)                     # (the order inside a cost bucket is free)
+    vs = torch.zeros(n, L.VSPLAT_FLOATS, device=cuda)
+    poison = order2.clone()
+    L.check(lib.qed_composite_bwd(1, n, L.ptr(splats), L.ptr(fid), L.ptr(offs), w, h, tw, th, 4, None, L.ptr(alpha),
+                                  None, L.ptr(last), L.ptr(v_r), L.ptr(v_a), L.ptr(vs), L.ptr(cost), L.ptr(order2), None,
+                                  L.CL_ORDER_READY, st), "bwd, order ready")
+    assert torch.equal(order2, poison)                                 # the kernel used it and did not recompute it
+    assert float((vs - outs[0]).abs().max()) <= 2e-5 * scale
     with pytest.raises(L.QedSplatError):                               # the two buffers go together
         L.check(lib.qed_composite_bwd(1, n, L.ptr(splats), L.ptr(fid), L.ptr(offs), w, h, tw, th, 4, None, L.ptr(alpha),
                                       None, L.ptr(last), L.ptr(v_r), L.ptr(v_a), L.ptr(outs[0]), L.ptr(cost), None, None, 0, st), "bwd")
+
+
+def test_fused_step_hands_the_backward_its_tile_order(cuda):
+    """model.fused_loss: the SSIM forward launch carries the ordering job, the compositing backward receives that order
+    (no ordering launch of its own) -- the node keeps it for inspection."""
+    from qed_splatter_amd.model import PinholeCameras, QEDSplatterModel, QEDSplatterModelConfig
+    w, h, n = 320, 208, 6000
+    sc = scene(n, w, h, seed=9)
+    cfg = QEDSplatterModelConfig.synthetic(sh_degree=3, sh_degree_interval=1)
+    K = sc["Ks"][0]
+    cam = PinholeCameras(sc["camera_to_worlds"].to(cuda), float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), w, h)
+    batch = {"image": sc["gt_rgb"].to(cuda), "depth_image": sc["gt_depth"].to(cuda)}
+    model = QEDSplatterModel(cfg, **{k: sc[k].to(cuda) for k in PARAM_NAMES})
+    model.step = 3
+    out = model.fused_loss(cam, batch)
+    node = out["loss"].grad_fn.next_functions[0][0]
+    holder = node.vsplat_holder
+    assert holder and isinstance(holder[0], dict) and holder[0]["order_ws"] is not None
+    handed = holder[0]["order_ws"]
+    model.backward_fused(out)
+    assert node.order_ws is handed                                     # taken over, not recomputed
+    T = node.tile_cost.shape[0]
+    c = node.tile_cost.sum(dim=1).cpu().clamp(max=4095)
+    order = handed[:T].cpu().long()
+    assert sorted(order.tolist()) == list(range(T))
+    key = c[order]
+    assert bool((key[1:] <= key[:-1]).all())
+    assert all(model.gauss_params[k].grad is not None and bool(torch.isfinite(model.gauss_params[k].grad).all())
+               for k in PARAM_NAMES if k != "features_rest")
 
 
 @pytest.mark.parametrize("tight", [True, False])
