@@ -450,6 +450,9 @@ def main():
         opt.set_lr("means", opt._means_lr_init)
 
     dp_compact = not args.dp_plain and not args.plain_adam
+    # every rank renders ONE fixed camera step after step: the compositing forward takes its launch order from the previous
+    # frame of that camera (model.fused_loss, frame_key); QED_BENCH_FRAME_KEY=0 is the A/B switch
+    FRAME_KEY = None if os.environ.get("QED_BENCH_FRAME_KEY", "1") == "0" else 0
     fused_sh = dp_compact
     # N > 1: row capacity of the sparse colour-gradient message, agreed by all ranks after the first step (None: the dense
     # message is no larger -- SURVEY 8d's scene is 95 % visible; QED_BENCH_DP_SPARSE=1 forces the sparse form for rehearsals)
@@ -481,7 +484,7 @@ def main():
     def step(sync):
         for p in model.parameters():
             p.grad = None
-        losses = model.fused_loss(cam, batch, background=bg, sync=sync, compact_sh_grad=dp_compact)
+        losses = model.fused_loss(cam, batch, background=bg, sync=sync, compact_sh_grad=dp_compact, frame_key=FRAME_KEY)
         model.backward_fused(losses)
         if multi:
             exchange_and_step(lambda: opt.step(fused_sh=True, part=1), lambda: opt.step(fused_sh=True, part=2),
@@ -562,7 +565,7 @@ def main():
             for p in model.parameters():
                 p.grad = None
             losses = model.fused_loss(cam, batch, background=bg, sync=False, compact_sh_grad=dp_compact,
-                                      optimizer=tick_for)
+                                      optimizer=tick_for, frame_key=FRAME_KEY)
             model.backward_fused(losses)
             return losses
 
@@ -613,7 +616,8 @@ def main():
                 def dp_step():
                     for p in model.parameters():
                         p.grad = None
-                    losses = model.fused_loss(cam, batch, background=bg, sync=False, compact_sh_grad=True, optimizer=opt)
+                    losses = model.fused_loss(cam, batch, background=bg, sync=False, compact_sh_grad=True, optimizer=opt,
+                                              frame_key=FRAME_KEY)
                     if one_graph_env == "1":                 # the gather ahead of the projection backward
                         P.backward_with_early_gather(model, losses, world)
                     else:
@@ -835,6 +839,10 @@ def main():
                                    f"depth-L1 + (0.8 L1 + 0.2 (1-SSIM)) RGB loss + fused Adam",
                        "gaussians": n, "visible": n_vis, "intersections": M, "intersections_after_timed_steps": M_end,
                        "intersections_reference_list": M_ref,
+                       "forward_launch_order": "costliest tiles first, from the work counts of the PREVIOUS frame of the same "
+                                               "camera (frame_key; a scheduling hint: images and gradients unchanged; "
+                                               "QED_BENCH_FRAME_KEY=0 turns it off: raster order + quadrant tail)"
+                                               if FRAME_KEY is not None else "raster order + a tail of quadrant waves",
                        "tile_lists": "exact (the tiles of the 3-sigma square in which some pixel can reach alpha >= 1/255; "
                                      "images and gradients identical)" if cfg.tight_tile_lists else "gsplat 3-sigma squares",
                        "width": w, "height": h,

@@ -65,8 +65,9 @@ extern "C" {
  *   1  rounds 1-3.
  *   2  round 4: qed_composite_fwd / qed_composite_bwd gained `t_final` in the middle of their argument lists; the row of
  *      the compact data-parallel message grew from 3 N + 16 to 3 N + 20 floats (still reported as 1 by that round's
- *      library).  A caller built against another version must not call further: the pointers would be shifted. */
-#define QED_ABI_VERSION 2
+ *      library).  A caller built against another version must not call further: the pointers would be shifted.
+ *   3  round 5: qed_composite_fwd gained `tile_order` behind `tile_cost`. */
+#define QED_ABI_VERSION 3
 int qed_version(void);   /* == QED_ABI_VERSION of the header the library was built from */
 const char* qed_last_error(void);
 
@@ -234,7 +235,12 @@ int qed_tile_offsets(const uint64_t* sorted_keys, const int32_t* n_dev, int64_t 
  * / _HALF_AND_HALF force one shape and QED_CL_NO_CULL turns the per-quadrant culling off -- results must
  * not change (parity tests).
  * tile_cost (may be NULL; [C*tiles][4] i32): receives, per tile and quadrant wave, the number of (Gaussian, quadrant)
- * visits + a staging term per batch -- the work predictor qed_composite_bwd orders its launch by. */
+ * visits + a staging term per batch -- the work predictor qed_composite_bwd orders its launch by.
+ * tile_order (may be NULL; [C * tiles + 1]): a launch order for THIS kernel -- the order_ws an ordering job (qed_ssim_fwd_step,
+ * or qed_composite_bwd's own) produced for an EARLIER frame of the same camera and tile grid.  The forward kernel cannot
+ * know its tiles' costs in advance (the list length does not predict them), an earlier frame's counts do: heaviest tiles
+ * first, 114-117 us against 122-126 at config B.  Must be a permutation of the tiles as those jobs write it (any valid
+ * order gives the same image; a poor predictor only costs time).  NULL: raster order with a tail of quadrant waves. */
 /* get_outputs' post-processing (model.py:295-297, 304-306) folded into the compositing kernels -- the reference-shaped route
  * then has no pass of its own over the image between the rasterizer and the loss, in either direction:
  *   qed_post_t (forward, may be NULL): rgb[C,H,W,3] = clamp(render[..., :3] + (1 - alpha) background[3], 0, 1) is written by
@@ -265,7 +271,7 @@ int qed_composite_fwd(int32_t C, int32_t N, const float* splats, const int32_t* 
                       const int32_t* offsets, int32_t width, int32_t height, int32_t tile_w,
                       int32_t tile_h, int32_t channels, const float* backgrounds, float* render,
                       float* alpha, float* t_final, int32_t* last_ids, int32_t* tile_cost,
-                      const qed_post_t* post, int32_t launch_flags, void* stream);
+                      const int32_t* tile_order, const qed_post_t* post, int32_t launch_flags, void* stream);
 
 /* ---- K7: alpha compositing backward ------------------------------------------------------------
  * Back-to-front replay from last_ids; per-pixel gradients are reduced across each 64-wide wave

@@ -37,7 +37,7 @@ SIGNATURES = {
     "qed_tile_offsets": (C.c_int, [_P, _P, _L, _I, _I, _I, _P, _P]),
     "qed_bin_workspace_bytes": (_L, [_L, _L]),
     "qed_bin_tiles": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P]),
-    "qed_composite_fwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "qed_composite_fwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "qed_composite_bwd": (C.c_int, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "qed_loss_reduce": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qed_loss_grad": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _I, _F, _F, _P]),
@@ -130,7 +130,7 @@ class QedSplatError(RuntimeError):
     pass
 
 
-ABI_VERSION = 2          # include/qed_splat.h: QED_ABI_VERSION (tests/test_abi.py checks the two against each other)
+ABI_VERSION = 3          # include/qed_splat.h: QED_ABI_VERSION (tests/test_abi.py checks the two against each other)
 
 
 def load():

@@ -553,12 +553,33 @@ composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
                      const int* __restrict__ offsets, int width, int height, int tile_w, int tile_h,
                      const float* __restrict__ backgrounds, float* __restrict__ render, float* __restrict__ alpha_out,
                      float* __restrict__ t_final, int* __restrict__ last_ids, int* __restrict__ tile_cost, int n_big_flags,
-                     FwdPost post) {
+                     FwdPost post, const int* __restrict__ tile_order) {
     __shared__ __attribute__((aligned(16))) float s_rec[kBatch][kRecFloats];
     const int n_total = C * tile_w * tile_h;
     const int b = blockIdx.x;
     const int keep_all = (n_big_flags >> 30) << 2;      // test hook, see quadrant_masks
     const int n_big = n_big_flags & 0x3fffffff;
+    if (tile_order != nullptr) {
+        // A costliest-first order handed in by the caller: the launch order the compositing BACKWARD of an earlier frame of
+        // the same camera was given (the forward pass's own work counts of that frame: they predict this frame's, and this
+        // kernel cannot know its costs in advance -- the list length does not predict them, corr -0.02 at config B).  As in
+        // composite_bwd_kernel: the n_split heaviest tiles as four quadrant waves each ahead of everything, then whole tiles
+        // in order of decreasing cost.  Any permutation gives the same image; a poor predictor only costs time.
+        // Measured at config B (scripts/k6_order_ab.py): 114-117 us against 122-126 with the raster order + quadrant tail.
+        const int n_split = min(max(tile_order[n_total], 0), n_total / 8);
+        if (b < 4 * n_split) {
+            fwd_tile<CH, 1>(min(max(tile_order[b >> 2], 0), n_total - 1), (b & 3) | keep_all, s_rec, C, splats, flatten_ids, offsets,
+                            width, height, tile_w, tile_h, backgrounds, render, alpha_out, t_final, last_ids, tile_cost, post);
+            return;
+        }
+        const int i = b - 3 * n_split;
+        if (i >= n_total) return;                        // (the grid is sized for the largest n_split the host allows)
+        // (ids clamped: a buffer that is not an order of THIS grid must not fault the device; the caller's contract is a
+        // permutation -- the image is wrong otherwise)
+        fwd_tile<CH, 4>(min(max(tile_order[i], 0), n_total - 1), keep_all, s_rec, C, splats, flatten_ids, offsets, width, height, tile_w, tile_h,
+                        backgrounds, render, alpha_out, t_final, last_ids, tile_cost, post);
+        return;
+    }
     if (b < n_big) {
         fwd_tile<CH, 4>(xcd_remap(b, n_total), keep_all, s_rec, C, splats, flatten_ids, offsets, width, height, tile_w,
                         tile_h, backgrounds, render, alpha_out, t_final, last_ids, tile_cost, post);
@@ -1112,7 +1133,7 @@ extern "C" int qed_composite_fwd(int32_t C, int32_t N, const float* splats, cons
                                  const int32_t* offsets, int32_t width, int32_t height, int32_t tile_w,
                                  int32_t tile_h, int32_t channels, const float* backgrounds, float* render,
                                  float* alpha, float* t_final, int32_t* last_ids, int32_t* tile_cost,
-                                 const qed_post_t* post, int32_t launch_flags, void* stream) {
+                                 const int32_t* tile_order, const qed_post_t* post, int32_t launch_flags, void* stream) {
     QED_REQUIRE(C >= 1 && N >= 0 && width > 0 && height > 0, "bad extents");
     QED_REQUIRE(channels == 3 || channels == 4, "channels must be 3 (RGB) or 4 (RGB+D)");
     QED_REQUIRE(tile_w == (width + QED_TILE - 1) / QED_TILE && tile_h == (height + QED_TILE - 1) / QED_TILE,
@@ -1130,15 +1151,21 @@ extern "C" int qed_composite_fwd(int32_t C, int32_t N, const float* splats, cons
     }
     hipStream_t st = (hipStream_t)stream;
     const long long n_big = big_tiles(grid, QED_K6_SMALL, QED_K6_WAVES, launch_flags);
-    const unsigned blocks = (unsigned)(n_big + 4 * (grid - n_big));
+    unsigned blocks = (unsigned)(n_big + 4 * (grid - n_big));
+    const int* fwd_order = nullptr;
+    // a forced launch shape (test hook) keeps the plain tile order
+    if (tile_order != nullptr && (launch_flags & 3) == 0) {
+        fwd_order = tile_order;
+        blocks = (unsigned)(grid + 3ll * max_split_tiles(grid));
+    }
     if (channels == 4)
         hipLaunchKernelGGL(composite_fwd_kernel<4>, dim3(blocks), dim3(64), 0, st, C, (const float4*)splats,
                            flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render, alpha, t_final, last_ids,
-                           tile_cost, (int)n_big | no_cull_flag(launch_flags), fp);
+                           tile_cost, (int)n_big | no_cull_flag(launch_flags), fp, fwd_order);
     else
         hipLaunchKernelGGL(composite_fwd_kernel<3>, dim3(blocks), dim3(64), 0, st, C, (const float4*)splats,
                            flatten_ids, offsets, width, height, tile_w, tile_h, backgrounds, render, alpha, t_final, last_ids,
-                           tile_cost, (int)n_big | no_cull_flag(launch_flags), fp);
+                           tile_cost, (int)n_big | no_cull_flag(launch_flags), fp, fwd_order);
     if (post != nullptr && channels == 4) {
         const long long n_pix = (long long)C * width * height;
         long long g = (n_pix / 4 + 255) / 256;

@@ -435,7 +435,7 @@ class _FusedImageLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, render, alpha, background, gt_rgb, gt_depth, mask, ssim_lambda, depth_lambda, vsplat_holder=None,
-                vsplat_rows=0, tick=None, tile_cost=None):
+                vsplat_rows=0, tick=None, tile_cost=None, order_buf=None):
         import ctypes
         lib = L.load()
         ctx.set_materialize_grads(False)
@@ -464,7 +464,9 @@ class _FusedImageLoss(torch.autograd.Function):
             # are known by now -- the compositing backward's launch order (~10 us in front of that kernel).
             order_ws = None
             if vsplat_holder is not None and tile_cost is not None:
-                order_ws = torch.empty(tile_cost.shape[0] + 1, dtype=torch.int32, device=dev)
+                # (the camera's persistent launch-order buffer when the caller keeps one: model.fused_loss, frame_key)
+                order_ws = order_buf if (order_buf is not None and order_buf.numel() == tile_cost.shape[0] + 1) else \
+                    torch.empty(tile_cost.shape[0] + 1, dtype=torch.int32, device=dev)
             if os.environ.get("QED_STEP_PASSENGERS", "1") == "0":          # measurement hook: every job a launch of its own
                 L.check(lib.qed_loss_reduce(*args, L.ptr(sums), st), "qed_loss_reduce")
                 L.check(lib.qed_ssim_fwd(H, W, CH, L.ptr(render), L.ptr(alpha), L.ptr(background), L.ptr(gt_rgb),
@@ -497,13 +499,13 @@ class _FusedImageLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_total, _v_parts):
         if v_total is None:
-            return (None,) * 12
+            return (None,) * 13
         v_render, v_alpha = ctx.saved_tensors
         # the kernel wrote d(total)/d(render, alpha).  The usual upstream gradient is the cached unit tensor of
         # backward_fused() and needs no scaling pass; anything else (a weighted loss, a GradScaler) is applied
         if v_total.data_ptr() != _unit_grad(v_total.device).data_ptr():
             v_render, v_alpha = v_render * v_total, v_alpha * v_total
-        return v_render, v_alpha, None, None, None, None, None, None, None, None, None, None
+        return v_render, v_alpha, None, None, None, None, None, None, None, None, None, None, None
 
 
 def write_sh_grads(means: Tensor, viewmat: Tensor, sh_degree: int, v_color: Tensor, v_rest: Tensor) -> None:
@@ -1212,11 +1214,19 @@ class QEDSplatterModel(nn.Module):
 
     # ---- fused training step: model.py:199-321 + 73-118 in as few passes as possible ----
     def fused_loss(self, camera, batch, background: Optional[Tensor] = None, sync: bool = True,
-                   compact_sh_grad: bool = False, optimizer: Optional["FlatAdam"] = None) -> Dict[str, Tensor]:
+                   compact_sh_grad: bool = False, optimizer: Optional["FlatAdam"] = None,
+                   frame_key=None) -> Dict[str, Tensor]:
         """Forward + K8 fused loss.  Returns {"loss", "main_loss", "depth_loss"}: ``loss`` = main + depth is
         the differentiable total (call ``.backward()`` on it as is: the kernel already wrote its gradient
         for an upstream gradient of 1); the two parts are detached views for logging.  Numerically the
-        same quantities as get_outputs + get_loss_dict."""
+        same quantities as get_outputs + get_loss_dict.
+
+        ``frame_key`` (hashable, optional): identifies the CAMERA this frame is rendered from -- the dataset's camera
+        index.  Frames under one key share a launch-order buffer: the order the loss launch computes for this frame's
+        compositing backward (from this frame's per-tile work counts) is what the NEXT frame under the same key hands
+        its compositing FORWARD kernel, which cannot know its costs in advance (heaviest tiles first: 114-117 us against
+        122-126 at config B).  A scheduling hint only: images and gradients do not depend on it.  Leave it None when
+        consecutive frames come from unrelated cameras and no index is at hand."""
         assert camera.shape[0] == 1, "Only one camera at a time"
         if self.__dict__.get("_lazy_sh") is not None and torch.is_grad_enabled():
             self._materialise_sh_grads()          # (compact gradients of a get_outputs step nobody consumed: see there)
@@ -1266,6 +1276,17 @@ class QEDSplatterModel(nn.Module):
         gt_depth = _f32_image(self.get_gt_img(batch["depth_image"]), H * W, "batch['depth_image']", self.device)
         mask = self._loss_mask(batch, (H, W))
         holder: list = []         # (the fused loss launch leaves the compositing backward's zeroed accumulator here)
+        # the launch-order buffer of this camera (see ``frame_key``): [C T + 1] int32, written by every training frame's
+        # loss launch, read by the next frame's compositing forward -- persistent, so that a captured step replays against it
+        frame_slot, frame_order, frame_order_valid = None, None, False
+        if frame_key is not None:
+            tiles = ((W + 15) // 16) * ((H + 15) // 16)
+            orders = self.__dict__.setdefault("_frame_orders", {})
+            frame_slot = orders.get((frame_key, H, W))
+            if frame_slot is None or frame_slot[0].device != self.device:
+                frame_slot = [torch.empty(tiles + 1, dtype=torch.int32, device=self.device), False]
+                orders[(frame_key, H, W)] = frame_slot
+            frame_order, frame_order_valid = frame_slot[0], frame_slot[1]
         # ``optimizer`` (a FlatAdam stepped with device_state=True, fused_sh=True right after this step's backward): the
         # loss pass's fold launch advances its device step state, so that the optimiser needs no launch of its own for it
         tick = None
@@ -1277,7 +1298,7 @@ class QEDSplatterModel(nn.Module):
                 viewmats=viewmat, Ks=K, width=W, height=H, tile_size=16, packed=False, near_plane=0.01, far_plane=1e10,
                 render_mode="RGB+D", sh_degree=deg, sparse_grad=False, absgrad=True,
                 rasterize_mode=cfg.rasterize_mode, _flags=flags, _sh_rest=sh_rest, _sync=sync, _vsplat_holder=holder,
-                _c2w=cam_c2w)
+                _c2w=cam_c2w, _tile_order=frame_order if frame_order_valid else None)
             self.xys = self.info["means2d"]
             self.radii = self.info["radii"][0]
             self.last_viewmat, self.last_sh_degree = viewmat, deg
@@ -1286,7 +1307,10 @@ class QEDSplatterModel(nn.Module):
             total, parts = _FusedImageLoss.apply(render, alpha, bg.contiguous(), gt_rgb, gt_depth, mask,
                                                  float(cfg.ssim_lambda), cfg.depth_lambda,
                                                  holder if torch.is_grad_enabled() else None, self.num_points, tick,
-                                                 tile_cost)
+                                                 tile_cost, frame_order)
+            if frame_slot is not None and tile_cost is not None and float(cfg.ssim_lambda) > 0.0 \
+                    and os.environ.get("QED_STEP_PASSENGERS", "1") != "0":
+                frame_slot[1] = True              # (the buffer holds an order from here on, in stream order)
         except BaseException:
             # the launch that would have advanced the optimiser's device step state did not happen: the optimiser
             # must tick for itself on the next step (otherwise its counter would be off by one from here on)

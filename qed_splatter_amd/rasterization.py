@@ -542,7 +542,8 @@ def _bin_and_sort(N, C, means2d, radii, depths, tiles_per_gauss, block_sums, til
 class _Composite(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means2d, conics, rgb, opac, depths, splats, flatten_ids, offsets, backgrounds, width, height,
-                tile_w, tile_h, channels, absgrad, vsplat_holder=None, post_background=None, grad_leaf=None):
+                tile_w, tile_h, channels, absgrad, vsplat_holder=None, post_background=None, grad_leaf=None,
+                tile_order=None):
         lib = L.load()
         ctx.set_materialize_grads(False)
         ctx.vsplat_holder = vsplat_holder
@@ -573,7 +574,9 @@ class _Composite(torch.autograd.Function):
                 post.depth, post.tile_dmax = post_depth.data_ptr(), dmax.data_ptr()
         L.check(lib.qed_composite_fwd(C, N, L.ptr(splats), L.ptr(flatten_ids), L.ptr(offsets), width, height, tile_w,
                                       tile_h, channels, L.ptr(bg), L.ptr(render), L.ptr(alpha), L.ptr(t_final),
-                                      L.ptr(last_ids), L.ptr(tile_cost), C_byref(post), L.composite_launch_flags(), _stream()),
+                                      L.ptr(last_ids), L.ptr(tile_cost),
+                                      L.ptr(tile_order) if (tile_order is not None and tile_order.numel() == C * tile_w * tile_h + 1)
+                                      else None, C_byref(post), L.composite_launch_flags(), _stream()),
                 "qed_composite_fwd")
         ctx.tile_cost = tile_cost
         ctx.save_for_backward(splats, flatten_ids, offsets, alpha, last_ids, bg, render if post is not None else None, pbg,
@@ -653,7 +656,7 @@ class _Composite(torch.autograd.Function):
         if absgrad:
             # gsplat convention (absgrad=True at model.py:284): the densifier reads means2d.absgrad
             (leaf if leaf is not None else ctx.means2d_ref).absgrad = v3[..., 2:4]
-        return (v_means2d, v_conics, v_rgb_g, v_opac, v_depths) + (None,) * 13
+        return (v_means2d, v_conics, v_rgb_g, v_opac, v_depths) + (None,) * 14
 
 
 def C_byref(struct):
@@ -673,7 +676,7 @@ def rasterization(
     backgrounds: Optional[Tensor] = None, _flags: int = 0, _sh_rest: Optional[Tensor] = None,
     _sync: bool = True, _vsplat_holder: Optional[list] = None, _c2w: Optional[Tuple[Tensor, Tensor]] = None,
     _post_background: Optional[Tensor] = None, _means2d_leaf: bool = False, _capture_slot=None,
-    _manual: Optional[list] = None, _lazy_sh=None,
+    _manual: Optional[list] = None, _lazy_sh=None, _tile_order: Optional[Tensor] = None,
 ) -> Tuple[Tensor, Tensor, Dict]:
     """Same call surface as the reference's call (model.py:267-288).
 
@@ -753,10 +756,10 @@ def rasterization(
     if _means2d_leaf and wants_grad:
         means2d_out = means2d.detach().requires_grad_(True)
         grad_leaf = [means2d_out]
-    outs = _run_node(_Composite, _manual, (wants_grad,) * 5 + (False,) * 13,
+    outs = _run_node(_Composite, _manual, (wants_grad,) * 5 + (False,) * 14,
                      means2d, conics, rgb, opac, depths if channels == 4 else None, splats, flatten_ids, offsets,
                      backgrounds, int(width), int(height), tile_w, tile_h, channels, bool(absgrad), _vsplat_holder,
-                     _post_background, grad_leaf)
+                     _post_background, grad_leaf, _tile_order)
     render, alpha, last_ids = outs[:3]
     info = {
         "camera_ids": None, "gaussian_ids": None,

@@ -41,7 +41,7 @@ def test_host_only_entry_points(lib):
     from qed_splatter_amd import _lib
     header = open(HEADER).read()
     declared = int(re.search(r"#define\s+QED_ABI_VERSION\s+(\d+)", header).group(1))
-    assert lib.qed_version() == declared == _lib.ABI_VERSION == 2
+    assert lib.qed_version() == declared == _lib.ABI_VERSION == 3
     # workspace sizing is pure host arithmetic: monotone, and enough for 256 counters per block
     a, b = lib.qed_sort_workspace_bytes(1), lib.qed_sort_workspace_bytes(10_000_000)
     assert 0 < a < b and b >= 256 * 4 * (10_000_000 // 2048)
@@ -50,7 +50,7 @@ def test_host_only_entry_points(lib):
 
 def test_argument_validation_needs_no_gpu(lib):
     """Invalid arguments are rejected on the host before any launch, with a readable message."""
-    rc = lib.qed_composite_fwd(1, 0, 0, 0, 0, 64, 64, 4, 4, 5, 0, 0, 0, 0, 0, 0, 0, 0, 0)   # channels = 5
+    rc = lib.qed_composite_fwd(1, 0, 0, 0, 0, 64, 64, 4, 4, 5, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)   # channels = 5
     assert rc == -1 and b"channels" in lib.qed_last_error()
     rc = lib.qed_sort_pairs(0, 0, 0, 0, 0, 100, 0, 0, 0, 0, 0)                     # end_bit = 0
     assert rc == -1 and b"end_bit" in lib.qed_last_error()

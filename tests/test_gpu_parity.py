@@ -1546,7 +1546,7 @@ def test_backward_tile_order_is_costliest_first_and_changes_no_gradient(cuda, li
     cost = torch.full((T, 4), -7, dtype=torch.int32, device=cuda)
     st = _stream()
     L.check(lib.qed_composite_fwd(1, n, L.ptr(splats), L.ptr(fid), L.ptr(offs), w, h, tw, th, 4, None, L.ptr(render),
-                                  L.ptr(alpha), None, L.ptr(last), L.ptr(cost), None, 0, st), "fwd")
+                                  L.ptr(alpha), None, L.ptr(last), L.ptr(cost), None, None, 0, st), "fwd")
     c = cost.sum(dim=1).cpu()
     assert int(cost.min()) >= 0 and int(c.sum()) > 0                  # every tile's entry was written
     lens = (offs[1:] - offs[:-1]).cpu()
@@ -1554,7 +1554,7 @@ def test_backward_tile_order_is_costliest_first_and_changes_no_gradient(cuda, li
     # the same image with and without the cost output
     r2 = torch.empty_like(render)
     L.check(lib.qed_composite_fwd(1, n, L.ptr(splats), L.ptr(fid), L.ptr(offs), w, h, tw, th, 4, None, L.ptr(r2),
-                                  L.ptr(alpha), None, L.ptr(last), None, None, 0, st), "fwd")
+                                  L.ptr(alpha), None, L.ptr(last), None, None, None, 0, st), "fwd")
     assert torch.equal(r2, render)
     g = torch.Generator().manual_seed(4)
     v_r = torch.randn(1, h, w, 4, generator=g).to(cuda)
@@ -1617,6 +1617,20 @@ def test_backward_tile_order_is_costliest_first_and_changes_no_gradient(cuda, li
     with pytest.raises(L.QedSplatError):                               # the two buffers go together
         L.check(lib.qed_composite_bwd(1, n, L.ptr(splats), L.ptr(fid), L.ptr(offs), w, h, tw, th, 4, None, L.ptr(alpha),
                                       None, L.ptr(last), L.ptr(v_r), L.ptr(v_a), L.ptr(outs[0]), L.ptr(cost), None, None, 0, st), "bwd")
+    # the FORWARD kernel under a handed-in order (an earlier frame's backward order of the same camera, or any other
+    # permutation of the tiles): images, alphas, last ids and transmittances bit for bit those of the plain launch
+    tfin0 = torch.empty(1, h, w, device=cuda)
+    L.check(lib.qed_composite_fwd(1, n, L.ptr(splats), L.ptr(fid), L.ptr(offs), w, h, tw, th, 4, None, L.ptr(render),
+                                  L.ptr(alpha), L.ptr(tfin0), L.ptr(last), L.ptr(cost), None, None, 0, st), "fwd")
+    perm = torch.cat([torch.randperm(T, generator=g), torch.tensor([T // 16])]).to(torch.int32).to(cuda)
+    for order_in in (order2, perm):
+        r3, a3 = torch.full_like(render, -1.0), torch.full_like(alpha, -1.0)
+        l3, t3 = torch.full_like(last, -1), torch.full_like(tfin0, -1.0)
+        c3 = torch.full_like(cost, -7)
+        L.check(lib.qed_composite_fwd(1, n, L.ptr(splats), L.ptr(fid), L.ptr(offs), w, h, tw, th, 4, None, L.ptr(r3),
+                                      L.ptr(a3), L.ptr(t3), L.ptr(l3), L.ptr(c3), L.ptr(order_in), None, 0, st), "fwd, ordered")
+        assert torch.equal(r3, render) and torch.equal(a3, alpha) and torch.equal(l3, last) and torch.equal(t3, tfin0)
+        assert int(c3.min()) >= 0                                      # every tile's cost entry written
 
 
 def test_fused_step_hands_the_backward_its_tile_order(cuda):
@@ -1646,6 +1660,22 @@ def test_fused_step_hands_the_backward_its_tile_order(cuda):
     assert bool((key[1:] <= key[:-1]).all())
     assert all(model.gauss_params[k].grad is not None and bool(torch.isfinite(model.gauss_params[k].grad).all())
                for k in PARAM_NAMES if k != "features_rest")
+    # frame_key: the camera's persistent order buffer -- written by a frame's loss launch, read by the NEXT frame's
+    # compositing forward.  A scheduling hint only: the same losses bit for bit, the same gradients up to the atomics' order
+    ref = {k: model.gauss_params[k].grad.detach().clone() for k in PARAM_NAMES if k != "features_rest"}
+    loss_ref = float(out["loss"])
+    for rep in range(3):
+        for p in model.parameters():
+            p.grad = None
+        o2 = model.fused_loss(cam, batch, frame_key="cam 7")
+        slot = model._frame_orders[("cam 7", h, w)]
+        node2 = o2["loss"].grad_fn.next_functions[0][0]
+        assert node2.vsplat_holder[0]["order_ws"] is slot[0] and slot[1]
+        model.backward_fused(o2)
+        assert float(o2["loss"]) == loss_ref
+        for k, r in ref.items():
+            assert_close(model.gauss_params[k].grad, r, 2e-5, f"frame_key rep {rep}: grad {k}")
+    assert sorted(slot[0][:T].cpu().tolist()) == list(range(T))
 
 
 @pytest.mark.parametrize("tight", [True, False])
