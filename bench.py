@@ -259,7 +259,9 @@ def api_path_ms(args, sc, dev, optimizer: str, separate_params: bool = False, ho
     model.step = 30000
     model.train()
     K = sc["Ks"][0].cpu()
-    cam = PinholeCameras(sc["camera_to_worlds"], float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), w, h)
+    # (Nerfstudio's datamanager hands the camera index along: the model keeps the compositing forward's launch order per camera)
+    cam = PinholeCameras(sc["camera_to_worlds"], float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), w, h,
+                         metadata={"cam_idx": 0})
     batch = {"image": sc["gt_rgb"].contiguous(), "depth_image": sc["gt_depth"].contiguous()}
     cls = QedAdam if optimizer == "qed" else torch.optim.Adam
     lrs = FlatAdam.DEFAULT_LRS                                   # = config.py:44-68

@@ -972,6 +972,13 @@ class QEDSplatterModel(nn.Module):
         background = self._get_background_color()
         holder: list = []         # (get_loss_dict's backward launch leaves the compositing backward's zeroed accumulator here)
 
+        # the camera's launch-order slot (fused_loss: frame_key): the reference's trainer hands the camera index in
+        # camera.metadata["cam_idx"]; only on the eager route -- a captured segment is replayed for every camera
+        frame_slot = None
+        meta = getattr(camera, "metadata", None)
+        if self.training and torch.is_grad_enabled() and meta is not None and "cam_idx" in meta and crop_ids is None:
+            frame_slot = self._frame_order_slot(meta["cam_idx"], H, W)
+
         def render_fn(c2w, intr, bg, hold, capture_slot=None, viewmats=None, Ks=None, manual=None):
             """The rasterization(...) call of model.py:267-288 (+ the statements that follow it, inside the compositing
             kernels): here on this call's tensors, and -- once the shape has been seen a few times -- captured on static
@@ -1010,6 +1017,7 @@ class QEDSplatterModel(nn.Module):
                 _manual=manual,
                 # (a captured backward pass always writes the compact form; _SegmentFn.backward asks per replay)
                 _lazy_sh=self._lazy_sh_begin if (lazy and manual is None) else None,
+                _tile_order=frame_slot if (manual is None and capture_slot is None) else None,
             )
 
         seg = None
@@ -1213,6 +1221,18 @@ class QEDSplatterModel(nn.Module):
         losses["loss"].backward(gradient=_unit_grad(losses["loss"].device))
 
     # ---- fused training step: model.py:199-321 + 73-118 in as few passes as possible ----
+    def _frame_order_slot(self, frame_key, H: int, W: int) -> list:
+        """[order buffer [tiles + 1] int32, holds-an-order flag] of camera ``frame_key`` at this resolution: the launch order
+        a frame's compositing backward is given (from that frame's per-tile work counts), which the NEXT frame of the same
+        camera hands its compositing forward.  Persistent, so that a captured step replays against it."""
+        tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        orders = self.__dict__.setdefault("_frame_orders", {})
+        slot = orders.get((frame_key, H, W))
+        if slot is None or slot[0].device != self.device:
+            slot = [torch.empty(tiles + 1, dtype=torch.int32, device=self.device), False]
+            orders[(frame_key, H, W)] = slot
+        return slot
+
     def fused_loss(self, camera, batch, background: Optional[Tensor] = None, sync: bool = True,
                    compact_sh_grad: bool = False, optimizer: Optional["FlatAdam"] = None,
                    frame_key=None) -> Dict[str, Tensor]:
@@ -1280,12 +1300,7 @@ class QEDSplatterModel(nn.Module):
         # loss launch, read by the next frame's compositing forward -- persistent, so that a captured step replays against it
         frame_slot, frame_order, frame_order_valid = None, None, False
         if frame_key is not None:
-            tiles = ((W + 15) // 16) * ((H + 15) // 16)
-            orders = self.__dict__.setdefault("_frame_orders", {})
-            frame_slot = orders.get((frame_key, H, W))
-            if frame_slot is None or frame_slot[0].device != self.device:
-                frame_slot = [torch.empty(tiles + 1, dtype=torch.int32, device=self.device), False]
-                orders[(frame_key, H, W)] = frame_slot
+            frame_slot = self._frame_order_slot(frame_key, H, W)
             frame_order, frame_order_valid = frame_slot[0], frame_slot[1]
         # ``optimizer`` (a FlatAdam stepped with device_state=True, fused_sh=True right after this step's backward): the
         # loss pass's fold launch advances its device step state, so that the optimiser needs no launch of its own for it

@@ -548,6 +548,12 @@ class _Composite(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.vsplat_holder = vsplat_holder
         ctx.grad_leaf = grad_leaf[0] if grad_leaf else None      # (in a list: not an autograd input)
+        # tile_order: a launch order for THIS kernel from an earlier frame of the same camera -- a tensor, or a camera's
+        # SLOT [tensor, valid] (model.py: _frame_orders): read while valid, and the backward pass below writes its own
+        # order into it for the next frame
+        ctx.order_slot = tile_order if isinstance(tile_order, list) else None
+        if ctx.order_slot is not None:
+            tile_order = ctx.order_slot[0] if ctx.order_slot[1] else None
         C, N = opac.shape
         dev = opac.device
         render = torch.empty(C, height, width, channels, dtype=torch.float32, device=dev)
@@ -633,8 +639,15 @@ class _Composite(torch.autograd.Function):
         flags = L.composite_launch_flags()
         if order_ws is not None and tile_cost is not None and order_ws.numel() == C * tile_w * tile_h + 1 and (flags & 3) == 0:
             flags |= L.CL_ORDER_READY
+        elif tile_cost is not None:
+            slot = ctx.order_slot
+            if slot is not None and slot[0].numel() == C * tile_w * tile_h + 1 and (flags & 3) == 0:
+                order_ws = slot[0]              # the camera's persistent buffer: the next frame's forward pass reads it
+                slot[1] = True
+            else:
+                order_ws = torch.empty(C * tile_w * tile_h + 1, dtype=torch.int32, device=dev)
         else:
-            order_ws = torch.empty(C * tile_w * tile_h + 1, dtype=torch.int32, device=dev) if tile_cost is not None else None
+            order_ws = None
         L.check(lib.qed_composite_bwd(C, N, L.ptr(splats), L.ptr(flatten_ids), L.ptr(offsets), width, height, tile_w,
                                       tile_h, channels, L.ptr(bg), L.ptr(alpha), L.ptr(t_final), L.ptr(last_ids),
                                       L.ptr(v_render) if post is None else None, L.ptr(v_alpha) if post is None else None,

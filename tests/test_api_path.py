@@ -1294,3 +1294,33 @@ def test_lazy_sh_gradients_read_as_the_full_gradients(cuda):
     for _ in range(3):
         _reference_sequence(m2, cam, batch, opts2)
         assert m2.__dict__.get("_lazy_sh") is None and _raw_grad(m2.gauss_params["features_rest"]) is not None
+
+
+def test_camera_index_keeps_a_launch_order_per_camera_and_changes_no_result(cuda):
+    """The reference's trainer hands the camera index in camera.metadata["cam_idx"]: on the eager route the model keeps one
+    launch-order slot per camera -- the compositing backward writes its costliest-first order into it, the next frame of
+    that camera hands it to the compositing forward.  A scheduling hint: outputs, losses and gradients are those of a
+    camera without an index."""
+    sc = scene(6000, 320, 208, seed=12)
+    m, cam, batch = _model(sc, cuda, graph_segments=False)
+    m.train()
+
+    def step(camera):
+        for p in m.parameters():
+            p.grad = None
+        out = m.get_outputs(camera)
+        ld = m.get_loss_dict(out, batch)
+        (ld["main_loss"] + ld["depth_loss"]).backward()
+        return out["rgb"].detach().clone(), float(ld["main_loss"]), {k: m.gauss_params[k].grad.detach().clone() for k in PARAM_NAMES}
+
+    rgb0, l0, g0 = step(cam)
+    assert not m.__dict__.get("_frame_orders")
+    cam.metadata = {"cam_idx": 3}
+    T = ((320 + 15) // 16) * ((208 + 15) // 16)
+    for rep in range(3):
+        rgb1, l1, g1 = step(cam)
+        slot = m._frame_orders[(3, 208, 320)]
+        assert slot[1] and sorted(slot[0][:T].cpu().tolist()) == list(range(T))       # written by the backward pass
+        assert torch.equal(rgb1, rgb0) and l1 == l0                                   # (rep >= 1: the forward pass used it)
+        for k in PARAM_NAMES:
+            assert_close(g1[k], g0[k], 2e-5, f"rep {rep}: grad {k}")
