@@ -258,8 +258,21 @@ __global__ void loss_finalize_kernel(int n_pix, int n_blocks, int has_depth, flo
 #ifndef QED_K7_WAVES
 #define QED_K7_WAVES 4                                    // waves per SIMD the compositing backward is built for
 #endif
-constexpr int kCostBuckets = 4096;
-constexpr int kOrderLdsInts = kCostBuckets + 16 + 2;      // LDS a caller provides: histogram, wave totals, the 64-bit total
+// XCD-aware (round 5): workgroups are dealt round-robin over the 8 XCDs, each with an L2 of its own, and a tile's neighbours
+// read largely the same splat records.  A plain cost order scatters neighbours over all XCDs (both compositing kernels then
+// fetch ~3x the bytes of a raster-order launch).  So the image is cut into 8 REGIONS of consecutive tiles, every region's
+// tiles are sorted by cost on their own, and the regions are interleaved in step with the block index: position p holds
+// the next costliest tile of region (p + 3 n_split) mod 8 -- the XCD that runs block p.  Each XCD's working set is then one
+// region's records (3 MB of 24 at config B: it fits the 4 MB L2), and every XCD still works costliest-first.  The few
+// tiles by which the regions' sizes differ go to the very end.  Measured at config B against the plain cost order
+// (scripts/xcd_order_ab.py): K7 237 us against 245, K6 108 against 110.
+// Cost resolution: 256 buckets of 16 per region.
+constexpr int kCostShift = 4;                             // cost units per bucket = 16
+constexpr int kCostBuckets = 256;
+constexpr int kCostClip = (kCostBuckets << kCostShift) - 1;          // 4095
+constexpr int kOrderRegions = 8;
+constexpr int kOrderCells = kCostBuckets * kOrderRegions;            // (bucket, region) cells
+constexpr int kOrderLdsInts = 2 * kOrderCells + 16 + 2 + 6 * kOrderRegions + 2;   // cell bases, cell tickets, wave totals, total, per-region words
 struct TileOrderJob {
     const int* cost4;       // [n_tiles][4] (NULL: no job)
     int n_tiles;
@@ -273,19 +286,28 @@ inline int max_split_tiles(long long grid) { return (int)(grid / 8); }
 
 template <int NT>
 __device__ __forceinline__ void tile_order_body(const TileOrderJob& job, int* __restrict__ lds) {
-    static_assert(NT % 64 == 0 && NT <= 1024 && kCostBuckets % NT == 0, "workgroup size");
+    static_assert(NT % 64 == 0 && NT <= 1024 && NT >= kCostBuckets, "workgroup size");
     constexpr int kRegs = 8;                              // tiles per thread held in registers between the passes: all of 1080p's
                                                           // 8 160 for the 1 024-thread launch, the first 2 048 for a 256-thread passenger
-    constexpr int kPer = kCostBuckets / NT;               // histogram counts per thread in the scan
-    int* hist = lds;
-    int* wave_tot = lds + kCostBuckets;
-    long long* total_s = reinterpret_cast<long long*>(lds + kCostBuckets + 16);
+    constexpr int R = kOrderRegions;
+    int* cnt = lds;                                       // [bucket][region]: tiles, then the cell's first rank inside its region
+    int* tick = lds + kOrderCells;                        // [bucket][region] tickets handed out in the placement pass
+    int* wave_tot = lds + 2 * kOrderCells;                // [16]
+    long long* total_s = reinterpret_cast<long long*>(wave_tot + 16);
+    int* reg_tot = wave_tot + 18;                         // [R] tiles of the region
+    int* reg_heavy = reg_tot + R;                         // [R] of them above the split threshold
+    int* reg_head = reg_heavy + R;                        // [R] first head position of the region's heavy tiles
+    int* reg_i0 = reg_head + R;                           // [R] first interleaved position of the region
+    int* reg_left = reg_i0 + R;                           // [R] first position of the region's left-over tiles
+    int* misc = reg_left + R;                             // [0] n_split, [1] interleaved rounds (the smallest region's size)
     const int* __restrict__ cost4 = job.cost4;
     int* __restrict__ order = job.order;
     const int n_tiles = job.n_tiles;
+    const int per = (n_tiles + R - 1) / R;                                       // tiles per region
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     auto cost_of = [&](int i) { const int4 c4 = reinterpret_cast<const int4*>(cost4)[i]; return c4.x + c4.y + c4.z + c4.w; };
-    auto bucket_of = [](int c) { return kCostBuckets - 1 - min(c, kCostBuckets - 1); };          // bucket 0 = the costliest
+    auto bucket_of = [](int c) { return kCostBuckets - 1 - (min(c, kCostClip) >> kCostShift); };   // bucket 0 = the costliest
+    auto region_of = [&](int i) { return min(i / per, R - 1); };
     // the first 8 NT tiles stay in registers between the two passes: their loads are requested together, one memory round
     // trip; the rest are re-read from L2 in the second pass
     int creg[kRegs];
@@ -294,48 +316,82 @@ __device__ __forceinline__ void tile_order_body(const TileOrderJob& job, int* __
         const int i = tid + NT * j;
         creg[j] = cost_of(i < n_tiles ? i : 0);
     }
-    for (int i = tid; i < kCostBuckets; i += NT) hist[i] = 0;
+    for (int i = tid; i < 2 * kOrderCells; i += NT) lds[i] = 0;
     if (tid == 0) total_s[0] = 0;
     __syncthreads();
     long long mine = 0;
 #pragma unroll
     for (int j = 0; j < kRegs; ++j)
-        if (tid + NT * j < n_tiles) { mine += creg[j]; atomicAdd(&hist[bucket_of(creg[j])], 1); }
+        if (tid + NT * j < n_tiles) { mine += creg[j]; atomicAdd(&cnt[bucket_of(creg[j]) * R + region_of(tid + NT * j)], 1); }
     for (int i = tid + NT * kRegs; i < n_tiles; i += NT) {
         const int c = cost_of(i);
         mine += c;
-        atomicAdd(&hist[bucket_of(c)], 1);
+        atomicAdd(&cnt[bucket_of(c) * R + region_of(i)], 1);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
     if (lane == 0) atomicAdd((unsigned long long*)total_s, (unsigned long long)mine);
     __syncthreads();
-    // exclusive scan of the 4096 counts: kPer per thread, wave scan, wave totals
-    int c[kPer], sum = 0;
-#pragma unroll
-    for (int j = 0; j < kPer; ++j) { c[j] = hist[kPer * tid + j]; sum += c[j]; }
-    int x = sum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-    if (lane == 63) wave_tot[wid] = x;
-    __syncthreads();
-    int base = x - sum;
-    for (int w = 0; w < wid; ++w) base += wave_tot[w];
-    // n_split: tiles in the buckets above the threshold (threshold in cost units -> bucket index)
+    // threshold of the split (in cost units -> bucket index): buckets [0, first_light) hold cost > thr
     const float per_slot = (float)total_s[0] / (float)max(job.slots, 1);
-    const int thr = (int)fminf(job.split_factor * per_slot, (float)(kCostBuckets - 1));
-    const int first_light = kCostBuckets - 1 - thr;       // buckets [0, first_light) hold cost > thr
+    const int thr = (int)fminf(job.split_factor * per_slot, (float)kCostClip);
+    const int first_light = kCostBuckets - 1 - (thr >> kCostShift);
+    // per region: exclusive scan of its 256 bucket counts (thread b < 256 owns bucket b) -> the cell's first rank in the region
+    for (int x = 0; x < R; ++x) {
+        const int v = tid < kCostBuckets ? cnt[tid * R + x] : 0;
+        int sc = v;
 #pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-        if (kPer * tid + j == first_light) order[n_tiles] = min(base, job.max_split);
-        hist[kPer * tid + j] = base;
-        base += c[j];
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(sc, o, 64); if (lane >= o) sc += y; }
+        if (lane == 63) wave_tot[wid] = sc;
+        __syncthreads();
+        int base = sc - v;
+        for (int w = 0; w < wid; ++w) base += wave_tot[w];
+        if (tid < kCostBuckets) {
+            cnt[tid * R + x] = base;
+            if (tid == first_light) reg_heavy[x] = base;                         // tiles of the region in heavier buckets
+            if (tid == kCostBuckets - 1) reg_tot[x] = base + v;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int heavy = 0;
+        for (int x = 0; x < R; ++x) heavy += reg_heavy[x];
+        // (more "heavy" tiles than the launch may split: a flat cost distribution -- nothing is split)
+        const int ns = heavy <= job.max_split ? heavy : 0;
+        if (ns == 0) for (int x = 0; x < R; ++x) reg_heavy[x] = 0;
+        int head = 0, rounds = 0x7fffffff;
+        for (int x = 0; x < R; ++x) {
+            reg_head[x] = head;
+            head += reg_heavy[x];
+            rounds = min(rounds, reg_tot[x] - reg_heavy[x]);
+        }
+        int left = ns + R * rounds;
+        for (int x = 0; x < R; ++x) {
+            // block of position p = p + 3 ns, on XCD (p + 3 ns) mod 8: the region's first position at or behind ns
+            reg_i0[x] = ns + ((x - 4 * ns) & (R - 1));
+            reg_left[x] = left;
+            left += reg_tot[x] - reg_heavy[x] - rounds;
+        }
+        misc[0] = ns;
+        misc[1] = rounds;
+        order[n_tiles] = ns;
     }
     __syncthreads();
+    const int rounds = misc[1];
+    auto place = [&](int i, int c) {
+        const int cell = bucket_of(c) * R + region_of(i), x = region_of(i);
+        const int k = cnt[cell] + atomicAdd(&tick[cell], 1);                     // rank inside the region, costliest first
+        const int h = reg_heavy[x];
+        int pos;
+        if (k < h) pos = reg_head[x] + k;                                        // one of the split tiles: the head of the order
+        else if (k - h < rounds) pos = reg_i0[x] + R * (k - h);                  // interleaved with the other regions
+        else pos = reg_left[x] + (k - h - rounds);                               // the tiles by which this region is larger
+        order[pos] = i;
+    };
 #pragma unroll
     for (int j = 0; j < kRegs; ++j)
-        if (tid + NT * j < n_tiles) order[atomicAdd(&hist[bucket_of(creg[j])], 1)] = tid + NT * j;
-    for (int i = tid + NT * kRegs; i < n_tiles; i += NT) order[atomicAdd(&hist[bucket_of(cost_of(i))], 1)] = i;
+        if (tid + NT * j < n_tiles) place(tid + NT * j, creg[j]);
+    for (int i = tid + NT * kRegs; i < n_tiles; i += NT) place(i, cost_of(i));
 }
 
 // ---- pass 1 of the fused image loss (loss.hip's loss_reduce_kernel; ssim.hip carries it as passenger workgroups of the

@@ -1570,12 +1570,27 @@ def test_backward_tile_order_is_costliest_first_and_changes_no_gradient(cuda, li
     torch.cuda.synchronize()
     order, n_split = order_ws[:T].cpu().long(), int(order_ws[T])
     assert sorted(order.tolist()) == list(range(T))                    # a permutation of the tiles
-    key = c.clamp(max=4095)[order]
-    assert bool((key[1:] <= key[:-1]).all())                           # costliest first (cost clipped at 4095)
+    cb = c.clamp(max=4095) >> 4                                        # cost buckets of 16 (clipped at 4095)
+    key = cb[order]
     slots = torch.cuda.get_device_properties(cuda).multi_processor_count * 4 * 4
     per_slot = float(c.sum()) / slots
-    want_split = min(int((c.clamp(max=4095) > int(min(per_slot, 4095.0))).sum()), T // 8)
+    heavy = cb > (int(min(per_slot, 4095.0)) >> 4)
+    want_split = int(heavy.sum()) if int(heavy.sum()) <= T // 8 else 0    # (more than the launch may split: nothing is)
     assert n_split == want_split, (n_split, want_split, per_slot)
+    assert bool(heavy[order[:n_split]].all()) and (n_split == 0 or not bool(heavy[order[n_split:]].any()))
+    # behind the split tiles: 8 regions of consecutive tiles, each costliest-first on its own, interleaved in step with the
+    # block index (block of position p = p + 3 n_split, dealt to XCD block % 8); the tiles by which the regions' sizes
+    # differ come last
+    per_region = (T + 7) // 8
+    region = torch.clamp(order // per_region, max=7)
+    for x in range(8):
+        kx = key[n_split:][region[n_split:] == x]
+        assert bool((kx[1:] <= kx[:-1]).all()), x                      # costliest bucket first inside every region
+    sizes = torch.bincount(region[n_split:], minlength=8)
+    rounds = int(sizes.min())
+    pos = torch.arange(T)
+    inter = slice(n_split, n_split + 8 * rounds)
+    assert bool((((pos + 3 * n_split) % 8) == region)[inter].all())    # every interleaved position holds its XCD's region
     scale = float(outs[0].abs().max())
     assert scale > 0 and float((outs[0] - outs[1]).abs().max()) <= 2e-5 * scale
     # the same order as a PASSENGER of the SSIM forward launch (the fused training step: qed_ssim_fwd_step), handed to the
@@ -1606,7 +1621,7 @@ def test_backward_tile_order_is_costliest_first_and_changes_no_gradient(cuda, li
     assert torch.equal(sums0, sums1)                                   # the passenger IS qed_loss_reduce, slot for slot
     o2 = order2[:T].cpu().long()
     assert sorted(o2.tolist()) == list(range(T)) and int(order2[T]) == n_split
-    assert torch.equal(c.clamp(max=4095)[o2], key)                     # (the order inside a cost bucket is free)
+    assert torch.equal(cb[o2], key)                                    # (the order inside a cost bucket is free)
     vs = torch.zeros(n, L.VSPLAT_FLOATS, device=cuda)
     poison = order2.clone()
     L.check(lib.qed_composite_bwd(1, n, L.ptr(splats), L.ptr(fid), L.ptr(offs), w, h, tw, th, 4, None, L.ptr(alpha),
@@ -1653,11 +1668,8 @@ def test_fused_step_hands_the_backward_its_tile_order(cuda):
     model.backward_fused(out)
     assert node.order_ws is handed                                     # taken over, not recomputed
     T = node.tile_cost.shape[0]
-    c = node.tile_cost.sum(dim=1).cpu().clamp(max=4095)
     order = handed[:T].cpu().long()
     assert sorted(order.tolist()) == list(range(T))
-    key = c[order]
-    assert bool((key[1:] <= key[:-1]).all())
     assert all(model.gauss_params[k].grad is not None and bool(torch.isfinite(model.gauss_params[k].grad).all())
                for k in PARAM_NAMES if k != "features_rest")
     # frame_key: the camera's persistent order buffer -- written by a frame's loss launch, read by the NEXT frame's
