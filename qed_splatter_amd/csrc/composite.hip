@@ -565,7 +565,8 @@ composite_fwd_kernel(int C, const float4* __restrict__ splats, const int* __rest
         // kernel cannot know its costs in advance -- the list length does not predict them, corr -0.02 at config B).  As in
         // composite_bwd_kernel: the n_split heaviest tiles as four quadrant waves each ahead of everything, then whole tiles
         // in order of decreasing cost.  Any permutation gives the same image; a poor predictor only costs time.
-        // Measured at config B (scripts/k6_order_ab.py): 114-117 us against 122-126 with the raster order + quadrant tail.
+        // Measured at config B (scripts/xcd_order_ab.py, profiles/r05_bench_kernel_stats_v6.txt): 108-111 us static, 119 in the
+        // training run, against 122-126 / 129-133 with the raster order + quadrant tail.
         const int n_split = min(max(tile_order[n_total], 0), n_total / 8);
         if (b < 4 * n_split) {
             fwd_tile<CH, 1>(min(max(tile_order[b >> 2], 0), n_total - 1), (b & 3) | keep_all, s_rec, C, splats, flatten_ids, offsets,
