@@ -61,7 +61,8 @@ def main():
         model.step = 10_000 + step
         for p in model.parameters():
             p.grad = None
-        losses = model.fused_loss(cam, batch, compact_sh_grad=True)
+        # (frame_key: the camera's index -- the compositing forward reuses the launch order of this camera's last frame)
+        losses = model.fused_loss(cam, batch, compact_sh_grad=True, frame_key=0)
         model.backward_fused(losses)
         opt.step(fused_sh=True)       # SH-coefficient gradients expanded inside the Adam pass
         dens.after_train(step)

@@ -50,10 +50,11 @@ for step in range(steps):
     for p in model.parameters():
         p.grad = None
     try:
-        losses = model.fused_loss(cams[c], batches[c], sync=(step % 100 == 0), compact_sh_grad=True)     # async between refinements
+        losses = model.fused_loss(cams[c], batches[c], sync=(step % 100 == 0), compact_sh_grad=True,
+                                  frame_key=c)     # async between refinements; the camera index keeps a launch order per camera
     except L.QedSplatError as e:                                                       # async overflow protocol
         print(f"step {step}: {e}")
-        losses = model.fused_loss(cams[c], batches[c], sync=True, compact_sh_grad=True)
+        losses = model.fused_loss(cams[c], batches[c], sync=True, compact_sh_grad=True, frame_key=c)
     model.backward_fused(losses)
     opt.step(fused_sh=True)
     dens.after_train(step)
